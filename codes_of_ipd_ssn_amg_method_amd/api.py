@@ -1,0 +1,378 @@
+"""Host-side mirror of the reference's MATLAB function signatures.
+
+Same names, argument meaning and error behaviour as the reference's ``.m``
+files; every call goes through the C ABI of libipdamg.so
+(hand-written HIP, gfx950).  MATLAB itself is not available in this pipeline,
+so this Python layer plays the role of the MEX gateway for tests and benches;
+the gateway a MATLAB maintainer would compile is ``mex/ipd_mex.cpp``.
+
+Differences forced by the host language, all documented in INTEGRATION.md:
+ * indices are 0-based;
+ * functions that consume MATLAB's global ``rand`` stream take a ``rng``
+   argument (``MatlabRand``; seed 5489 reproduces MATLAB's default stream);
+ * the reference's ``global Ack Prok J smoth_it Rk`` is the ``AMGHierarchy``
+   handle; ``MG_Vcycle``/``MG_Wcycle`` take it as first argument.
+"""
+from __future__ import annotations
+
+from ctypes import byref, c_double, c_int, c_int32, c_int64, c_void_p, POINTER
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib as L
+from ._lib import CscIn, IpdError, MatlabRand, bptr, check, csc_out_to_scipy, dptr, f64, get_ctx, \
+    iptr, lib, u8
+
+__all__ = [
+    "Ax", "Aty", "ASAt", "invAAt", "invHHt", "strength", "cf_split", "mis_set", "transfer",
+    "Class_AMG", "AMGHierarchy", "MG_Vcycle", "MG_Wcycle", "PCG", "components", "Hybrid_AMG",
+    "AMG4POT", "MatlabRand", "IpdError", "amg_options",
+]
+
+
+def _h():
+    return get_ctx().handle
+
+
+# ---------------------------------------------------------------------------
+# options structs
+# ---------------------------------------------------------------------------
+def amg_options(retol=None, bigph=None, maxit=None, theta=None, smoth=None, cycle=None,
+                isnsp=None, inter=None, guess=None, fnode=None) -> dict:
+    """``struct('retol',..,'bigph',..,...)`` with ``[]`` spelled ``None``."""
+    return dict(retol=retol, bigph=bigph, maxit=maxit, theta=theta, smoth=smoth, cycle=cycle,
+                isnsp=isnsp, inter=inter, guess=guess, fnode=fnode)
+
+
+def _opts_struct(o: dict | None) -> L.ipd_amg_opts:
+    s = L.ipd_amg_opts()
+    lib.ipd_amg_opts_init(byref(s))
+    if o is None:
+        # Class_AMG.m:22-23 (nargin == 2 defaults; note cycle = 1 selects no cycle)
+        o = dict(retol=1e-12, bigph=0, maxit=20, theta=1 / 4, smoth=10, cycle=1, isnsp=1, inter=1)
+    for key in ("retol", "theta"):
+        if o.get(key) is not None:
+            setattr(s, key, float(o[key]))
+    for key in ("bigph", "maxit", "smoth", "isnsp", "inter"):
+        if o.get(key) is not None:
+            setattr(s, key, int(o[key]))
+    if o.get("cycle") is not None:
+        cyc = o["cycle"]
+        s.cycle = ord(cyc) if isinstance(cyc, str) and len(cyc) == 1 else int(cyc)
+    if o.get("fnode") is not None:
+        s.fnode = int(o["fnode"])
+    return s
+
+
+# ---------------------------------------------------------------------------
+# L0 / L1
+# ---------------------------------------------------------------------------
+def Ax(x, p, q) -> np.ndarray:
+    """``y = Ax(x,p,q)`` (``Ax.m:2``)."""
+    p, q, x = f64(p), f64(q), f64(x)
+    m, n = p.size, q.size
+    if x.size != m * n:
+        raise ValueError("Ax: length(x) must be length(p)*length(q)")
+    y = np.empty(m + n)
+    check(lib.ipd_ax(_h(), dptr(x), dptr(p), dptr(q), c_int64(m), c_int64(n), dptr(y)))
+    return y
+
+
+def Aty(y, p, q) -> np.ndarray:
+    """``z = Aty(y,p,q)`` (``Aty.m:2``)."""
+    p, q, y = f64(p), f64(q), f64(y)
+    m, n = p.size, q.size
+    if y.size < m + n:
+        raise ValueError("Aty: y needs n+m entries")
+    z = np.empty(m * n)
+    check(lib.ipd_aty(_h(), dptr(y), dptr(p), dptr(q), c_int64(m), c_int64(n), dptr(z)))
+    return z
+
+
+def ASAt(s, p, q) -> sp.csc_matrix:
+    """``H = ASAt(s,p,q)`` (``ASAt.m:2``); ``s`` logical of length m*n."""
+    p, q, s = f64(p), f64(q), u8(s)
+    m, n = p.size, q.size
+    if s.size != m * n:
+        raise ValueError("ASAt: length(s) must be length(p)*length(q)")
+    out = L.ipd_csc_out()
+    check(lib.ipd_asat(_h(), bptr(s), dptr(p), dptr(q), c_int64(m), c_int64(n), byref(out)))
+    return csc_out_to_scipy(out)
+
+
+def invAAt(x, p, q, sg1=None, sg2=None) -> np.ndarray:
+    """``y = invAAt(x,p,q,sg1,sg2)`` (``invAAt.m:1``; nargin rules ``:7-12``)."""
+    if sg1 is None:
+        sg1, sg2 = 1.0, 1.0
+    elif sg2 is None:
+        sg2 = sg1
+    p, q, x = f64(p), f64(q), f64(x)
+    m, n = p.size, q.size
+    y = np.empty(m + n)
+    check(lib.ipd_inv_aat(_h(), dptr(x), dptr(p), dptr(q), c_int64(m), c_int64(n), c_double(sg1),
+                          c_double(sg2), dptr(y)))
+    return y
+
+
+def invHHt(v, p, q, sg, phi) -> np.ndarray:
+    """``y = invHHt(v,p,q,sg,phi)`` (``Class2/invHHt.m:1``)."""
+    p, q, v, phi = f64(p), f64(q), f64(v), f64(phi)
+    m, n = p.size, q.size
+    y = np.empty(m + n + 1)
+    check(lib.ipd_inv_hht(_h(), dptr(v), dptr(p), dptr(q), c_int64(m), c_int64(n), c_double(sg),
+                          dptr(phi), dptr(y)))
+    return y
+
+
+# ---------------------------------------------------------------------------
+# L2: setup pieces
+# ---------------------------------------------------------------------------
+def strength(A, which: int = 2) -> sp.csc_matrix:
+    """``S = strength(A,which)`` (``AMG/strength.m:1``)."""
+    a = CscIn(A)
+    out = L.ipd_csc_out()
+    check(lib.ipd_strength(_h(), a.ref(), c_int(which), byref(out)))
+    return csc_out_to_scipy(out)
+
+
+def cf_split(S):
+    """``[indC,indF] = cf_split(S)`` (``AMG/cf_split.m:1``)."""
+    a = CscIn(S)
+    n = a.struct.nrows
+    indC = np.zeros(n, np.uint8)
+    indF = np.zeros(n, np.uint8)
+    check(lib.ipd_cf_split(_h(), a.ref(), bptr(indC), bptr(indF)))
+    return indC.astype(bool), indF.astype(bool)
+
+
+def mis_set(A, theta: float = 0.025, rng: MatlabRand | None = None):
+    """``[isC,isF,As] = mis_set(A,theta)`` (``AMG/mis_set.m:1``)."""
+    rng = rng or MatlabRand()
+    a = CscIn(A)
+    n = a.struct.nrows
+    isC = np.zeros(n, np.uint8)
+    isF = np.zeros(n, np.uint8)
+    out = L.ipd_csc_out()
+    check(lib.ipd_mis_set(_h(), a.ref(), c_double(theta), rng.handle, bptr(isC), bptr(isF),
+                          byref(out)))
+    return isC.astype(bool), isF.astype(bool), csc_out_to_scipy(out)
+
+
+def transfer(A, amg_options: dict, level: int = 2, rng: MatlabRand | None = None):
+    """``[Ac,Pro,~,indC] = transfer(A,amg_options)`` (``AMG/transfer.m:1``);
+    ``level`` is the reference's ``global J``."""
+    rng = rng or MatlabRand()
+    a = CscIn(A)
+    o = _opts_struct(amg_options)
+    Ac, Pro = L.ipd_csc_out(), L.ipd_csc_out()
+    indC = np.zeros(a.struct.nrows, np.uint8)
+    check(lib.ipd_transfer(_h(), a.ref(), byref(o), c_int(level), rng.handle, byref(Ac),
+                           byref(Pro), bptr(indC)))
+    return csc_out_to_scipy(Ac), csc_out_to_scipy(Pro), indC.astype(bool)
+
+
+# ---------------------------------------------------------------------------
+# L3: hierarchy, cycles, PCG
+# ---------------------------------------------------------------------------
+class AMGHierarchy:
+    """Device-resident ``Ack/Prok/Rk/J`` (``AMG/Class_AMG.m:42-85``)."""
+
+    def __init__(self, A, amg_options: dict, rng: MatlabRand | None = None):
+        self.rng = rng or MatlabRand()
+        self._a = CscIn(A)
+        self.opts = dict(amg_options) if amg_options is not None else None
+        o = _opts_struct(amg_options)
+        self.handle = c_void_p()
+        check(lib.ipd_amg_setup(_h(), self._a.ref(), byref(o), self.rng.handle, byref(self.handle)))
+        self.maxit = int(o.maxit) if o.maxit >= 0 else 50
+        self.N = int(self._a.struct.nrows)
+
+    @property
+    def J(self) -> int:
+        return int(lib.ipd_amg_num_levels(self.handle))
+
+    def level_dims(self, k: int):
+        rows, nnz = c_int64(), c_int64()
+        check(lib.ipd_amg_level_dims(self.handle, c_int(k), byref(rows), byref(nnz)))
+        return int(rows.value), int(nnz.value)
+
+    def level_sizes(self):
+        return [self.level_dims(k)[0] for k in range(1, self.J + 1)]
+
+    def A(self, k: int) -> sp.csc_matrix:
+        out = L.ipd_csc_out()
+        check(lib.ipd_amg_get_A(self.handle, c_int(k), byref(out)))
+        return csc_out_to_scipy(out)
+
+    def P(self, k: int) -> sp.csc_matrix:
+        out = L.ipd_csc_out()
+        check(lib.ipd_amg_get_P(self.handle, c_int(k), byref(out)))
+        return csc_out_to_scipy(out)
+
+    def cmask(self, k: int) -> np.ndarray:
+        rows = self.level_dims(k - 1)[0]
+        m = np.zeros(rows, np.uint8)
+        check(lib.ipd_amg_get_cmask(self.handle, c_int(k), bptr(m)))
+        return m.astype(bool)
+
+    def solve(self, b, guess=None):
+        """Solve phase of Class_AMG: ``x, it, rel_res, rel_resk, rhok``."""
+        b = f64(b)
+        x = np.empty(self.N)
+        it = c_int32()
+        rel = c_double()
+        rel_resk = np.full(self.maxit + 2, np.nan)
+        rhok = np.full(self.maxit + 2, np.nan)
+        g = f64(guess) if guess is not None else None
+        check(lib.ipd_amg_solve(self.handle, dptr(b), dptr(g) if g is not None else None, dptr(x),
+                                byref(it), byref(rel), dptr(rel_resk), dptr(rhok)))
+        n = it.value + 1
+        return x, int(it.value), float(rel.value), rel_resk[:n].copy(), rhok[:n].copy()
+
+    def cycle_bytes(self) -> float:
+        v = c_double()
+        check(lib.ipd_amg_cycle_bytes(self.handle, byref(v)))
+        return float(v.value)
+
+    def close(self):
+        if self.handle:
+            lib.ipd_amg_destroy(self.handle)
+            self.handle = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def MG_Vcycle(h: AMGHierarchy, r, isnsp=0, k: int = 1) -> np.ndarray:
+    """``e = MG_Vcycle(r,isnsp,k)`` (``AMG/MG_Vcycle.m:2``); ``k`` is 1-based."""
+    r = f64(r)
+    e = np.empty(h.level_dims(k)[0])
+    check(lib.ipd_amg_vcycle(h.handle, dptr(r), c_int(int(isnsp)), c_int(k), dptr(e)))
+    return e
+
+
+def MG_Wcycle(h: AMGHierarchy, r, isnsp=0, k: int = 1, e=None) -> np.ndarray:
+    """``e = MG_Wcycle(r,isnsp,k,e)`` (``AMG/MG_Wcycle.m:2``)."""
+    r = f64(r)
+    out = np.empty(h.level_dims(k)[0])
+    ein = f64(e) if e is not None else None
+    check(lib.ipd_amg_wcycle(h.handle, dptr(r), c_int(int(isnsp)), c_int(k),
+                             dptr(ein) if ein is not None else None, dptr(out)))
+    return out
+
+
+def Class_AMG(A, b, amg_options: dict | None = None, rng: MatlabRand | None = None):
+    """``[x,it,rel_res,rel_resk,rhok] = Class_AMG(A,b,amg_options)``
+    (``AMG/Class_AMG.m:1``)."""
+    h = AMGHierarchy(A, amg_options, rng)
+    try:
+        guess = None if amg_options is None else amg_options.get("guess")
+        return h.solve(b, guess)
+    finally:
+        h.close()
+
+
+def PCG(H, e, pcg_options: dict | None = None):
+    """``[d,it,res,resk] = PCG(H,e,pcg_options)`` (``PCG.m:1``)."""
+    e = f64(e)
+    a = CscIn(H)
+    o = L.ipd_pcg_opts()
+    lib.ipd_pcg_opts_init(byref(o))
+    guess = None
+    if pcg_options is not None:
+        if pcg_options.get("retol") is not None:
+            o.retol = float(pcg_options["retol"])
+        if pcg_options.get("maxit") is not None:
+            o.maxit = int(pcg_options["maxit"])
+        if pcg_options.get("precd") is not None:
+            o.precd = int(pcg_options["precd"])
+        if pcg_options.get("guess") is not None:
+            guess = f64(pcg_options["guess"])
+    maxit = int(o.maxit) if o.maxit >= 0 else 10000
+    d = np.empty(e.size)
+    it = c_int64()
+    res = c_double()
+    resk = np.zeros(maxit)
+    check(lib.ipd_pcg(_h(), a.ref(), dptr(e), dptr(guess) if guess is not None else None, byref(o),
+                      dptr(d), byref(it), byref(res), dptr(resk)))
+    return d, int(it.value), float(res.value), resk
+
+
+# ---------------------------------------------------------------------------
+# L4
+# ---------------------------------------------------------------------------
+def components(A):
+    """``[blocks,sizes,p,r] = components(A)`` (``components.m:1``), 0-based."""
+    a = CscIn(A)
+    n = int(a.struct.nrows)
+    blocks = np.zeros(n, np.int64)
+    sizes = np.zeros(n, np.int64)
+    p = np.zeros(n, np.int64)
+    r = np.zeros(n + 1, np.int64)
+    nc = c_int64()
+    check(lib.ipd_components(_h(), a.ref(), iptr(blocks), iptr(sizes), iptr(p), iptr(r), byref(nc)))
+    k = int(nc.value)
+    return blocks, sizes[:k].copy(), p, r[:k + 1].copy()
+
+
+def _prob_struct(pd: dict, need_pot: bool):
+    keep = []
+    p, q = f64(pd["p"]), f64(pd["q"])
+    m, n = p.size, q.size
+    T = pd.get("T")
+    t = None
+    if T is not None:
+        t = f64(sp.csr_matrix(T).diagonal() if sp.issparse(T) else np.asarray(T))
+        if not np.any(t):
+            t = None
+    H0 = CscIn(pd["H0"])
+    z = f64(pd["z"])
+    s = L.ipd_prob()
+    s.m, s.n, s.bk1, s.tk = m, n, float(pd["bk1"]), float(pd["tk"])
+    s.p, s.q = dptr(p), dptr(q)
+    s.t = dptr(t) if t is not None else None
+    s.H0 = POINTER(L.ipd_csc)(H0.struct)
+    s.z = dptr(z)
+    keep += [p, q, t, H0, z]
+    if need_pot:
+        sm = u8(pd["s"])
+        phi = f64(pd["phi"])
+        s.s, s.phi = bptr(sm), dptr(phi)
+        keep += [sm, phi]
+    return s, keep, m, n
+
+
+def Hybrid_AMG(prob_data: dict, amg_options: dict, rng: MatlabRand | None = None):
+    """``[zeta,itamg,resamg,info] = Hybrid_AMG(prob_data,amg_options)``
+    (``Hybrid_AMG.m:1``)."""
+    rng = rng or MatlabRand()
+    s, keep, m, n = _prob_struct(prob_data, False)
+    o = _opts_struct(amg_options)
+    zeta = np.empty(m + n)
+    it = c_int32()
+    res = c_double()
+    info = np.zeros(2, np.int64)
+    check(lib.ipd_hybrid_amg(_h(), byref(s), byref(o), rng.handle, dptr(zeta), byref(it),
+                             byref(res), iptr(info)))
+    return zeta, int(it.value), float(res.value), info
+
+
+def AMG4POT(prob_data: dict, amg_options: dict, str_: str = "amg", rng: MatlabRand | None = None):
+    """``[zeta,itamg,resamg,info] = AMG4POT(prob_data,amg_options,str)``
+    (``Class2/AMG4POT.m:1``)."""
+    if str_ != "amg":
+        raise IpdError(L.IPD_E_UNSUPPORTED, "only the 'amg' inner solver is built (SURVEY f4)")
+    rng = rng or MatlabRand()
+    s, keep, m, n = _prob_struct(prob_data, True)
+    o = _opts_struct(amg_options)
+    zeta = np.empty(m + n + 1)
+    it = c_int32()
+    res = c_double()
+    info = np.zeros(2, np.int64)
+    check(lib.ipd_amg4pot(_h(), byref(s), byref(o), rng.handle, dptr(zeta), byref(it), byref(res),
+                          iptr(info)))
+    return zeta, int(it.value), float(res.value), info

@@ -1,0 +1,77 @@
+// Device-resident AMG hierarchy: the reference's `global Ack Prok J smoth_it Rk`
+// (AMG/Class_AMG.m:42-47) as one handle.
+#pragma once
+
+#include "ipd_internal.h"
+
+// Filled-in amg_options (Class_AMG.m:26-34 defaults applied).
+struct AmgOpts {
+    double retol = 1e-12;
+    int bigph = 0;
+    int maxit = 50;
+    double theta = 0.25;
+    int smoth = 3;
+    int cycle = 'v';
+    int isnsp = 0;
+    int inter = 1;
+    long long fnode = -1;
+};
+AmgOpts amg_fill_defaults(const ipd_amg_opts* o);
+
+struct Level {
+    int N = 0;          // rows of A
+    Csr A;              // Ack{k}
+    Csr P;              // Prok{k}   : N_{k-1} x N_k   (k >= 2; stored on the coarse level)
+    Csr Pt;             // Prok{k}'  : N_k x N_{k-1}   (restriction, CSR)
+    uint8_t* cmask = nullptr;  // isC of level k-1 (N_{k-1} bytes), k >= 2
+    // smoother Rk{k}: level 1 with bigph -> forward Gauss-Seidel on the [F|C] blocks
+    // (dinv = 1/diag, nf = fnode); otherwise weighted Jacobi (dinv = 0.5/diag, nf = 0)
+    double* dinv = nullptr;
+    int nf = 0;
+    double* Axi = nullptr;  // A*1   (MG_Vcycle.m:15)
+    double* xx = nullptr;   // device scalar 1'*A*1
+    // work vectors of the cycle
+    double* r = nullptr;    // right-hand side of this level
+    double* e = nullptr;    // iterate
+    double* e2 = nullptr;   // ping-pong partner of e
+    double* w = nullptr;    // first-half result of a Gauss-Seidel sweep (without the +c shift)
+    double* rr = nullptr;   // residual r - A e
+    double* scal = nullptr; // small device scalars (sum r, partial dots ...)
+    int lanes = 64;         // lanes per row used by the row kernels of this level
+};
+
+struct CycleState;  // ipd_cycle.hip
+
+struct ipd_amg {
+    ipd_ctx* ctx = nullptr;
+    std::shared_ptr<CycleState> cyc;  // launch geometry + partial-sum buffers
+    std::unique_ptr<Arena> arena;
+    AmgOpts opts;
+    int J = 0;
+    std::vector<Level> L;  // 1-based like the MATLAB cells; L[0] unused
+    // solve-phase buffers (level-1 sized)
+    double* x = nullptr;
+    double* b = nullptr;
+    double* res = nullptr;   // A x - b
+    double* hist = nullptr;  // device copy of [res0, res, rnorm]
+    // PCG work vectors for the coarsest level
+    double* pcg_work = nullptr;
+};
+
+// ipd_setup.hip
+void amg_strength_mask(ipd_ctx* ctx, const Csr& A, double theta, uint8_t* strong, int* degi,
+                       int* rowcnt);
+void amg_mis_set(ipd_ctx* ctx, const Csr& A, double theta, ipd_rng* rng, uint8_t* isC,
+                 uint8_t* isF, uint8_t* strong_out /*nnz bytes or NULL*/);
+void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int level,
+                  ipd_rng* rng, Csr* Ac, Csr* P, Csr* Pt, uint8_t* cmask /*A.nr bytes*/);
+ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng);
+int amg_coarsest_threshold(int N);
+
+// ipd_cycle.hip
+void amg_prepare_levels(ipd_amg* h);  // dinv, Axi, xx, work vectors
+void amg_cycle(ipd_amg* h, int k, int isnsp, bool wcycle, bool keep_e);
+void amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev, double* x_dev,
+                   int32_t* it, double* rel_res, double* rel_resk, double* rhok);
+void pcg_dev(ipd_ctx* ctx, const Csr& H, const double* e, const double* guess, double tol,
+             long long maxit, int precd, double* d, long long* it, double* res, double* resk_host);

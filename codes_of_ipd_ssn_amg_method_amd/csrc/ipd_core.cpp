@@ -1,0 +1,295 @@
+// Context, memory pools, MATLAB-compatible rand stream and the small C-ABI
+// entry points that do not launch kernels.
+#include "ipd_internal.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+static thread_local std::string g_last_error;
+
+void ipd_set_error(const std::string& msg) { g_last_error = msg; }
+
+// ---------------------------------------------------------------------------
+// ChunkPool / Arena
+// ---------------------------------------------------------------------------
+static constexpr size_t kMinChunk = size_t(64) << 20;  // 64 MiB
+static constexpr size_t kAlign = 256;
+
+ChunkPool::Chunk ChunkPool::get(size_t min_bytes) {
+    // best fit among free chunks
+    int best = -1;
+    for (int i = 0; i < (int)free_chunks.size(); ++i) {
+        if (free_chunks[i].bytes >= min_bytes &&
+            (best < 0 || free_chunks[i].bytes < free_chunks[best].bytes))
+            best = i;
+    }
+    if (best >= 0) {
+        Chunk c = free_chunks[best];
+        free_chunks.erase(free_chunks.begin() + best);
+        return c;
+    }
+    Chunk c;
+    c.bytes = std::max(kMinChunk, (min_bytes + kAlign - 1) / kAlign * kAlign);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, c.bytes);
+    if (e != hipSuccess)
+        throw IpdError(IPD_E_NOMEM, std::string("hipMalloc(") + std::to_string(c.bytes) +
+                                        "): " + hipGetErrorString(e));
+    c.base = static_cast<char*>(p);
+    total_bytes += c.bytes;
+    return c;
+}
+
+void ChunkPool::release_all() {
+    for (auto& c : free_chunks) (void)hipFree(c.base);
+    free_chunks.clear();
+}
+
+void* Arena::alloc_bytes(size_t bytes) {
+    bytes = (bytes + kAlign - 1) / kAlign * kAlign;
+    while (true) {
+        if (cur < chunks.size()) {
+            if (off + bytes <= chunks[cur].bytes) {
+                void* p = chunks[cur].base + off;
+                off += bytes;
+                return p;
+            }
+            ++cur;
+            off = 0;
+            continue;
+        }
+        chunks.push_back(pool->get(bytes));
+        cur = chunks.size() - 1;
+        off = 0;
+    }
+}
+
+void Arena::release() {
+    if (pool)
+        for (auto& c : chunks) pool->put(c);
+    chunks.clear();
+    cur = off = 0;
+}
+
+// ---------------------------------------------------------------------------
+// ipd_ctx
+// ---------------------------------------------------------------------------
+void ipd_ctx::fetch_bytes(const void* dsrc, void* hdst, size_t bytes) {
+    if (bytes == 0) return;
+    if (bytes <= pinned_bytes) {
+        IPD_HIP(hipMemcpyAsync(pinned, dsrc, bytes, hipMemcpyDeviceToHost, stream));
+        IPD_HIP(hipStreamSynchronize(stream));
+        std::memcpy(hdst, pinned, bytes);
+    } else {
+        IPD_HIP(hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, stream));
+        IPD_HIP(hipStreamSynchronize(stream));
+    }
+}
+
+void ipd_ctx::upload_bytes(void* ddst, const void* hsrc, size_t bytes) {
+    if (bytes == 0) return;
+    // The source is usually a transient pageable host buffer: complete the copy
+    // before returning so the caller may free or reuse it.
+    IPD_HIP(hipMemcpyAsync(ddst, hsrc, bytes, hipMemcpyHostToDevice, stream));
+    IPD_HIP(hipStreamSynchronize(stream));
+}
+
+extern "C" int ipd_version(void) { return IPD_VERSION; }
+
+extern "C" const char* ipd_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int ipd_ctx_create(int device, ipd_ctx** out) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(out != nullptr, IPD_E_ARG, "ipd_ctx_create: out is NULL");
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0)
+            throw IpdError(IPD_E_HIP,
+                           "no HIP device available: libipdamg has no CPU fallback "
+                           "(hipGetDeviceCount: " +
+                               std::string(hipGetErrorString(e)) + ")");
+        IPD_REQUIRE(device >= 0 && device < ndev, IPD_E_ARG, "ipd_ctx_create: bad device index");
+        IPD_HIP(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        IPD_HIP(hipGetDeviceProperties(&prop, device));
+        std::unique_ptr<ipd_ctx> c(new ipd_ctx());
+        c->device = device;
+        c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        IPD_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->scratch.reset(new Arena(&c->pool));
+        c->pinned_bytes = size_t(1) << 20;
+        IPD_HIP(hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault));
+        *out = c.release();
+    });
+}
+
+extern "C" void ipd_ctx_destroy(ipd_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ipd_comm_cleanup(ctx);
+    ctx->scratch.reset();
+    ctx->pool.release_all();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int ipd_ctx_sync(ipd_ctx* ctx) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx, IPD_E_ARG, "ctx is NULL");
+        ctx->set_device();
+        ctx->sync();
+    });
+}
+
+extern "C" void ipd_csc_free(ipd_csc_out* m) {
+    if (!m) return;
+    std::free(m->jc);
+    std::free(m->ir);
+    std::free(m->pr);
+    m->jc = m->ir = nullptr;
+    m->pr = nullptr;
+    m->nnz = m->nrows = m->ncols = 0;
+}
+
+extern "C" void ipd_amg_opts_init(ipd_amg_opts* o) {
+    if (!o) return;
+    o->retol = -1;
+    o->bigph = -1;
+    o->maxit = -1;
+    o->theta = -1;
+    o->smoth = -1;
+    o->cycle = -1;
+    o->isnsp = -1;
+    o->inter = -1;
+    o->fnode = -1;
+}
+
+extern "C" void ipd_pcg_opts_init(ipd_pcg_opts* o) {
+    if (!o) return;
+    o->retol = -1;
+    o->maxit = -1;
+    o->precd = -1;
+}
+
+// ---------------------------------------------------------------------------
+// raw device memory
+// ---------------------------------------------------------------------------
+extern "C" int ipd_dmalloc(ipd_ctx* ctx, size_t bytes, void** dptr) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && dptr, IPD_E_ARG, "ipd_dmalloc: NULL argument");
+        ctx->set_device();
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) throw IpdError(IPD_E_NOMEM, hipGetErrorString(e));
+        *dptr = p;
+    });
+}
+
+extern "C" int ipd_dfree(ipd_ctx* ctx, void* dptr) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx, IPD_E_ARG, "ctx is NULL");
+        ctx->set_device();
+        ctx->sync();
+        IPD_HIP(hipFree(dptr));
+    });
+}
+
+extern "C" int ipd_h2d(ipd_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx, IPD_E_ARG, "ctx is NULL");
+        ctx->set_device();
+        IPD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        ctx->sync();
+    });
+}
+
+extern "C" int ipd_d2h(ipd_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx, IPD_E_ARG, "ctx is NULL");
+        ctx->set_device();
+        IPD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+    });
+}
+
+// ---------------------------------------------------------------------------
+// mt19937ar, 53-bit doubles: MATLAB's default `rand`
+// ---------------------------------------------------------------------------
+void ipd_rng::seed(uint32_t s) {
+    mt[0] = s;
+    for (int i = 1; i < 624; ++i)
+        mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    mti = 624;
+}
+
+uint32_t ipd_rng::next_u32() {
+    static const uint32_t mag01[2] = {0u, 0x9908b0dfu};
+    if (mti >= 624) {
+        int kk;
+        for (kk = 0; kk < 624 - 397; ++kk) {
+            uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+            mt[kk] = mt[kk + 397] ^ (y >> 1) ^ mag01[y & 1u];
+        }
+        for (; kk < 623; ++kk) {
+            uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+            mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ mag01[y & 1u];
+        }
+        uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+        mt[623] = mt[396] ^ (y >> 1) ^ mag01[y & 1u];
+        mti = 0;
+    }
+    uint32_t y = mt[mti++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+double ipd_rng::next_double() {
+    uint32_t a = next_u32() >> 5, b = next_u32() >> 6;
+    return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+}
+
+void ipd_rng::fill(double* out, int64_t n) {
+    if (replay) {
+        if (consumed + n > (int64_t)values.size())
+            throw IpdError(IPD_E_ARG, "replay rand stream exhausted");
+        std::copy(values.begin() + consumed, values.begin() + consumed + n, out);
+    } else {
+        for (int64_t i = 0; i < n; ++i) out[i] = next_double();
+    }
+    consumed += n;
+}
+
+extern "C" int ipd_rng_create(uint32_t seed, ipd_rng** out) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(out, IPD_E_ARG, "out is NULL");
+        std::unique_ptr<ipd_rng> r(new ipd_rng());
+        r->seed(seed);
+        *out = r.release();
+    });
+}
+
+extern "C" int ipd_rng_create_replay(const double* values, int64_t count, ipd_rng** out) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(out && (values || count == 0) && count >= 0, IPD_E_ARG, "bad argument");
+        std::unique_ptr<ipd_rng> r(new ipd_rng());
+        r->replay = true;
+        r->values.assign(values, values + count);
+        *out = r.release();
+    });
+}
+
+extern "C" void ipd_rng_destroy(ipd_rng* rng) { delete rng; }
+
+extern "C" int ipd_rng_rand(ipd_rng* rng, int64_t count, double* out) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(rng && out && count >= 0, IPD_E_ARG, "bad argument");
+        rng->fill(out, count);
+    });
+}
+
+extern "C" int64_t ipd_rng_consumed(const ipd_rng* rng) { return rng ? rng->consumed : -1; }

@@ -1,0 +1,210 @@
+// Internal declarations shared by the translation units of libipdamg.
+// Not part of the C ABI (that is include/ipd_amg.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ipd_amg.h"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+struct IpdError : public std::runtime_error {
+    int code;
+    IpdError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void ipd_set_error(const std::string& msg);
+
+#define IPD_HIP(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e__ = (expr);                                                        \
+        if (e__ != hipSuccess)                                                          \
+            throw IpdError(IPD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+#define IPD_REQUIRE(cond, code, msg)                 \
+    do {                                             \
+        if (!(cond)) throw IpdError((code), (msg));  \
+    } while (0)
+
+// Wraps a C-ABI body: converts exceptions into status codes + ipd_last_error().
+template <class F>
+static inline int ipd_guard(F&& f) {
+    try {
+        f();
+        return IPD_OK;
+    } catch (const IpdError& e) {
+        ipd_set_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        ipd_set_error("out of host memory");
+        return IPD_E_NOMEM;
+    } catch (const std::exception& e) {
+        ipd_set_error(e.what());
+        return IPD_E_ARG;
+    }
+}
+
+#define IPD_KERNEL_CHECK() IPD_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------------------
+// device memory: chunk pool + bump arenas
+// ---------------------------------------------------------------------------
+// hipMalloc is slow (tens of microseconds) and the AMG setup is redone for
+// every Newton step, so all temporaries and all hierarchy storage come out of
+// bump arenas whose chunks are recycled through a per-context pool.
+struct ChunkPool {
+    struct Chunk {
+        char* base;
+        size_t bytes;
+    };
+    std::vector<Chunk> free_chunks;
+    size_t total_bytes = 0;
+    Chunk get(size_t min_bytes);
+    void put(Chunk c) { free_chunks.push_back(c); }
+    void release_all();
+};
+
+struct Arena {
+    ChunkPool* pool = nullptr;
+    std::vector<ChunkPool::Chunk> chunks;
+    size_t cur = 0;   // index of the chunk being filled
+    size_t off = 0;   // offset inside it
+    explicit Arena(ChunkPool* p = nullptr) : pool(p) {}
+    Arena(const Arena&) = delete;
+    Arena& operator=(const Arena&) = delete;
+    ~Arena() { release(); }
+    void* alloc_bytes(size_t bytes);
+    template <class T>
+    T* alloc(size_t n) {
+        return static_cast<T*>(alloc_bytes((n ? n : 1) * sizeof(T)));
+    }
+    void reset() {  // keep chunks, forget contents
+        cur = 0;
+        off = 0;
+    }
+    void release();  // give chunks back to the pool
+};
+
+// ---------------------------------------------------------------------------
+// device sparse matrix (CSR, int32 indices, fp64 values, sorted columns)
+// ---------------------------------------------------------------------------
+struct Csr {
+    int nr = 0, nc = 0, nnz = 0;
+    int* rp = nullptr;     // nr+1
+    int* ci = nullptr;     // nnz
+    double* va = nullptr;  // nnz
+};
+
+struct ipd_dmat {
+    ipd_ctx* ctx = nullptr;
+    std::unique_ptr<Arena> arena;  // owns the storage of `m`
+    Csr m;
+};
+
+// ---------------------------------------------------------------------------
+// MATLAB-compatible rand stream
+// ---------------------------------------------------------------------------
+struct ipd_rng {
+    bool replay = false;
+    uint32_t mt[624];
+    int mti = 625;
+    std::vector<double> values;  // replay mode
+    int64_t consumed = 0;
+    void seed(uint32_t s);
+    uint32_t next_u32();
+    double next_double();  // genrand_res53, as MATLAB's mt19937ar rand
+    void fill(double* out, int64_t n);
+};
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct RcclState;  // ipd_dist.cpp
+
+struct ipd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ChunkPool pool;
+    std::unique_ptr<Arena> scratch;  // per-call temporaries (reset by CallScope)
+    void* pinned = nullptr;          // host staging for small readbacks
+    size_t pinned_bytes = 0;
+    int num_cu = 256;
+    RcclState* comm = nullptr;
+
+    // read back `n` elements synchronously through the pinned staging buffer
+    template <class T>
+    void fetch(const T* dsrc, T* hdst, size_t n) {
+        fetch_bytes(dsrc, hdst, n * sizeof(T));
+    }
+    template <class T>
+    T fetch1(const T* dsrc) {
+        T v;
+        fetch_bytes(dsrc, &v, sizeof(T));
+        return v;
+    }
+    void fetch_bytes(const void* dsrc, void* hdst, size_t bytes);
+    void upload_bytes(void* ddst, const void* hsrc, size_t bytes);
+    template <class T>
+    void upload(T* ddst, const T* hsrc, size_t n) {
+        upload_bytes(ddst, hsrc, n * sizeof(T));
+    }
+    void sync() { IPD_HIP(hipStreamSynchronize(stream)); }
+    void set_device() { IPD_HIP(hipSetDevice(device)); }
+};
+
+// Resets the scratch arena when a top-level call ends (nesting-aware).
+struct CallScope {
+    ipd_ctx* ctx;
+    size_t cur, off;
+    explicit CallScope(ipd_ctx* c) : ctx(c), cur(c->scratch->cur), off(c->scratch->off) {
+        c->set_device();
+    }
+    ~CallScope() {
+        ctx->scratch->cur = cur;
+        ctx->scratch->off = off;
+    }
+};
+
+void ipd_comm_cleanup(ipd_ctx* ctx);  // ipd_dist.cpp
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// cross-TU device routines (all asynchronous on ctx->stream unless noted)
+// ---------------------------------------------------------------------------
+// ipd_sparse.hip
+Csr csr_alloc(Arena& a, int nr, int nc, int nnz);
+void csr_upload_from_csc(ipd_ctx* ctx, Arena& a, const ipd_csc* A, bool symmetric, Csr* out);
+void csr_download_as_csc(ipd_ctx* ctx, const Csr& m, bool already_transposed, ipd_csc_out* out);
+void csr_transpose(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* At);  // deterministic
+void csr_spmv(ipd_ctx* ctx, const Csr& A, const double* x, double* y);
+void exclusive_scan_i32(ipd_ctx* ctx, const int* in, int* out, int n);  // out has n+1 entries
+void fill_i32(ipd_ctx* ctx, int* p, int v, size_t n);
+void fill_f64(ipd_ctx* ctx, double* p, double v, size_t n);
+void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n);
+// C = X*Y with MATLAB ordering (ascending inner index, no FMA, exact zeros dropped)
+void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C);
+void csr_copy(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out);
+void csr_drop_zeros(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out);  // ipd_kkt.hip
+
+// ipd_kkt.hip
+void kkt_ax(ipd_ctx* ctx, const double* x, const double* p, const double* q, int m, int n,
+            double* y);
+void kkt_aty(ipd_ctx* ctx, const double* y, const double* p, const double* q, int m, int n,
+             double* z);
+void kkt_asat(ipd_ctx* ctx, Arena& dst, const uint8_t* s, const double* p, const double* q,
+              int m, int n, Csr* H);
+void kkt_inv_aat(ipd_ctx* ctx, const double* x, const double* p, const double* q, int m, int n,
+                 double sg1, double sg2, double* y);
+void kkt_inv_hht(ipd_ctx* ctx, const double* v, const double* p, const double* q, int m, int n,
+                 double sg, const double* phi, double* y);

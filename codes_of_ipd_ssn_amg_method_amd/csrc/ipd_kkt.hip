@@ -1,0 +1,660 @@
+// Matrix-free A operators and the active-set KKT assembly:
+//   Ax.m:10-13, Aty.m:10-13, ASAt.m:14-19, invAAt.m:13-20, Class2/invHHt.m:7-17.
+//
+// Layout: x, s, phi are m*n column-major (X(i,j) = x[i + j*m]); the KKT unknowns
+// are ordered [0,n) = column constraints, [n,n+m) = row constraints
+// (Class1/APD_SsN_Class1.m:33).
+//
+// Roofline: all of these are single streaming passes -> HBM bound.
+//   Ax   : 8*m*n + 16*(m+n) bytes      Aty : 8*m*n + 16*(m+n) bytes
+//   ASAt : m*n (mask) + 8*(m+n) + 16*(2E+M) bytes
+// This TU is compiled with -ffp-contract=off so that Aty and the ASAt values
+// are bit-identical to the oracle (two multiplies and one add per entry).
+#pragma clang fp contract(off)
+
+#include "ipd_internal.h"
+
+// ---------------------------------------------------------------------------
+// Ax:  y = [X'*p ; X*q]
+// ---------------------------------------------------------------------------
+// A workgroup stages a 256-row x 16-column tile of X in LDS with coalesced
+// column-contiguous loads (16 independent 8-byte loads in flight per lane), then
+// forms 256 partial row sums (row i over the 16 columns) and 16 partial column
+// sums (column j over the 256 rows) from the LDS copy.  Partials are combined
+// by a second kernel in a fixed order (deterministic, no float atomics).
+static constexpr int AX_TR = 256;       // tile rows
+static constexpr int AX_TC = 16;        // tile columns
+static constexpr int AX_LD = AX_TR + 16;  // padded column stride (bank spread)
+
+__global__ __launch_bounds__(256) void k_ax_tiles(const double* __restrict__ x,
+                                                  const double* __restrict__ p,
+                                                  const double* __restrict__ q, int m, int n,
+                                                  double* __restrict__ lpart,
+                                                  double* __restrict__ rpart) {
+    __shared__ double tile[AX_TC * AX_LD];
+    const int tid = threadIdx.x;
+    const int ib = blockIdx.x, jb = blockIdx.y;
+    const int i = ib * AX_TR + tid;
+    const int j0 = jb * AX_TC;
+    const bool in_i = i < m;
+    double xv[AX_TC];
+#pragma unroll
+    for (int jj = 0; jj < AX_TC; ++jj) {
+        const int j = j0 + jj;
+        xv[jj] = (in_i && j < n) ? x[(size_t)j * m + i] : 0.0;
+    }
+    double lacc = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < AX_TC; ++jj) {
+        const int j = j0 + jj;
+        const double qj = j < n ? q[j] : 0.0;
+        lacc += xv[jj] * qj;
+        tile[jj * AX_LD + tid] = xv[jj];
+    }
+    if (in_i) lpart[(size_t)jb * m + i] = lacc;
+    __syncthreads();
+    // column sums: 16 lanes per column, each lane 16 rows, then a 16-lane reduce
+    const int jj = tid >> 4, sub = tid & 15;
+    double cacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < AX_TR / 16; ++k) {
+        const int r = sub + 16 * k;
+        const int gi = ib * AX_TR + r;
+        const double pi = gi < m ? p[gi] : 0.0;
+        cacc += tile[jj * AX_LD + r] * pi;
+    }
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) cacc += __shfl_xor(cacc, d);
+    if (sub == 0 && j0 + jj < n) rpart[(size_t)ib * n + j0 + jj] = cacc;
+}
+
+__global__ __launch_bounds__(256) void k_ax_final(const double* __restrict__ lpart,
+                                                  const double* __restrict__ rpart, int m, int n,
+                                                  int nib, int njb, double* __restrict__ y) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        double s = 0.0;
+        for (int ib = 0; ib < nib; ++ib) s += rpart[(size_t)ib * n + t];
+        y[t] = s;
+    } else if (t < n + m) {
+        const int i = t - n;
+        double s = 0.0;
+        for (int jb = 0; jb < njb; ++jb) s += lpart[(size_t)jb * m + i];
+        y[t] = s;
+    }
+}
+
+void kkt_ax(ipd_ctx* ctx, const double* x, const double* p, const double* q, int m, int n,
+            double* y) {
+    if (m <= 0 || n <= 0) return;
+    Arena& tmp = *ctx->scratch;
+    const int nib = cdiv(m, AX_TR), njb = cdiv(n, AX_TC);
+    double* lpart = tmp.alloc<double>((size_t)njb * m);
+    double* rpart = tmp.alloc<double>((size_t)nib * n);
+    hipLaunchKernelGGL(k_ax_tiles, dim3(nib, njb), dim3(256), 0, ctx->stream, x, p, q, m, n, lpart,
+                       rpart);
+    IPD_KERNEL_CHECK();
+    hipLaunchKernelGGL(k_ax_final, dim3(cdiv(m + n, 256)), dim3(256), 0, ctx->stream, lpart, rpart,
+                       m, n, nib, njb, y);
+    IPD_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// Aty:  z(i,j) = p_i*y1_j + y2_i*q_j        (pure streaming write)
+// ---------------------------------------------------------------------------
+static constexpr int ATY_TC = 16;
+
+__global__ __launch_bounds__(256) void k_aty_v2(const double* __restrict__ y,
+                                                const double* __restrict__ p,
+                                                const double* __restrict__ q, int m, int n,
+                                                double* __restrict__ z) {
+    // two consecutive rows per lane -> 16-byte stores (m even, z 16-byte aligned)
+    const int i = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= m) return;
+    const double p0 = p[i], p1 = p[i + 1];
+    const double a0 = y[n + i], a1 = y[n + i + 1];
+    const int j0 = blockIdx.y * ATY_TC;
+#pragma unroll
+    for (int jj = 0; jj < ATY_TC; ++jj) {
+        const int j = j0 + jj;
+        if (j < n) {
+            const double y1 = y[j], qj = q[j];
+            double2 v;
+            v.x = p0 * y1 + a0 * qj;
+            v.y = p1 * y1 + a1 * qj;
+            *reinterpret_cast<double2*>(z + (size_t)j * m + i) = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_aty_v1(const double* __restrict__ y,
+                                                const double* __restrict__ p,
+                                                const double* __restrict__ q, int m, int n,
+                                                double* __restrict__ z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double pi = p[i], ai = y[n + i];
+    const int j0 = blockIdx.y * ATY_TC;
+#pragma unroll
+    for (int jj = 0; jj < ATY_TC; ++jj) {
+        const int j = j0 + jj;
+        if (j < n) z[(size_t)j * m + i] = pi * y[j] + ai * q[j];
+    }
+}
+
+void kkt_aty(ipd_ctx* ctx, const double* y, const double* p, const double* q, int m, int n,
+             double* z) {
+    if (m <= 0 || n <= 0) return;
+    const bool vec2 = (m % 2 == 0) && ((reinterpret_cast<uintptr_t>(z) & 15) == 0);
+    if (vec2) {
+        hipLaunchKernelGGL(k_aty_v2, dim3(cdiv(m / 2, 256), cdiv(n, ATY_TC)), dim3(256), 0,
+                           ctx->stream, y, p, q, m, n, z);
+    } else {
+        hipLaunchKernelGGL(k_aty_v1, dim3(cdiv(m, 256), cdiv(n, ATY_TC)), dim3(256), 0, ctx->stream,
+                           y, p, q, m, n, z);
+    }
+    IPD_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// ASAt:  H = A*diag(s)*A'  as CSR (== MATLAB's CSC, H is symmetric)
+// ---------------------------------------------------------------------------
+// Row j < n      : [ (j,j) , (j, n+i) for every i with Y(i,j)=1, ascending i ]
+// Row n+i        : [ (n+i, j) for every j with Y(i,j)=1, ascending j , (n+i,n+i) ]
+// A diagonal entry exists iff its row has any off-diagonal (MATLAB stores no
+// explicit zeros; a p or q whose square underflows to 0 is handled by a
+// zero-dropping pass).
+//
+// The byte mask is read once, as 64x64 tiles, one tile per wave: a wave ballot
+// turns the 64 bytes of a column into a 64-bit row mask; 64 more ballots
+// transpose the tile into per-row column masks.  Both bit-packed copies
+// (2*m*n/8 bytes) are kept so the fill pass never touches the bytes again.
+struct AsatPlan {
+    int m, n, nib, njb;
+    unsigned long long* colmask;  // [nib][n]  bits = rows of the tile
+    unsigned long long* rowmask;  // [njb][m]  bits = columns of the tile
+    int* coloff;                  // [nib][n]  entries of column j in tiles above
+    int* rowoff;                  // [njb][m]
+    int* cntc;                    // [n]
+    int* cntr;                    // [m]
+    int* rowlen;                  // [n+m]
+};
+
+__global__ __launch_bounds__(256) void k_asat_masks(const uint8_t* __restrict__ s, AsatPlan pl) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= pl.nib * pl.njb) return;
+    const int ib = tile % pl.nib, jb = tile / pl.nib;
+    const int i0 = ib * 64, j0 = jb * 64;
+    const int i = i0 + lane;
+    unsigned long long colm = 0ull;
+#pragma unroll 8
+    for (int jj = 0; jj < 64; ++jj) {
+        const int j = j0 + jj;
+        uint8_t b = 0;
+        if (i < pl.m && j < pl.n) b = s[(size_t)j * pl.m + i];
+        const unsigned long long mk = __ballot(b != 0);
+        if (lane == jj) colm = mk;
+    }
+    unsigned long long rowm = 0ull;
+#pragma unroll 8
+    for (int b = 0; b < 64; ++b) {
+        const unsigned long long mk = __ballot((colm >> b) & 1ull);
+        if (lane == b) rowm = mk;
+    }
+    if (j0 + lane < pl.n) pl.colmask[(size_t)ib * pl.n + j0 + lane] = colm;
+    if (i < pl.m) pl.rowmask[(size_t)jb * pl.m + i] = rowm;
+}
+
+// per column / per row: running offsets over the tiles, counts, H row lengths,
+// and the "some p_i^2 or q_j^2 is exactly zero" flag (meta[1]).
+__global__ __launch_bounds__(256) void k_asat_offsets(AsatPlan pl, const double* __restrict__ p,
+                                                      const double* __restrict__ q,
+                                                      int* __restrict__ meta_flag) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < pl.n) {
+        int run = 0;
+        for (int ib = 0; ib < pl.nib; ++ib) {
+            pl.coloff[(size_t)ib * pl.n + t] = run;
+            run += __popcll(pl.colmask[(size_t)ib * pl.n + t]);
+        }
+        pl.cntc[t] = run;
+        pl.rowlen[t] = run + (run > 0 ? 1 : 0);
+        const double qq = q[t] * q[t];
+        if (qq == 0.0) *meta_flag = 1;
+    } else if (t < pl.n + pl.m) {
+        const int i = t - pl.n;
+        int run = 0;
+        for (int jb = 0; jb < pl.njb; ++jb) {
+            pl.rowoff[(size_t)jb * pl.m + i] = run;
+            run += __popcll(pl.rowmask[(size_t)jb * pl.m + i]);
+        }
+        pl.cntr[i] = run;
+        pl.rowlen[t] = run + (run > 0 ? 1 : 0);
+        const double pp = p[i] * p[i];
+        if (pp == 0.0) *meta_flag = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_asat_fill(AsatPlan pl, const double* __restrict__ p,
+                                                   const double* __restrict__ q,
+                                                   const int* __restrict__ rp,
+                                                   int* __restrict__ ci, double* __restrict__ va) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= pl.nib * pl.njb) return;
+    const int ib = tile % pl.nib, jb = tile / pl.nib;
+    const int i0 = ib * 64, j0 = jb * 64;
+    {   // rows [0,n): column j of Y
+        const int j = j0 + lane;
+        if (j < pl.n) {
+            unsigned long long cm = pl.colmask[(size_t)ib * pl.n + j];
+            if (cm) {
+                int pos = rp[j] + 1 + pl.coloff[(size_t)ib * pl.n + j];
+                const double qj = q[j];
+                while (cm) {
+                    const int b = __ffsll((long long)cm) - 1;
+                    cm &= cm - 1ull;
+                    const int i = i0 + b;
+                    ci[pos] = pl.n + i;
+                    va[pos] = qj * p[i];  // q_j * (p_i * Y_ij)
+                    ++pos;
+                }
+            }
+        }
+    }
+    {   // rows [n,n+m): row i of Y
+        const int i = i0 + lane;
+        if (i < pl.m) {
+            unsigned long long rm = pl.rowmask[(size_t)jb * pl.m + i];
+            if (rm) {
+                int pos = rp[pl.n + i] + pl.rowoff[(size_t)jb * pl.m + i];
+                const double pi = p[i];
+                while (rm) {
+                    const int b = __ffsll((long long)rm) - 1;
+                    rm &= rm - 1ull;
+                    const int j = j0 + b;
+                    ci[pos] = j;
+                    va[pos] = pi * q[j];  // p_i * (Y_ij * q_j)
+                    ++pos;
+                }
+            }
+        }
+    }
+}
+
+// Diagonal values, accumulated sequentially in ascending index order exactly as
+// the sparse products U'*p and Q*q of ASAt.m:19 do (one lane per H row).
+__global__ __launch_bounds__(256) void k_asat_diag(AsatPlan pl, const double* __restrict__ p,
+                                                   const double* __restrict__ q,
+                                                   const int* __restrict__ rp,
+                                                   int* __restrict__ ci, double* __restrict__ va) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < pl.n) {
+        const int cnt = pl.cntc[t];
+        if (cnt > 0) {
+            const int pos = rp[t];
+            double sum = 0.0;
+            for (int e = pos + 1; e <= pos + cnt; ++e) {
+                const double pi = p[ci[e] - pl.n];
+                sum = sum + pi * pi;  // (p_i*Y_ij) * p_i
+            }
+            ci[pos] = t;
+            va[pos] = sum;
+        }
+    } else if (t < pl.n + pl.m) {
+        const int cnt = pl.cntr[t - pl.n];
+        if (cnt > 0) {
+            const int pos = rp[t];
+            double sum = 0.0;
+            for (int e = pos; e < pos + cnt; ++e) {
+                const double qj = q[ci[e]];
+                sum = sum + qj * qj;  // (Y_ij*q_j) * q_j
+            }
+            ci[pos + cnt] = t;
+            va[pos + cnt] = sum;
+        }
+    }
+}
+
+// generic "drop exact zeros" (rare path: squares that underflow)
+__global__ __launch_bounds__(256) void k_count_nz(int nr, const int* __restrict__ rp,
+                                                  const double* __restrict__ va,
+                                                  int* __restrict__ cnt) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nr) return;
+    int c = 0;
+    for (int e = rp[r]; e < rp[r + 1]; ++e) c += (va[e] != 0.0);
+    cnt[r] = c;
+}
+__global__ __launch_bounds__(256) void k_copy_nz(int nr, const int* __restrict__ rp,
+                                                 const int* __restrict__ ci,
+                                                 const double* __restrict__ va,
+                                                 const int* __restrict__ orp, int* __restrict__ oci,
+                                                 double* __restrict__ ova) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nr) return;
+    int pos = orp[r];
+    for (int e = rp[r]; e < rp[r + 1]; ++e)
+        if (va[e] != 0.0) {
+            oci[pos] = ci[e];
+            ova[pos] = va[e];
+            ++pos;
+        }
+}
+
+void csr_drop_zeros(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out) {
+    Arena& tmp = *ctx->scratch;
+    int* cnt = tmp.alloc<int>((size_t)A.nr + 1);
+    Csr o;
+    o.nr = A.nr;
+    o.nc = A.nc;
+    o.rp = dst.alloc<int>((size_t)A.nr + 1);
+    hipLaunchKernelGGL(k_count_nz, dim3(cdiv(std::max(A.nr, 1), 256)), dim3(256), 0, ctx->stream,
+                       A.nr, A.rp, A.va, cnt);
+    IPD_KERNEL_CHECK();
+    exclusive_scan_i32(ctx, cnt, o.rp, A.nr);
+    o.nnz = ctx->fetch1(o.rp + A.nr);
+    o.ci = dst.alloc<int>((size_t)o.nnz);
+    o.va = dst.alloc<double>((size_t)o.nnz);
+    hipLaunchKernelGGL(k_copy_nz, dim3(cdiv(std::max(A.nr, 1), 256)), dim3(256), 0, ctx->stream,
+                       A.nr, A.rp, A.ci, A.va, o.rp, o.ci, o.va);
+    IPD_KERNEL_CHECK();
+    *out = o;
+}
+
+void kkt_asat(ipd_ctx* ctx, Arena& dst, const uint8_t* s, const double* p, const double* q, int m,
+              int n, Csr* H) {
+    IPD_REQUIRE(m > 0 && n > 0, IPD_E_ARG, "ASAt: empty p or q");
+    Arena& tmp = *ctx->scratch;
+    AsatPlan pl;
+    pl.m = m;
+    pl.n = n;
+    pl.nib = cdiv(m, 64);
+    pl.njb = cdiv(n, 64);
+    pl.colmask = tmp.alloc<unsigned long long>((size_t)pl.nib * n);
+    pl.rowmask = tmp.alloc<unsigned long long>((size_t)pl.njb * m);
+    pl.coloff = tmp.alloc<int>((size_t)pl.nib * n);
+    pl.rowoff = tmp.alloc<int>((size_t)pl.njb * m);
+    pl.cntc = tmp.alloc<int>((size_t)n);
+    pl.cntr = tmp.alloc<int>((size_t)m);
+    pl.rowlen = tmp.alloc<int>((size_t)m + n);
+    const int M = m + n;
+    int* rp = dst.alloc<int>((size_t)M + 2);  // rp[M] = nnz, rp[M+1] = zero-square flag
+    const int ntiles = pl.nib * pl.njb;
+    IPD_HIP(hipMemsetAsync(rp + M + 1, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_asat_masks, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, s, pl);
+    IPD_KERNEL_CHECK();
+    hipLaunchKernelGGL(k_asat_offsets, dim3(cdiv(M, 256)), dim3(256), 0, ctx->stream, pl, p, q,
+                       rp + M + 1);
+    IPD_KERNEL_CHECK();
+    exclusive_scan_i32(ctx, pl.rowlen, rp, M);
+    int meta[2];
+    ctx->fetch(rp + M, meta, 2);
+    Csr h;
+    h.nr = h.nc = M;
+    h.nnz = meta[0];
+    h.rp = rp;
+    h.ci = dst.alloc<int>((size_t)h.nnz);
+    h.va = dst.alloc<double>((size_t)h.nnz);
+    if (h.nnz) {
+        hipLaunchKernelGGL(k_asat_fill, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, pl, p, q,
+                           rp, h.ci, h.va);
+        IPD_KERNEL_CHECK();
+        hipLaunchKernelGGL(k_asat_diag, dim3(cdiv(M, 256)), dim3(256), 0, ctx->stream, pl, p, q, rp,
+                           h.ci, h.va);
+        IPD_KERNEL_CHECK();
+    }
+    if (meta[1] && h.nnz) {
+        Csr clean;
+        csr_drop_zeros(ctx, dst, h, &clean);
+        h = clean;
+    }
+    *H = h;
+}
+
+// ---------------------------------------------------------------------------
+// invAAt / invHHt  (closed forms; O(m+n) plus one Ax for invHHt)
+// ---------------------------------------------------------------------------
+__device__ inline double block_sum_1024(double v, double* red) {
+    // all 1024 threads participate; returns the sum in every thread
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k];
+    return s;
+}
+
+// y = (diag(sg1 I_n, sg2 I_m) + A A')^{-1} x        invAAt.m:13-20
+__global__ __launch_bounds__(1024) void k_inv_aat(const double* __restrict__ x,
+                                                  const double* __restrict__ p,
+                                                  const double* __restrict__ q, int m, int n,
+                                                  double sg1, double sg2, double* __restrict__ y) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    double a = 0, b = 0, c = 0, d = 0;
+    for (int i = tid; i < m; i += 1024) {
+        a += p[i] * p[i];
+        c += p[i] * x[n + i];
+    }
+    for (int j = tid; j < n; j += 1024) {
+        b += q[j] * q[j];
+        d += q[j] * x[j];
+    }
+    const double np = block_sum_1024(a, red);
+    const double nq = block_sum_1024(b, red);
+    const double pvm = block_sum_1024(c, red);
+    const double qvn = block_sum_1024(d, red);
+    const double den = sg1 * sg2 + sg1 * nq + sg2 * np;
+    const double cn = (np / (sg1 + np) * qvn - pvm);
+    const double cm = (nq / (sg2 + nq) * pvm - qvn);
+    for (int j = tid; j < n; j += 1024) y[j] = x[j] / (sg1 + np) + cn * q[j] / den;
+    for (int i = tid; i < m; i += 1024) y[n + i] = x[n + i] / (sg2 + nq) + cm * p[i] / den;
+}
+
+void kkt_inv_aat(ipd_ctx* ctx, const double* x, const double* p, const double* q, int m, int n,
+                 double sg1, double sg2, double* y) {
+    hipLaunchKernelGGL(k_inv_aat, dim3(1), dim3(1024), 0, ctx->stream, x, p, q, m, n, sg1, sg2, y);
+    IPD_KERNEL_CHECK();
+}
+
+__global__ __launch_bounds__(256) void k_sumsq_partial(const double* __restrict__ v, size_t len,
+                                                       double* __restrict__ part) {
+    __shared__ double red[4];
+    double a = 0.0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < len; i += (size_t)gridDim.x * 256)
+        a += v[i] * v[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) a += __shfl_xor(a, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// Class2/invHHt.m:8-17 once l = Ax(phi), Vl = invAAt(l,sg+1), Vv1 = invAAt(v1,sg+1)
+__global__ __launch_bounds__(1024) void k_inv_hht_combine(const double* __restrict__ v,
+                                                          const double* __restrict__ l,
+                                                          const double* __restrict__ Vl,
+                                                          const double* __restrict__ Vv1,
+                                                          const double* __restrict__ part,
+                                                          int npart, int M, double sg,
+                                                          double* __restrict__ y) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    double a = 0, b = 0, c = 0;
+    for (int k = tid; k < npart; k += 1024) a += part[k];
+    for (int k = tid; k < M; k += 1024) {
+        b += l[k] * Vl[k];
+        c += l[k] * Vv1[k];
+    }
+    const double t = sg + block_sum_1024(a, red);
+    const double lVl = block_sum_1024(b, red);
+    const double lVv = block_sum_1024(c, red);
+    const double s = t - lVl;
+    const double v2 = v[M];
+    for (int k = tid; k < M; k += 1024) y[k] = (s * Vv1[k] + lVv * Vl[k] - v2 * Vl[k]) / s;
+    if (tid == 0) y[M] = (v2 - lVv) / s;
+}
+
+void kkt_inv_hht(ipd_ctx* ctx, const double* v, const double* p, const double* q, int m, int n,
+                 double sg, const double* phi, double* y) {
+    Arena& tmp = *ctx->scratch;
+    const int M = m + n;
+    const size_t mn = (size_t)m * n;
+    const int npart = (int)std::max<size_t>(1, std::min<size_t>((mn + 255) / 256, 1024));
+    double* part = tmp.alloc<double>((size_t)npart);
+    double* l = tmp.alloc<double>((size_t)M);
+    double* Vl = tmp.alloc<double>((size_t)M);
+    double* Vv1 = tmp.alloc<double>((size_t)M);
+    hipLaunchKernelGGL(k_sumsq_partial, dim3(npart), dim3(256), 0, ctx->stream, phi, mn, part);
+    IPD_KERNEL_CHECK();
+    kkt_ax(ctx, phi, p, q, m, n, l);
+    kkt_inv_aat(ctx, l, p, q, m, n, sg + 1, sg + 1, Vl);
+    kkt_inv_aat(ctx, v, p, q, m, n, sg + 1, sg + 1, Vv1);
+    hipLaunchKernelGGL(k_inv_hht_combine, dim3(1), dim3(1024), 0, ctx->stream, v, l, Vl, Vv1, part,
+                       npart, M, sg, y);
+    IPD_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+static void check_mn(int64_t m, int64_t n) {
+    IPD_REQUIRE(m > 0 && n > 0, IPD_E_ARG, "m and n must be positive");
+    IPD_REQUIRE(m < (1 << 28) && n < (1 << 28) && m * n < (int64_t(1) << 40), IPD_E_LIMIT,
+                "m*n too large");
+}
+
+extern "C" int ipd_ax_dev(ipd_ctx* ctx, const double* x, const double* p, const double* q,
+                          int64_t m, int64_t n, double* y) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && x && p && q && y, IPD_E_ARG, "NULL argument");
+        check_mn(m, n);
+        CallScope scope(ctx);
+        kkt_ax(ctx, x, p, q, (int)m, (int)n, y);
+    });
+}
+
+extern "C" int ipd_aty_dev(ipd_ctx* ctx, const double* y, const double* p, const double* q,
+                           int64_t m, int64_t n, double* z) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && z && p && q && y, IPD_E_ARG, "NULL argument");
+        check_mn(m, n);
+        CallScope scope(ctx);
+        kkt_aty(ctx, y, p, q, (int)m, (int)n, z);
+    });
+}
+
+extern "C" int ipd_asat_dev(ipd_ctx* ctx, const uint8_t* s, const double* p, const double* q,
+                            int64_t m, int64_t n, ipd_dmat** H) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && s && p && q && H, IPD_E_ARG, "NULL argument");
+        check_mn(m, n);
+        CallScope scope(ctx);
+        std::unique_ptr<ipd_dmat> d(new ipd_dmat());
+        d->ctx = ctx;
+        d->arena.reset(new Arena(&ctx->pool));
+        kkt_asat(ctx, *d->arena, s, p, q, (int)m, (int)n, &d->m);
+        *H = d.release();
+    });
+}
+
+namespace {
+struct HostVecs {
+    ipd_ctx* ctx;
+    Arena& a;
+    explicit HostVecs(ipd_ctx* c) : ctx(c), a(*c->scratch) {}
+    template <class T>
+    T* up(const T* h, size_t n) {
+        T* d = a.alloc<T>(n);
+        ctx->upload(d, h, n);
+        return d;
+    }
+};
+}  // namespace
+
+extern "C" int ipd_ax(ipd_ctx* ctx, const double* x, const double* p, const double* q, int64_t m,
+                      int64_t n, double* y) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && x && p && q && y, IPD_E_ARG, "NULL argument");
+        check_mn(m, n);
+        CallScope scope(ctx);
+        HostVecs hv(ctx);
+        double* dx = hv.up(x, (size_t)(m * n));
+        double* dp = hv.up(p, (size_t)m);
+        double* dq = hv.up(q, (size_t)n);
+        double* dy = ctx->scratch->alloc<double>((size_t)(m + n));
+        kkt_ax(ctx, dx, dp, dq, (int)m, (int)n, dy);
+        ctx->fetch(dy, y, (size_t)(m + n));
+    });
+}
+
+extern "C" int ipd_aty(ipd_ctx* ctx, const double* y, const double* p, const double* q, int64_t m,
+                       int64_t n, double* z) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && z && p && q && y, IPD_E_ARG, "NULL argument");
+        check_mn(m, n);
+        CallScope scope(ctx);
+        HostVecs hv(ctx);
+        double* dy = hv.up(y, (size_t)(m + n));
+        double* dp = hv.up(p, (size_t)m);
+        double* dq = hv.up(q, (size_t)n);
+        double* dz = ctx->scratch->alloc<double>((size_t)(m * n));
+        kkt_aty(ctx, dy, dp, dq, (int)m, (int)n, dz);
+        ctx->fetch(dz, z, (size_t)(m * n));
+    });
+}
+
+extern "C" int ipd_asat(ipd_ctx* ctx, const uint8_t* s, const double* p, const double* q,
+                        int64_t m, int64_t n, ipd_csc_out* H) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && s && p && q && H, IPD_E_ARG, "NULL argument");
+        check_mn(m, n);
+        CallScope scope(ctx);
+        HostVecs hv(ctx);
+        uint8_t* ds = hv.up(s, (size_t)(m * n));
+        double* dp = hv.up(p, (size_t)m);
+        double* dq = hv.up(q, (size_t)n);
+        Csr h;
+        kkt_asat(ctx, *ctx->scratch, ds, dp, dq, (int)m, (int)n, &h);
+        csr_download_as_csc(ctx, h, /*H symmetric: CSR == CSC*/ true, H);
+    });
+}
+
+extern "C" int ipd_inv_aat(ipd_ctx* ctx, const double* x, const double* p, const double* q,
+                           int64_t m, int64_t n, double sg1, double sg2, double* y) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && x && p && q && y, IPD_E_ARG, "NULL argument");
+        check_mn(m, n);
+        CallScope scope(ctx);
+        HostVecs hv(ctx);
+        double* dx = hv.up(x, (size_t)(m + n));
+        double* dp = hv.up(p, (size_t)m);
+        double* dq = hv.up(q, (size_t)n);
+        double* dy = ctx->scratch->alloc<double>((size_t)(m + n));
+        kkt_inv_aat(ctx, dx, dp, dq, (int)m, (int)n, sg1, sg2, dy);
+        ctx->fetch(dy, y, (size_t)(m + n));
+    });
+}
+
+extern "C" int ipd_inv_hht(ipd_ctx* ctx, const double* v, const double* p, const double* q,
+                           int64_t m, int64_t n, double sg, const double* phi, double* y) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && v && p && q && phi && y, IPD_E_ARG, "NULL argument");
+        check_mn(m, n);
+        CallScope scope(ctx);
+        HostVecs hv(ctx);
+        double* dv = hv.up(v, (size_t)(m + n + 1));
+        double* dp = hv.up(p, (size_t)m);
+        double* dq = hv.up(q, (size_t)n);
+        double* dphi = hv.up(phi, (size_t)(m * n));
+        double* dy = ctx->scratch->alloc<double>((size_t)(m + n + 1));
+        kkt_inv_hht(ctx, dv, dp, dq, (int)m, (int)n, sg, dphi, dy);
+        ctx->fetch(dy, y, (size_t)(m + n + 1));
+    });
+}

@@ -1,0 +1,843 @@
+// AMG setup on the device: Ruge-Stueben strength, C/F splitting (mis_set, the live
+// one, and cf_split, the one north_star names), interpolation, Galerkin product.
+//   AMG/strength.m:6-18, AMG/mis_set.m:9-67, AMG/cf_split.m:6-16,
+//   AMG/transfer.m:17-66, AMG/Class_AMG.m:41-85.
+//
+// Everything in this TU is integer/compare work or strictly ordered fp64
+// arithmetic (no FMA contraction, sequential accumulation in ascending index),
+// so C/F masks, Pro and Ac are BIT-IDENTICAL to the oracle's on every level.
+// The kernels are latency-bound at realistic sizes (N <= 4096, nnz 1e3..1e6):
+// the design goal is few launches and no float atomics, not bandwidth.
+#pragma clang fp contract(off)
+
+#include "ipd_amg_internal.h"
+
+#include <cmath>
+
+static inline int rows_grid(int nr) { return std::max(1, std::min(cdiv(nr, 4), 4096)); }
+static inline int elems_grid(long long n) {
+    return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
+}
+
+#define WAVE_ROWS(r, nr)                                                    \
+    const int lane = threadIdx.x & 63;                                      \
+    const int wave__ = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;        \
+    const int nwaves__ = (gridDim.x * blockDim.x) >> 6;                     \
+    for (int r = wave__; r < (nr); r += nwaves__)
+
+#define THREAD_ELEMS(i, n)                                                  \
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (n);            \
+         i += gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------------------
+// strength                                                (AMG/strength.m:7-18)
+// ---------------------------------------------------------------------------
+// max_row(i) = max over the row of D-A; the diagonal of D-A is an implicit zero,
+// so the maximum is never negative; "<= 0 -> Inf" (strength.m:9-10).
+__global__ __launch_bounds__(256) void k_rowmax(int nr, const int* __restrict__ rp,
+                                                const int* __restrict__ ci,
+                                                const double* __restrict__ va,
+                                                double* __restrict__ maxrow,
+                                                double* __restrict__ diag) {
+    WAVE_ROWS(r, nr) {
+        double mx = 0.0, dg = 0.0;
+        for (int t = rp[r] + lane; t < rp[r + 1]; t += 64) {
+            const int j = ci[t];
+            const double v = va[t];
+            if (j == r)
+                dg = v;
+            else
+                mx = fmax(mx, -v);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            mx = fmax(mx, __shfl_xor(mx, d));
+            dg += __shfl_xor(dg, d);  // at most one lane holds the diagonal
+        }
+        if (lane == 0) {
+            maxrow[r] = mx > 0.0 ? mx : INFINITY;
+            diag[r] = dg;
+        }
+    }
+}
+
+// strong(t) = [ -a_ij / min(max_row(i), max_row(j)) >= theta ], j != i   (mis_set.m:25)
+// degi = column counts of the mask (mis_set.m:28), rowcnt = row counts (mis_set.m:67)
+__global__ __launch_bounds__(256) void k_strong(int nr, const int* __restrict__ rp,
+                                                const int* __restrict__ ci,
+                                                const double* __restrict__ va,
+                                                const double* __restrict__ maxrow, double theta,
+                                                uint8_t* __restrict__ strong,
+                                                int* __restrict__ degi, int* __restrict__ rowcnt) {
+    WAVE_ROWS(r, nr) {
+        const double mr = maxrow[r];
+        int cnt = 0;
+        for (int t = rp[r] + lane; t < rp[r + 1]; t += 64) {
+            const int j = ci[t];
+            bool f = false;
+            if (j != r) {
+                const double sv = (-va[t]) / fmin(mr, maxrow[j]);
+                f = sv >= theta;
+            }
+            strong[t] = f ? 1 : 0;
+            if (f) {
+                atomicAdd(&degi[j], 1);
+                ++cnt;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+        if (lane == 0) rowcnt[r] = cnt;
+    }
+}
+
+void amg_strength_mask(ipd_ctx* ctx, const Csr& A, double theta, uint8_t* strong, int* degi,
+                       int* rowcnt) {
+    Arena& tmp = *ctx->scratch;
+    double* maxrow = tmp.alloc<double>((size_t)A.nr);
+    double* diag = tmp.alloc<double>((size_t)A.nr);
+    IPD_HIP(hipMemsetAsync(degi, 0, sizeof(int) * (size_t)std::max(A.nr, 1), ctx->stream));
+    hipLaunchKernelGGL(k_rowmax, dim3(rows_grid(A.nr)), dim3(256), 0, ctx->stream, A.nr, A.rp, A.ci,
+                       A.va, maxrow, diag);
+    IPD_KERNEL_CHECK();
+    hipLaunchKernelGGL(k_strong, dim3(rows_grid(A.nr)), dim3(256), 0, ctx->stream, A.nr, A.rp, A.ci,
+                       A.va, maxrow, theta, strong, degi, rowcnt);
+    IPD_KERNEL_CHECK();
+}
+
+// strength VALUES for ipd_strength (zero where dropped; compacted afterwards)
+__global__ __launch_bounds__(256) void k_strength_values(int nr, const int* __restrict__ rp,
+                                                         const int* __restrict__ ci,
+                                                         const double* __restrict__ va,
+                                                         const double* __restrict__ maxrow,
+                                                         int which, double* __restrict__ out) {
+    WAVE_ROWS(r, nr) {
+        const double mr = maxrow[r];
+        for (int t = rp[r] + lane; t < rp[r + 1]; t += 64) {
+            const int j = ci[t];
+            double sv = 0.0;
+            if (j != r) sv = (-va[t]) / (which == 1 ? mr : fmin(mr, maxrow[j]));
+            out[t] = sv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// mis_set                                                  (AMG/mis_set.m:25-67)
+// ---------------------------------------------------------------------------
+__global__ void k_flag_pos(int n, const int* __restrict__ v, int* __restrict__ flag) {
+    THREAD_ELEMS(i, n) flag[i] = v[i] > 0 ? 1 : 0;
+}
+
+// deg(idx) = deg(idx) + 0.1*rand(sum(idx),1)  (:35);  isF(deg==0) = true (:40)
+__global__ void k_deg_init(int n, const int* __restrict__ degi, const int* __restrict__ rank,
+                           const double* __restrict__ randv, double* __restrict__ deg,
+                           uint8_t* __restrict__ isC, uint8_t* __restrict__ isF,
+                           uint8_t* __restrict__ isU) {
+    THREAD_ELEMS(i, n) {
+        const int d = degi[i];
+        double dv = 0.0;
+        if (d > 0) {
+            const double tie = 0.1 * randv[rank[i]];
+            dv = (double)d + tie;
+        }
+        deg[i] = dv;
+        isC[i] = 0;
+        isF[i] = d == 0 ? 1 : 0;
+        isU[i] = 1;
+    }
+}
+
+__global__ void k_mis_sel_init(int n, const double* __restrict__ deg, uint8_t* __restrict__ isS) {
+    THREAD_ELEMS(i, n) isS[i] = deg[i] > 0.0 ? 1 : 0;
+}
+
+// edges (i,j), i<j, of triu(As(S,S),1): the smaller degree loses; ties keep the
+// smaller index (:49-52).  Every write stores 0, so the races are benign.
+__global__ __launch_bounds__(256) void k_mis_sel_kill(int nr, const int* __restrict__ rp,
+                                                      const int* __restrict__ ci,
+                                                      const uint8_t* __restrict__ strong,
+                                                      const double* __restrict__ deg,
+                                                      uint8_t* __restrict__ isS) {
+    WAVE_ROWS(i, nr) {
+        const double di = deg[i];
+        if (di > 0.0) {
+            for (int t = rp[i] + lane; t < rp[i + 1]; t += 64) {
+                const int j = ci[t];
+                if (strong[t] && j > i) {
+                    const double dj = deg[j];
+                    if (dj > 0.0) {
+                        if (di >= dj)
+                            isS[j] = 0;
+                        else
+                            isS[i] = 0;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void k_mis_commit(int n, const uint8_t* __restrict__ isS, uint8_t* __restrict__ isC) {
+    THREAD_ELEMS(i, n) if (isS[i]) isC[i] = 1;
+}
+
+// [i,~] = find(As(:,isC)); isF(i) = true   (:56-57)
+__global__ __launch_bounds__(256) void k_mis_markF(int nr, const int* __restrict__ rp,
+                                                   const int* __restrict__ ci,
+                                                   const uint8_t* __restrict__ strong,
+                                                   const uint8_t* __restrict__ isC,
+                                                   uint8_t* __restrict__ isF) {
+    WAVE_ROWS(i, nr) {
+        bool hit = false;
+        for (int t = rp[i] + lane; t < rp[i + 1]; t += 64)
+            if (strong[t] && isC[ci[t]]) hit = true;
+        if (__any(hit) && lane == 0) isF[i] = 1;
+    }
+}
+
+// isU = ~(isF|isC); deg(~isU) = 0 (:58-59); counts for the loop test (:42)
+__global__ void k_mis_update(int n, const uint8_t* __restrict__ isC,
+                             const uint8_t* __restrict__ isF, uint8_t* __restrict__ isU,
+                             double* __restrict__ deg, int* __restrict__ counts) {
+    THREAD_ELEMS(i, n) {
+        const bool c = isC[i], f = isF[i];
+        const bool u = !(c || f);
+        isU[i] = u ? 1 : 0;
+        if (!u) deg[i] = 0.0;
+        if (c) atomicAdd(&counts[0], 1);
+        if (u) atomicAdd(&counts[1], 1);
+    }
+}
+
+__global__ void k_mis_absorb(int n, uint8_t* __restrict__ isU, uint8_t* __restrict__ isC) {
+    THREAD_ELEMS(i, n) if (isU[i]) {
+        isC[i] = 1;
+        isU[i] = 0;
+    }
+}
+
+// iso = sum(As,2)==0; isC(iso) = true; isF(iso) = false   (:67)
+__global__ void k_mis_iso(int n, const int* __restrict__ rowcnt, uint8_t* __restrict__ isC,
+                          uint8_t* __restrict__ isF) {
+    THREAD_ELEMS(i, n) if (rowcnt[i] == 0) {
+        isC[i] = 1;
+        isF[i] = 0;
+    }
+}
+
+void amg_mis_set(ipd_ctx* ctx, const Csr& A, double theta, ipd_rng* rng, uint8_t* isC,
+                 uint8_t* isF, uint8_t* strong_out) {
+    IPD_REQUIRE(rng, IPD_E_ARG, "mis_set needs a rand stream");
+    IPD_REQUIRE(theta > 0, IPD_E_ARG, "mis_set: theta must be positive");
+    const int N = A.nr;
+    Arena& tmp = *ctx->scratch;
+    uint8_t* strong = strong_out ? strong_out : tmp.alloc<uint8_t>((size_t)A.nnz);
+    int* degi = tmp.alloc<int>((size_t)N + 1);
+    int* rowcnt = tmp.alloc<int>((size_t)N + 1);
+    int* flag = tmp.alloc<int>((size_t)N + 1);
+    int* rank = tmp.alloc<int>((size_t)N + 2);
+    double* deg = tmp.alloc<double>((size_t)N);
+    uint8_t* isU = tmp.alloc<uint8_t>((size_t)N);
+    uint8_t* isS = tmp.alloc<uint8_t>((size_t)N);
+    int* counts = tmp.alloc<int>(2);
+    const int N0 = std::min((int)std::floor(std::sqrt((double)N)) + 1, 25);  // :12
+    amg_strength_mask(ctx, A, theta, strong, degi, rowcnt);                  // :25-29
+    const int g = elems_grid(N);
+    hipLaunchKernelGGL(k_flag_pos, dim3(g), dim3(256), 0, ctx->stream, N, degi, flag);
+    IPD_KERNEL_CHECK();
+    exclusive_scan_i32(ctx, flag, rank, N);
+    const int nconn = ctx->fetch1(rank + N);
+    if ((double)nconn < 0.25 * std::sqrt((double)N)) {                       // :30-34
+        std::vector<double> rv((size_t)N0);
+        rng->fill(rv.data(), N0);
+        std::vector<uint8_t> hc((size_t)N, 0), hf((size_t)N, 1);
+        for (int k = 0; k < N0; ++k) {
+            long long pick = (long long)std::ceil(rv[k] * (double)N) - 1;
+            if (pick < 0) pick = 0;  // rand never returns exactly 0; guard anyway
+            if (pick >= N) pick = N - 1;
+            hc[(size_t)pick] = 1;
+            hf[(size_t)pick] = 0;
+        }
+        ctx->upload(isC, hc.data(), (size_t)N);
+        ctx->upload(isF, hf.data(), (size_t)N);
+        return;
+    }
+    std::vector<double> rv((size_t)nconn);
+    rng->fill(rv.data(), nconn);                                             // :35
+    double* drand = tmp.alloc<double>((size_t)nconn);
+    ctx->upload(drand, rv.data(), (size_t)nconn);
+    hipLaunchKernelGGL(k_deg_init, dim3(g), dim3(256), 0, ctx->stream, N, degi, rank, drand, deg,
+                       isC, isF, isU);
+    IPD_KERNEL_CHECK();
+    int sumC = 0, sumU = N;
+    int rounds = 0;
+    while ((double)sumC < (double)N / 2.0 && sumU > N0) {                    // :42
+        IPD_REQUIRE(++rounds <= N + 8, IPD_E_NUMERIC, "mis_set: no progress");
+        hipLaunchKernelGGL(k_mis_sel_init, dim3(g), dim3(256), 0, ctx->stream, N, deg, isS);
+        hipLaunchKernelGGL(k_mis_sel_kill, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp,
+                           A.ci, strong, deg, isS);
+        hipLaunchKernelGGL(k_mis_commit, dim3(g), dim3(256), 0, ctx->stream, N, isS, isC);
+        hipLaunchKernelGGL(k_mis_markF, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp, A.ci,
+                           strong, isC, isF);
+        IPD_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_mis_update, dim3(g), dim3(256), 0, ctx->stream, N, isC, isF, isU, deg,
+                           counts);
+        IPD_KERNEL_CHECK();
+        int hc[2];
+        ctx->fetch(counts, hc, 2);
+        sumC = hc[0];
+        sumU = hc[1];
+        if (sumU <= N0) {                                                    // :61-64
+            hipLaunchKernelGGL(k_mis_absorb, dim3(g), dim3(256), 0, ctx->stream, N, isU, isC);
+            IPD_KERNEL_CHECK();
+            sumU = 0;
+        }
+    }
+    hipLaunchKernelGGL(k_mis_iso, dim3(g), dim3(256), 0, ctx->stream, N, rowcnt, isC, isF);
+    IPD_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// cf_split                                                (AMG/cf_split.m:6-16)
+// ---------------------------------------------------------------------------
+// The sequential greedy pass (k = 1..N: an unvisited k becomes C and its
+// neighbours F) yields the lexicographically-first maximal independent set:
+// k is C iff no lower-indexed neighbour is C.  Parallel form, one workgroup:
+// an undecided node becomes F as soon as a lower neighbour is C, and C as soon
+// as every lower neighbour is F.  Decisions are final, so in-place updates and
+// any interleaving give the identical (bit-exact) result.
+__global__ __launch_bounds__(1024) void k_cf_split(int n, const int* __restrict__ rp,
+                                                   const int* __restrict__ ci,
+                                                   uint8_t* __restrict__ state /*0 U,1 C,2 F*/,
+                                                   int* __restrict__ rounds_out) {
+    __shared__ int pending;
+    int rounds = 0;
+    while (true) {
+        if (threadIdx.x == 0) pending = 0;
+        __syncthreads();
+        bool mine = false;
+        for (int k = threadIdx.x; k < n; k += 1024) {
+            if (state[k] != 0) continue;
+            bool anyC = false, anyU = false;
+            for (int t = rp[k]; t < rp[k + 1]; ++t) {
+                const int j = ci[t];
+                if (j >= k) break;  // columns ascend: only lower neighbours matter
+                const uint8_t sj = state[j];
+                anyC |= (sj == 1);
+                anyU |= (sj == 0);
+            }
+            if (anyC)
+                state[k] = 2;
+            else if (!anyU)
+                state[k] = 1;
+            else
+                mine = true;
+        }
+        if (mine) pending = 1;
+        __syncthreads();
+        ++rounds;
+        const int p = pending;
+        __syncthreads();
+        if (!p) break;
+    }
+    if (threadIdx.x == 0) *rounds_out = rounds;
+}
+
+__global__ void k_state_to_masks(int n, const uint8_t* __restrict__ state,
+                                 uint8_t* __restrict__ isC, uint8_t* __restrict__ isF) {
+    THREAD_ELEMS(i, n) {
+        isC[i] = state[i] == 1;
+        isF[i] = state[i] == 2;
+    }
+}
+
+static void amg_cf_split(ipd_ctx* ctx, const Csr& S, uint8_t* isC, uint8_t* isF) {
+    Arena& tmp = *ctx->scratch;
+    uint8_t* state = tmp.alloc<uint8_t>((size_t)S.nr);
+    int* rounds = tmp.alloc<int>(1);
+    IPD_HIP(hipMemsetAsync(state, 0, (size_t)std::max(S.nr, 1), ctx->stream));
+    hipLaunchKernelGGL(k_cf_split, dim3(1), dim3(1024), 0, ctx->stream, S.nr, S.rp, S.ci, state,
+                       rounds);
+    IPD_KERNEL_CHECK();
+    hipLaunchKernelGGL(k_state_to_masks, dim3(elems_grid(S.nr)), dim3(256), 0, ctx->stream, S.nr,
+                       state, isC, isF);
+    IPD_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// interpolation                                          (AMG/transfer.m:19-63)
+// ---------------------------------------------------------------------------
+// level 1 of a bigraph: F = first nf rows, W = (-Aff)\Afc with Aff diagonal
+// (transfer.m:20-25); one lane per row, sequential, so the row sum used by the
+// isnsp normalisation (:22-24) is accumulated in ascending column order.
+__global__ void k_bigph_count(int N, int nf, const int* __restrict__ rp,
+                              const int* __restrict__ ci, int* __restrict__ rowlen,
+                              int* __restrict__ bad) {
+    THREAD_ELEMS(i, N) {
+        if (i >= nf) {
+            rowlen[i] = 1;
+        } else {
+            int c = 0;
+            for (int t = rp[i]; t < rp[i + 1]; ++t) {
+                const int j = ci[t];
+                if (j >= nf)
+                    ++c;
+                else if (j != i)
+                    *bad = 1;  // Aff is not diagonal
+            }
+            rowlen[i] = c;
+        }
+    }
+}
+
+__global__ void k_bigph_fill(int N, int nf, int isnsp, const int* __restrict__ rp,
+                             const int* __restrict__ ci, const double* __restrict__ va,
+                             const int* __restrict__ prp, int* __restrict__ pci,
+                             double* __restrict__ pva, uint8_t* __restrict__ cmask) {
+    THREAD_ELEMS(i, N) {
+        int pos = prp[i];
+        if (i >= nf) {
+            pci[pos] = i - nf;
+            pva[pos] = 1.0;
+            cmask[i] = 1;
+            continue;
+        }
+        cmask[i] = 0;
+        double dii = 0.0;
+        for (int t = rp[i]; t < rp[i + 1]; ++t)
+            if (ci[t] == i) dii = va[t];
+        const double nd = -dii;
+        const int start = pos;
+        for (int t = rp[i]; t < rp[i + 1]; ++t) {
+            const int j = ci[t];
+            if (j >= nf) {
+                pci[pos] = j - nf;
+                pva[pos] = va[t] / nd;
+                ++pos;
+            }
+        }
+        if (isnsp == 1) {
+            double s = 0.0;
+            for (int e = start; e < pos; ++e) s = s + pva[e];
+            for (int e = start; e < pos; ++e) pva[e] = pva[e] / s;
+        }
+    }
+}
+
+// General level (transfer.m:41-63).  One single-wave workgroup per row keeps two
+// dense coarse rows in LDS: acc1 = W1(i,:) = Afc(i,:)/(-a_ii), acc2 = W2(i,:) =
+// sum_k X(i,k) W1(k,:) with X = ((-Dff)\(Aff.*(I+As_FF))), k ascending; the row of
+// W is W1 + 0.5*W2 (the always-true test at transfer.m:54).
+__global__ __launch_bounds__(64) void k_build_W(int N, int Nc, const int* __restrict__ rp,
+                                                const int* __restrict__ ci,
+                                                const double* __restrict__ va,
+                                                const double* __restrict__ diag,
+                                                const uint8_t* __restrict__ strong,
+                                                const uint8_t* __restrict__ isC,
+                                                const uint8_t* __restrict__ isF,
+                                                const int* __restrict__ cidx,
+                                                double* __restrict__ dense,
+                                                int* __restrict__ rowcnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* acc2 = reinterpret_cast<double*>(smem_raw);
+    double* acc1 = acc2 + Nc;
+    const int lane = threadIdx.x;
+    for (int i = blockIdx.x; i < N; i += gridDim.x) {
+        double* drow = dense + (size_t)i * Nc;
+        if (isC[i]) {  // identity row of P = [W; I]
+            const int me = cidx[i];
+            for (int c = lane; c < Nc; c += 64) drow[c] = (c == me) ? 1.0 : 0.0;
+            if (lane == 0) rowcnt[i] = 1;
+            continue;
+        }
+        for (int c = lane; c < Nc; c += 64) {
+            acc1[c] = 0.0;
+            acc2[c] = 0.0;
+        }
+        __syncthreads();
+        const double ndi = -diag[i];
+        const int b = rp[i], e = rp[i + 1];
+        for (int t = b + lane; t < e; t += 64) {
+            const int j = ci[t];
+            if (isC[j]) acc1[cidx[j]] = va[t] / ndi;
+        }
+        for (int t = b; t < e; ++t) {
+            const int k = ci[t];
+            if (isF[k] && (k == i || strong[t])) {
+                const double x = va[t] / ndi;
+                const double ndk = -diag[k];
+                for (int u = rp[k] + lane; u < rp[k + 1]; u += 64) {
+                    const int j = ci[u];
+                    if (isC[j]) {
+                        const double w1 = va[u] / ndk;
+                        const double prod = x * w1;
+                        const int c = cidx[j];
+                        acc2[c] = acc2[c] + prod;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        int nz = 0;
+        for (int c = lane; c < Nc; c += 64) {
+            const double half = 0.5 * acc2[c];
+            const double v = acc1[c] + half;
+            drow[c] = v;
+            nz += (v != 0.0);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d);
+        if (lane == 0) rowcnt[i] = nz;
+        __syncthreads();
+    }
+}
+
+// D = diag(W*1); W = D\W on the F rows (transfer.m:60-62)
+__global__ void k_row_normalize(int N, const uint8_t* __restrict__ isF,
+                                const int* __restrict__ prp, double* __restrict__ pva) {
+    THREAD_ELEMS(i, N) if (isF[i]) {
+        double s = 0.0;
+        for (int e = prp[i]; e < prp[i + 1]; ++e) s = s + pva[e];
+        for (int e = prp[i]; e < prp[i + 1]; ++e) pva[e] = pva[e] / s;
+    }
+}
+
+__global__ void k_u8_to_flag(int n, const uint8_t* __restrict__ a, int* __restrict__ f) {
+    THREAD_ELEMS(i, n) f[i] = a[i] ? 1 : 0;
+}
+__global__ void k_count_bad_split(int n, const uint8_t* __restrict__ isC,
+                                  const uint8_t* __restrict__ isF, int* __restrict__ bad) {
+    THREAD_ELEMS(i, n) if ((isC[i] != 0) == (isF[i] != 0)) atomicAdd(bad, 1);
+}
+
+// dense rows -> CSR (shared with ipd_sparse.hip's SpGEMM; re-declared here)
+__global__ __launch_bounds__(256) void k_dense_compact2(int nr, int nc,
+                                                        const double* __restrict__ dense,
+                                                        const int* __restrict__ rp,
+                                                        int* __restrict__ ci,
+                                                        double* __restrict__ va) {
+    WAVE_ROWS(i, nr) {
+        int base = rp[i];
+        const double* drow = dense + (size_t)i * nc;
+        for (int j0 = 0; j0 < nc; j0 += 64) {
+            const int j = j0 + lane;
+            const double v = j < nc ? drow[j] : 0.0;
+            const bool nzf = v != 0.0;
+            const unsigned long long mask = __ballot(nzf);
+            if (nzf) {
+                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                ci[pos] = j;
+                va[pos] = v;
+            }
+            base += __popcll(mask);
+        }
+    }
+}
+
+void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int level,
+                  ipd_rng* rng, Csr* Ac, Csr* Pout, Csr* Ptout, uint8_t* cmask) {
+    IPD_REQUIRE(A.nr == A.nc, IPD_E_ARG, "transfer: A must be square");
+    IPD_REQUIRE(&dst != ctx->scratch.get(), IPD_E_ARG, "transfer: dst must not be the scratch arena");
+    CallScope scope(ctx);  // temporaries die with this call; results live in dst
+    Arena& tmp = *ctx->scratch;
+    const int N = A.nr;
+    Csr P;
+    P.nr = N;
+    if (level == 1 && o.bigph) {                                             // transfer.m:19-25
+        const int nf = (int)o.fnode;
+        IPD_REQUIRE(nf > 0 && nf < N, IPD_E_ARG, "transfer: fnode must satisfy 0 < fnode < N");
+        P.nc = N - nf;
+        int* rowlen = tmp.alloc<int>((size_t)N + 1);
+        int* bad = tmp.alloc<int>(1);
+        IPD_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_bigph_count, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N, nf,
+                           A.rp, A.ci, rowlen, bad);
+        IPD_KERNEL_CHECK();
+        P.rp = dst.alloc<int>((size_t)N + 1);
+        exclusive_scan_i32(ctx, rowlen, P.rp, N);
+        P.nnz = ctx->fetch1(P.rp + N);
+        IPD_REQUIRE(ctx->fetch1(bad) == 0, IPD_E_UNSUPPORTED,
+                    "transfer: bigph level 1 needs a diagonal Aff block (transfer.m:20-21)");
+        P.ci = dst.alloc<int>((size_t)P.nnz);
+        P.va = dst.alloc<double>((size_t)P.nnz);
+        hipLaunchKernelGGL(k_bigph_fill, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N, nf,
+                           o.isnsp, A.rp, A.ci, A.va, P.rp, P.ci, P.va, cmask);
+        IPD_KERNEL_CHECK();
+    } else {                                                                 // transfer.m:41-63
+        IPD_REQUIRE(o.inter < 2, IPD_E_UNSUPPORTED,
+                    "transfer: ideal interpolation (inter=2) is a cold path and not built");
+        uint8_t* isC = cmask;
+        uint8_t* isF = tmp.alloc<uint8_t>((size_t)N);
+        uint8_t* strong = tmp.alloc<uint8_t>((size_t)std::max(A.nnz, 1));
+        amg_mis_set(ctx, A, o.theta, rng, isC, isF, strong);                 // :41
+        int* flag = tmp.alloc<int>((size_t)N + 1);
+        int* cidx = tmp.alloc<int>((size_t)N + 2);  // cidx[N] = Nc, cidx[N+1] = #bad
+        IPD_HIP(hipMemsetAsync(cidx + N + 1, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_u8_to_flag, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N, isC,
+                           flag);
+        hipLaunchKernelGGL(k_count_bad_split, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N, isC,
+                           isF, cidx + N + 1);
+        IPD_KERNEL_CHECK();
+        exclusive_scan_i32(ctx, flag, cidx, N);
+        int meta[2];
+        ctx->fetch(cidx + N, meta, 2);
+        const int Nc = meta[0];
+        IPD_REQUIRE(meta[1] == 0, IPD_E_NUMERIC,
+                    "mis_set left nodes in neither/both of the C and F sets (SURVEY A-6)");
+        IPD_REQUIRE(Nc > 0, IPD_E_NUMERIC, "transfer: empty coarse set");
+        IPD_REQUIRE((size_t)Nc * 16 <= 128 * 1024, IPD_E_LIMIT,
+                    "transfer: more than 8192 coarse nodes on a non-bigraph level");
+        P.nc = Nc;
+        double* maxrow = tmp.alloc<double>((size_t)N);
+        double* diag = tmp.alloc<double>((size_t)N);
+        hipLaunchKernelGGL(k_rowmax, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp, A.ci,
+                           A.va, maxrow, diag);
+        IPD_KERNEL_CHECK();
+        const size_t dense_elems = (size_t)N * (size_t)Nc;
+        IPD_REQUIRE(dense_elems * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
+                    "transfer: dense interpolation scratch above 2 GiB");
+        double* dense = tmp.alloc<double>(dense_elems);
+        int* rowcnt = tmp.alloc<int>((size_t)N + 1);
+        static bool attr_set = false;
+        if (!attr_set) {
+            IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_W),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_build_W, dim3(std::min(N, 16384)), dim3(64), (size_t)Nc * 16,
+                           ctx->stream, N, Nc, A.rp, A.ci, A.va, diag, strong, isC, isF, cidx, dense,
+                           rowcnt);
+        IPD_KERNEL_CHECK();
+        P.rp = dst.alloc<int>((size_t)N + 1);
+        exclusive_scan_i32(ctx, rowcnt, P.rp, N);
+        P.nnz = ctx->fetch1(P.rp + N);
+        P.ci = dst.alloc<int>((size_t)P.nnz);
+        P.va = dst.alloc<double>((size_t)P.nnz);
+        hipLaunchKernelGGL(k_dense_compact2, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, Nc,
+                           dense, P.rp, P.ci, P.va);
+        IPD_KERNEL_CHECK();
+        if (o.isnsp == 1) {                                                  // :60-62
+            hipLaunchKernelGGL(k_row_normalize, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N,
+                               isF, P.rp, P.va);
+            IPD_KERNEL_CHECK();
+        }
+    }
+    // Ac = Pro'*A*Pro, evaluated left to right                               transfer.m:66
+    Csr Pt, T1, C;
+    csr_transpose(ctx, dst, P, &Pt);
+    csr_spgemm(ctx, tmp, Pt, A, &T1);
+    csr_spgemm(ctx, dst, T1, P, &C);
+    *Ac = C;
+    *Pout = P;
+    *Ptout = Pt;
+}
+
+// ---------------------------------------------------------------------------
+// hierarchy                                           (AMG/Class_AMG.m:20-85)
+// ---------------------------------------------------------------------------
+AmgOpts amg_fill_defaults(const ipd_amg_opts* in) {
+    AmgOpts o;  // Class_AMG.m:26-34 empty-field defaults
+    if (!in) return o;
+    if (in->retol >= 0) o.retol = in->retol;
+    if (in->bigph >= 0) o.bigph = in->bigph;
+    if (in->maxit >= 0) o.maxit = in->maxit;
+    if (in->theta >= 0) o.theta = in->theta;
+    if (in->smoth >= 0) o.smoth = in->smoth;
+    if (in->cycle >= 0) o.cycle = in->cycle;
+    if (in->isnsp >= 0) o.isnsp = in->isnsp;
+    if (in->inter >= 0) o.inter = in->inter;
+    o.fnode = in->fnode;
+    return o;
+}
+
+// 1 + fix(size(A,1)^(1/3)) in floating point (Class_AMG.m:76)
+int amg_coarsest_threshold(int N) { return 1 + (int)std::floor(std::pow((double)N, 1.0 / 3.0)); }
+
+ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng) {
+    IPD_REQUIRE(A.nr == A.nc && A.nr > 0, IPD_E_ARG, "Class_AMG: A must be square and non-empty");
+    if (o.bigph)  // Class_AMG.m:36-40
+        IPD_REQUIRE(o.fnode > 0, IPD_E_ARG, "amg_options.bigph = 1 requires Nf > 0");
+    IPD_REQUIRE(o.smoth >= 0 && o.maxit >= 0, IPD_E_ARG, "negative smoth/maxit");
+    std::unique_ptr<ipd_amg> h(new ipd_amg());
+    h->ctx = ctx;
+    h->arena.reset(new Arena(&ctx->pool));
+    h->opts = o;
+    h->L.resize(2);
+    h->J = 1;
+    csr_copy(ctx, *h->arena, A, &h->L[1].A);
+    h->L[1].N = A.nr;
+    const int thr = amg_coarsest_threshold(A.nr);
+    while (h->L[h->J].A.nr > thr) {                                          // :76
+        IPD_REQUIRE(h->J < 40, IPD_E_NUMERIC, "Class_AMG: coarsening stalled (40 levels)");
+        const Csr& Ak = h->L[h->J].A;
+        Level nl;
+        nl.cmask = h->arena->alloc<uint8_t>((size_t)Ak.nr);
+        amg_transfer(ctx, *h->arena, Ak, o, h->J, rng, &nl.A, &nl.P, &nl.Pt, nl.cmask);
+        nl.N = nl.A.nr;
+        IPD_REQUIRE(nl.N < Ak.nr, IPD_E_NUMERIC,
+                    "Class_AMG: coarsening made no progress (the reference would loop forever)");
+        h->L.push_back(nl);
+        h->J += 1;
+    }
+    amg_prepare_levels(h.get());
+    return h.release();
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" int ipd_strength(ipd_ctx* ctx, const ipd_csc* A, int which, ipd_csc_out* S) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && A && S, IPD_E_ARG, "NULL argument");
+        IPD_REQUIRE(which == 1 || which == 2, IPD_E_ARG, "strength: which must be 1 or 2");
+        CallScope scope(ctx);
+        Arena& tmp = *ctx->scratch;
+        Csr a;
+        csr_upload_from_csc(ctx, tmp, A, false, &a);
+        double* maxrow = tmp.alloc<double>((size_t)a.nr);
+        double* diag = tmp.alloc<double>((size_t)a.nr);
+        Csr v = a;
+        v.va = tmp.alloc<double>((size_t)a.nnz);
+        hipLaunchKernelGGL(k_rowmax, dim3(rows_grid(a.nr)), dim3(256), 0, ctx->stream, a.nr, a.rp,
+                           a.ci, a.va, maxrow, diag);
+        hipLaunchKernelGGL(k_strength_values, dim3(rows_grid(a.nr)), dim3(256), 0, ctx->stream, a.nr,
+                           a.rp, a.ci, a.va, maxrow, which, v.va);
+        IPD_KERNEL_CHECK();
+        Csr clean;
+        csr_drop_zeros(ctx, tmp, v, &clean);
+        csr_download_as_csc(ctx, clean, false, S);
+    });
+}
+
+extern "C" int ipd_cf_split(ipd_ctx* ctx, const ipd_csc* S, uint8_t* indC, uint8_t* indF) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && S && indC && indF, IPD_E_ARG, "NULL argument");
+        IPD_REQUIRE(S->nrows == S->ncols, IPD_E_ARG, "cf_split: S must be square");
+        CallScope scope(ctx);
+        Arena& tmp = *ctx->scratch;
+        Csr s;
+        csr_upload_from_csc(ctx, tmp, S, true, &s);  // graph(S) requires a symmetric S
+        uint8_t* dC = tmp.alloc<uint8_t>((size_t)s.nr);
+        uint8_t* dF = tmp.alloc<uint8_t>((size_t)s.nr);
+        amg_cf_split(ctx, s, dC, dF);
+        ctx->fetch(dC, indC, (size_t)s.nr);
+        ctx->fetch(dF, indF, (size_t)s.nr);
+    });
+}
+
+// strong flags (aligned with A's pattern) -> CSR pattern matrix with values 1
+__global__ void k_flag_to_value(int nnz, const uint8_t* __restrict__ f, double* __restrict__ v) {
+    THREAD_ELEMS(i, nnz) v[i] = f[i] ? 1.0 : 0.0;
+}
+
+extern "C" int ipd_mis_set(ipd_ctx* ctx, const ipd_csc* A, double theta, ipd_rng* rng,
+                           uint8_t* isC, uint8_t* isF, ipd_csc_out* As) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && A && rng && isC && isF, IPD_E_ARG, "NULL argument");
+        IPD_REQUIRE(A->nrows == A->ncols, IPD_E_ARG, "mis_set: A must be square");
+        CallScope scope(ctx);
+        Arena& tmp = *ctx->scratch;
+        Csr a;
+        csr_upload_from_csc(ctx, tmp, A, false, &a);
+        uint8_t* dC = tmp.alloc<uint8_t>((size_t)a.nr);
+        uint8_t* dF = tmp.alloc<uint8_t>((size_t)a.nr);
+        uint8_t* strong = tmp.alloc<uint8_t>((size_t)std::max(a.nnz, 1));
+        amg_mis_set(ctx, a, theta, rng, dC, dF, strong);
+        ctx->fetch(dC, isC, (size_t)a.nr);
+        ctx->fetch(dF, isF, (size_t)a.nr);
+        if (As) {
+            Csr v = a;
+            v.va = tmp.alloc<double>((size_t)std::max(a.nnz, 1));
+            hipLaunchKernelGGL(k_flag_to_value, dim3(elems_grid(a.nnz)), dim3(256), 0, ctx->stream,
+                               a.nnz, strong, v.va);
+            IPD_KERNEL_CHECK();
+            Csr clean;
+            csr_drop_zeros(ctx, tmp, v, &clean);
+            csr_download_as_csc(ctx, clean, false, As);
+        }
+    });
+}
+
+extern "C" int ipd_transfer(ipd_ctx* ctx, const ipd_csc* A, const ipd_amg_opts* o, int level,
+                            ipd_rng* rng, ipd_csc_out* Ac, ipd_csc_out* Pro, uint8_t* indC) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && A && Ac && Pro, IPD_E_ARG, "NULL argument");
+        CallScope scope(ctx);
+        AmgOpts opts = amg_fill_defaults(o);
+        Arena out(&ctx->pool);
+        Csr a, c, p, pt;
+        csr_upload_from_csc(ctx, out, A, true, &a);
+        uint8_t* cmask = out.alloc<uint8_t>((size_t)a.nr);
+        amg_transfer(ctx, out, a, opts, level, rng, &c, &p, &pt, cmask);
+        csr_download_as_csc(ctx, c, false, Ac);
+        csr_download_as_csc(ctx, pt, true, Pro);  // CSR of Pro' == CSC of Pro
+        if (indC) ctx->fetch(cmask, indC, (size_t)a.nr);
+        ctx->sync();
+    });
+}
+
+extern "C" int ipd_amg_setup_dev(ipd_ctx* ctx, const ipd_dmat* A, const ipd_amg_opts* o,
+                                 ipd_rng* rng, ipd_amg** out) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && A && out, IPD_E_ARG, "NULL argument");
+        CallScope scope(ctx);
+        *out = amg_setup(ctx, A->m, amg_fill_defaults(o), rng);
+    });
+}
+
+extern "C" int ipd_amg_setup(ipd_ctx* ctx, const ipd_csc* A, const ipd_amg_opts* o, ipd_rng* rng,
+                             ipd_amg** out) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && A && out, IPD_E_ARG, "NULL argument");
+        CallScope scope(ctx);
+        Arena up(&ctx->pool);
+        Csr a;
+        csr_upload_from_csc(ctx, up, A, true, &a);
+        *out = amg_setup(ctx, a, amg_fill_defaults(o), rng);
+        ctx->sync();
+    });
+}
+
+extern "C" void ipd_amg_destroy(ipd_amg* h) {
+    if (!h) return;
+    if (h->ctx) {
+        (void)hipSetDevice(h->ctx->device);
+        (void)hipStreamSynchronize(h->ctx->stream);
+    }
+    delete h;
+}
+
+extern "C" int ipd_amg_num_levels(const ipd_amg* h) { return h ? h->J : IPD_E_ARG; }
+
+extern "C" int ipd_amg_level_dims(const ipd_amg* h, int k, int64_t* rows, int64_t* nnz) {
+    if (!h || k < 1 || k > h->J) return IPD_E_ARG;
+    if (rows) *rows = h->L[k].A.nr;
+    if (nnz) *nnz = h->L[k].A.nnz;
+    return IPD_OK;
+}
+
+extern "C" int ipd_amg_get_A(const ipd_amg* h, int k, ipd_csc_out* A) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && A && k >= 1 && k <= h->J, IPD_E_ARG, "bad level");
+        CallScope scope(h->ctx);
+        csr_download_as_csc(h->ctx, h->L[k].A, false, A);
+    });
+}
+
+extern "C" int ipd_amg_get_P(const ipd_amg* h, int k, ipd_csc_out* P) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && P && k >= 2 && k <= h->J, IPD_E_ARG, "bad level (Prok{k} exists for k>=2)");
+        CallScope scope(h->ctx);
+        csr_download_as_csc(h->ctx, h->L[k].Pt, true, P);
+    });
+}
+
+extern "C" int ipd_amg_get_cmask(const ipd_amg* h, int k, uint8_t* isC) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && isC && k >= 2 && k <= h->J, IPD_E_ARG, "bad level");
+        CallScope scope(h->ctx);
+        h->ctx->fetch(h->L[k].cmask, isC, (size_t)h->L[k - 1].A.nr);
+    });
+}

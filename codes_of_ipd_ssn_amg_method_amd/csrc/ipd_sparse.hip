@@ -1,0 +1,461 @@
+// Device sparse-matrix utilities: upload/download in MATLAB's CSC layout,
+// deterministic transpose, ordered SpGEMM, scans, generic CSR SpMV.
+//
+// Arithmetic order contract: every setup-phase product
+// accumulates each output entry in ascending inner index with a separate
+// multiply and add -- the order MATLAB's column-Gustavson sparse mtimes uses,
+// restated row-wise -- so hierarchy matrices are bit-identical to the oracle's.
+// This TU is compiled with -ffp-contract=off.
+#pragma clang fp contract(off)
+
+#include "ipd_internal.h"
+
+#include <cstdlib>
+
+// ---------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ void k_fill(T* p, T v, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+template <class T>
+static void fill_t(ipd_ctx* ctx, T* p, T v, size_t n) {
+    if (n == 0) return;
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_fill<T>, dim3(blocks), dim3(256), 0, ctx->stream, p, v, n);
+    IPD_KERNEL_CHECK();
+}
+void fill_i32(ipd_ctx* ctx, int* p, int v, size_t n) { fill_t(ctx, p, v, n); }
+void fill_f64(ipd_ctx* ctx, double* p, double v, size_t n) { fill_t(ctx, p, v, n); }
+void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n) { fill_t(ctx, p, v, n); }
+
+// Exclusive scan of n ints by ONE workgroup (n is a row/column count, at most a
+// few thousand on this path); out[n] receives the total.  in == out is allowed.
+__global__ __launch_bounds__(1024) void k_exscan(const int* __restrict__ in, int* out, int n) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? in[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int s = wsum[k];
+            if (k < w) woff += s;
+            total += s;
+        }
+        if (i < n) out[i] = carry + woff + x - v;
+        carry += total;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+}
+
+void exclusive_scan_i32(ipd_ctx* ctx, const int* in, int* out, int n) {
+    hipLaunchKernelGGL(k_exscan, dim3(1), dim3(1024), 0, ctx->stream, in, out, n);
+    IPD_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// allocation / copies
+// ---------------------------------------------------------------------------
+Csr csr_alloc(Arena& a, int nr, int nc, int nnz) {
+    Csr m;
+    m.nr = nr;
+    m.nc = nc;
+    m.nnz = nnz;
+    m.rp = a.alloc<int>((size_t)nr + 1);
+    m.ci = a.alloc<int>((size_t)nnz);
+    m.va = a.alloc<double>((size_t)nnz);
+    return m;
+}
+
+void csr_copy(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out) {
+    Csr m = csr_alloc(dst, A.nr, A.nc, A.nnz);
+    IPD_HIP(hipMemcpyAsync(m.rp, A.rp, sizeof(int) * ((size_t)A.nr + 1), hipMemcpyDeviceToDevice,
+                           ctx->stream));
+    if (A.nnz) {
+        IPD_HIP(hipMemcpyAsync(m.ci, A.ci, sizeof(int) * (size_t)A.nnz, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+        IPD_HIP(hipMemcpyAsync(m.va, A.va, sizeof(double) * (size_t)A.nnz,
+                               hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    *out = m;
+}
+
+// ---------------------------------------------------------------------------
+// deterministic transpose through a per-column row bitmap
+// ---------------------------------------------------------------------------
+// Row r of A sets bit r of column c's bitmap for every stored (r,c); the slot of
+// (r,c) inside column c is the number of set bits below r.  Integer atomics
+// (OR) give a placement that is independent of execution order, so the result
+// has ascending row indices without any sort.
+__global__ void k_tr_mark(int nr, const int* __restrict__ rp, const int* __restrict__ ci,
+                          unsigned* __restrict__ bits, int wpc) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < nr; r += nwaves) {
+        const int b = rp[r], e = rp[r + 1];
+        for (int t = b + lane; t < e; t += 64)
+            atomicOr(&bits[(size_t)ci[t] * wpc + (r >> 5)], 1u << (r & 31));
+    }
+}
+
+// one wave per column: exclusive prefix of popcounts over the column's words
+__global__ void k_tr_prefix(int nc, const unsigned* __restrict__ bits, int* __restrict__ pref,
+                            int* __restrict__ cnt, int wpc) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int c = wave; c < nc; c += nwaves) {
+        int carry = 0;
+        for (int base = 0; base < wpc; base += 64) {
+            const int w = base + lane;
+            const int v = w < wpc ? __popc(bits[(size_t)c * wpc + w]) : 0;
+            int x = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                int y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            if (w < wpc) pref[(size_t)c * wpc + w] = carry + x - v;
+            carry += __shfl(x, 63);
+        }
+        if (lane == 0) cnt[c] = carry;
+    }
+}
+
+__global__ void k_tr_scatter(int nr, const int* __restrict__ rp, const int* __restrict__ ci,
+                             const double* __restrict__ va, const unsigned* __restrict__ bits,
+                             const int* __restrict__ pref, int wpc, const int* __restrict__ trp,
+                             int* __restrict__ tci, double* __restrict__ tva) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < nr; r += nwaves) {
+        const int b = rp[r], e = rp[r + 1];
+        const unsigned below = (1u << (r & 31)) - 1u;
+        for (int t = b + lane; t < e; t += 64) {
+            const int c = ci[t];
+            const size_t w = (size_t)c * wpc + (r >> 5);
+            const int pos = trp[c] + pref[w] + __popc(bits[w] & below);
+            tci[pos] = r;
+            tva[pos] = va[t];
+        }
+    }
+}
+
+void csr_transpose(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* At) {
+    Arena& tmp = *ctx->scratch;
+    const int wpc = (A.nr + 31) / 32;
+    const size_t words = (size_t)A.nc * (size_t)(wpc ? wpc : 1);
+    IPD_REQUIRE(words * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
+                "csr_transpose: matrix too large for the bitmap transpose (limit 2 GiB)");
+    Csr T = csr_alloc(dst, A.nc, A.nr, A.nnz);
+    unsigned* bits = tmp.alloc<unsigned>(words);
+    int* pref = tmp.alloc<int>(words);
+    int* cnt = tmp.alloc<int>((size_t)A.nc + 1);
+    IPD_HIP(hipMemsetAsync(bits, 0, words * sizeof(unsigned), ctx->stream));
+    const int rows_blocks = std::max(1, std::min(cdiv(A.nr, 4), 2048));
+    const int cols_blocks = std::max(1, std::min(cdiv(A.nc, 4), 2048));
+    if (A.nnz) {
+        hipLaunchKernelGGL(k_tr_mark, dim3(rows_blocks), dim3(256), 0, ctx->stream, A.nr, A.rp,
+                           A.ci, bits, wpc);
+        IPD_KERNEL_CHECK();
+    }
+    hipLaunchKernelGGL(k_tr_prefix, dim3(cols_blocks), dim3(256), 0, ctx->stream, A.nc, bits, pref,
+                       cnt, wpc);
+    IPD_KERNEL_CHECK();
+    exclusive_scan_i32(ctx, cnt, T.rp, A.nc);
+    if (A.nnz) {
+        hipLaunchKernelGGL(k_tr_scatter, dim3(rows_blocks), dim3(256), 0, ctx->stream, A.nr, A.rp,
+                           A.ci, A.va, bits, pref, wpc, T.rp, T.ci, T.va);
+        IPD_KERNEL_CHECK();
+    }
+    *At = T;
+}
+
+// ---------------------------------------------------------------------------
+// host <-> device in MATLAB's CSC layout
+// ---------------------------------------------------------------------------
+void csr_upload_from_csc(ipd_ctx* ctx, Arena& a, const ipd_csc* A, bool symmetric, Csr* out) {
+    IPD_REQUIRE(A && A->jc && (A->nnz == 0 || (A->ir && A->pr)), IPD_E_ARG,
+                "sparse input: NULL array");
+    IPD_REQUIRE(A->nrows >= 0 && A->ncols >= 0 && A->nnz >= 0, IPD_E_ARG,
+                "sparse input: negative dimension");
+    IPD_REQUIRE(A->nrows < (int64_t(1) << 30) && A->ncols < (int64_t(1) << 30) &&
+                    A->nnz < (int64_t(1) << 31) - 64,
+                IPD_E_LIMIT, "sparse input: dimensions exceed the int32 device index range");
+    const int nr = (int)A->nrows, nc = (int)A->ncols, nnz = (int)A->nnz;
+    IPD_REQUIRE(A->jc[0] == 0 && A->jc[nc] == nnz, IPD_E_ARG, "sparse input: bad column pointers");
+    std::vector<int> jc((size_t)nc + 1), ir((size_t)nnz);
+    for (int c = 0; c <= nc; ++c) jc[c] = (int)A->jc[c];
+    for (int c = 0; c < nc; ++c) {
+        IPD_REQUIRE(A->jc[c] <= A->jc[c + 1], IPD_E_ARG, "sparse input: column pointers decrease");
+        for (int64_t t = A->jc[c]; t < A->jc[c + 1]; ++t) {
+            const int64_t r = A->ir[t];
+            IPD_REQUIRE(r >= 0 && r < nr, IPD_E_ARG, "sparse input: row index out of range");
+            IPD_REQUIRE(t == A->jc[c] || A->ir[t - 1] < r, IPD_E_ARG,
+                        "sparse input: row indices must be strictly ascending per column");
+            ir[t] = (int)r;
+        }
+    }
+    // The CSC arrays of A are the CSR arrays of A'.
+    Arena& where = symmetric ? a : *ctx->scratch;
+    Csr T = csr_alloc(where, nc, nr, nnz);
+    ctx->upload(T.rp, jc.data(), (size_t)nc + 1);
+    if (nnz) {
+        ctx->upload(T.ci, ir.data(), (size_t)nnz);
+        ctx->upload(T.va, A->pr, (size_t)nnz);
+    }
+    if (symmetric) {
+        IPD_REQUIRE(nr == nc, IPD_E_ARG, "symmetric sparse input must be square");
+        *out = T;
+    } else {
+        csr_transpose(ctx, a, T, out);
+    }
+}
+
+void csr_download_as_csc(ipd_ctx* ctx, const Csr& m, bool is_transposed, ipd_csc_out* out) {
+    IPD_REQUIRE(out, IPD_E_ARG, "output matrix is NULL");
+    Csr T = m;  // CSR arrays of A' == CSC arrays of A
+    if (!is_transposed) csr_transpose(ctx, *ctx->scratch, m, &T);
+    const int ncols = T.nr, nrows = T.nc, nnz = T.nnz;
+    std::vector<int> rp((size_t)ncols + 1), ci((size_t)nnz);
+    out->nrows = nrows;
+    out->ncols = ncols;
+    out->nnz = nnz;
+    out->jc = (int64_t*)std::malloc(sizeof(int64_t) * ((size_t)ncols + 1));
+    out->ir = (int64_t*)std::malloc(sizeof(int64_t) * (size_t)(nnz ? nnz : 1));
+    out->pr = (double*)std::malloc(sizeof(double) * (size_t)(nnz ? nnz : 1));
+    if (!out->jc || !out->ir || !out->pr) {
+        ipd_csc_free(out);
+        throw IpdError(IPD_E_NOMEM, "out of host memory");
+    }
+    ctx->fetch(T.rp, rp.data(), (size_t)ncols + 1);
+    if (nnz) {
+        ctx->fetch(T.ci, ci.data(), (size_t)nnz);
+        ctx->fetch(T.va, out->pr, (size_t)nnz);
+    }
+    for (int c = 0; c <= ncols; ++c) out->jc[c] = rp[c];
+    for (int t = 0; t < nnz; ++t) out->ir[t] = ci[t];
+}
+
+// ---------------------------------------------------------------------------
+// generic CSR SpMV  y = A*x   (utility / ipd_spmv_dev; the cycle has fused forms)
+// ---------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(256) void k_spmv(int nr, const int* __restrict__ rp,
+                                              const int* __restrict__ ci,
+                                              const double* __restrict__ va,
+                                              const double* __restrict__ x,
+                                              double* __restrict__ y) {
+    const int gl = threadIdx.x & (L - 1);
+    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) / L;
+    const int ngrp = (gridDim.x * blockDim.x) / L;
+    for (int r = grp; r < nr; r += ngrp) {
+        const int b = rp[r], e = rp[r + 1];
+        double s = 0.0;
+        for (int t = b + gl; t < e; t += L) s += va[t] * x[ci[t]];
+#pragma unroll
+        for (int d = L >> 1; d > 0; d >>= 1) s += __shfl_xor(s, d);
+        if (gl == 0) y[r] = s;
+    }
+}
+
+void csr_spmv(ipd_ctx* ctx, const Csr& A, const double* x, double* y) {
+    if (A.nr == 0) return;
+    const double avg = (double)A.nnz / (double)A.nr;
+    auto launch = [&](auto kern, int L) {
+        const long long threads = (long long)A.nr * L;
+        const int blocks = (int)std::max<long long>(1, std::min<long long>((threads + 255) / 256, 8192));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, ctx->stream, A.nr, A.rp, A.ci, A.va, x,
+                           y);
+        IPD_KERNEL_CHECK();
+    };
+    if (avg <= 6)
+        launch(k_spmv<4>, 4);
+    else if (avg <= 24)
+        launch(k_spmv<16>, 16);
+    else
+        launch(k_spmv<64>, 64);
+}
+
+// ---------------------------------------------------------------------------
+// ordered SpGEMM  C = X*Y
+// ---------------------------------------------------------------------------
+// One single-wave workgroup per output row keeps a dense accumulator row in
+// LDS.  The inner-index loop is sequential (ascending k = ascending stored
+// order of X's row) and lanes only split the columns of Y's row k, which are
+// distinct, so every C(i,j) receives its terms one at a time in ascending k:
+// bit-identical to a sequential Gustavson product.  The dense row goes to a
+// scratch matrix; a second kernel compacts rows (exact zeros dropped, as
+// MATLAB's sparse mtimes does).
+__global__ __launch_bounds__(64) void k_spgemm_rows(int nr, int nc, const int* __restrict__ xrp,
+                                                    const int* __restrict__ xci,
+                                                    const double* __restrict__ xva,
+                                                    const int* __restrict__ yrp,
+                                                    const int* __restrict__ yci,
+                                                    const double* __restrict__ yva,
+                                                    double* __restrict__ dense,
+                                                    int* __restrict__ rowcnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* acc = reinterpret_cast<double*>(smem_raw);
+    const int lane = threadIdx.x;
+    for (int i = blockIdx.x; i < nr; i += gridDim.x) {
+        for (int j = lane; j < nc; j += 64) acc[j] = 0.0;
+        __syncthreads();
+        const int xb = xrp[i], xe = xrp[i + 1];
+        for (int e = xb; e < xe; ++e) {
+            const int k = xci[e];
+            const double a = xva[e];
+            const int yb = yrp[k], ye = yrp[k + 1];
+            for (int t = yb + lane; t < ye; t += 64) {
+                const int j = yci[t];
+                const double prod = a * yva[t];
+                acc[j] = acc[j] + prod;
+            }
+            __syncthreads();
+        }
+        int nz = 0;
+        double* drow = dense + (size_t)i * nc;
+        for (int j = lane; j < nc; j += 64) {
+            const double v = acc[j];
+            drow[j] = v;
+            nz += (v != 0.0);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d);
+        if (lane == 0) rowcnt[i] = nz;
+        __syncthreads();
+    }
+}
+
+// one wave per row: ordered compaction of the dense row into CSR
+__global__ __launch_bounds__(256) void k_dense_compact(int nr, int nc,
+                                                       const double* __restrict__ dense,
+                                                       const int* __restrict__ rp,
+                                                       int* __restrict__ ci,
+                                                       double* __restrict__ va) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < nr; i += nwaves) {
+        int base = rp[i];
+        const double* drow = dense + (size_t)i * nc;
+        for (int j0 = 0; j0 < nc; j0 += 64) {
+            const int j = j0 + lane;
+            const double v = j < nc ? drow[j] : 0.0;
+            const bool nzf = v != 0.0;
+            const unsigned long long mask = __ballot(nzf);
+            if (nzf) {
+                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                ci[pos] = j;
+                va[pos] = v;
+            }
+            base += __popcll(mask);
+        }
+    }
+}
+
+void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
+    IPD_REQUIRE(X.nc == Y.nr, IPD_E_ARG, "spgemm: inner dimensions differ");
+    const int nr = X.nr, nc = Y.nc;
+    IPD_REQUIRE((size_t)nc * 8 <= 128 * 1024, IPD_E_LIMIT,
+                "spgemm: more than 16384 columns (LDS accumulator row limit)");
+    const size_t dense_elems = (size_t)(nr ? nr : 1) * (size_t)(nc ? nc : 1);
+    IPD_REQUIRE(dense_elems * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
+                "spgemm: dense scratch above 2 GiB");
+    Arena& tmp = *ctx->scratch;
+    double* dense = tmp.alloc<double>(dense_elems);
+    int* rowcnt = tmp.alloc<int>((size_t)nr + 1);
+    Csr out;
+    out.nr = nr;
+    out.nc = nc;
+    out.rp = dst.alloc<int>((size_t)nr + 1);
+    if (nr > 0) {
+        const size_t lds = std::max<size_t>((size_t)nc * 8, 16);
+        static bool attr_set = false;
+        if (!attr_set) {
+            IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_spgemm_rows),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_spgemm_rows, dim3(std::min(nr, 16384)), dim3(64), lds, ctx->stream, nr,
+                           nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense, rowcnt);
+        IPD_KERNEL_CHECK();
+    }
+    exclusive_scan_i32(ctx, rowcnt, out.rp, nr);
+    out.nnz = ctx->fetch1(out.rp + nr);
+    out.ci = dst.alloc<int>((size_t)out.nnz);
+    out.va = dst.alloc<double>((size_t)out.nnz);
+    if (out.nnz) {
+        hipLaunchKernelGGL(k_dense_compact, dim3(std::max(1, std::min(cdiv(nr, 4), 4096))), dim3(256),
+                           0, ctx->stream, nr, nc, dense, out.rp, out.ci, out.va);
+        IPD_KERNEL_CHECK();
+    }
+    *C = out;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI: device matrices
+// ---------------------------------------------------------------------------
+extern "C" int ipd_dmat_upload(ipd_ctx* ctx, const ipd_csc* A, int symmetric, ipd_dmat** out) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && out, IPD_E_ARG, "NULL argument");
+        CallScope scope(ctx);
+        std::unique_ptr<ipd_dmat> d(new ipd_dmat());
+        d->ctx = ctx;
+        d->arena.reset(new Arena(&ctx->pool));
+        csr_upload_from_csc(ctx, *d->arena, A, symmetric != 0, &d->m);
+        ctx->sync();
+        *out = d.release();
+    });
+}
+
+extern "C" int ipd_dmat_download(ipd_ctx* ctx, const ipd_dmat* A, ipd_csc_out* out) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && A && out, IPD_E_ARG, "NULL argument");
+        CallScope scope(ctx);
+        csr_download_as_csc(ctx, A->m, false, out);
+    });
+}
+
+extern "C" int ipd_dmat_dims(const ipd_dmat* A, int64_t* rows, int64_t* cols, int64_t* nnz) {
+    if (!A) return IPD_E_ARG;
+    if (rows) *rows = A->m.nr;
+    if (cols) *cols = A->m.nc;
+    if (nnz) *nnz = A->m.nnz;
+    return IPD_OK;
+}
+
+extern "C" void ipd_dmat_destroy(ipd_dmat* A) {
+    if (!A) return;
+    if (A->ctx) {
+        (void)hipSetDevice(A->ctx->device);
+        (void)hipStreamSynchronize(A->ctx->stream);
+    }
+    delete A;
+}
+
+extern "C" int ipd_spmv_dev(ipd_ctx* ctx, const ipd_dmat* A, const double* x, double* y) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && A && x && y, IPD_E_ARG, "NULL argument");
+        CallScope scope(ctx);
+        csr_spmv(ctx, A->m, x, y);
+    });
+}

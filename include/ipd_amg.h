@@ -1,0 +1,252 @@
+/*
+ * ipd_amg.h -- C ABI of libipdamg, the MI355X-native (gfx950, hand-written HIP)
+ * implementation of the AMG V/W-cycle solve and the ASAt KKT assembly of
+ * zihang-student/Codes-of-IPD-SsN-AMG-method.
+ *
+ * The reference has no FFI layer: its boundary is the MATLAB function
+ * signature set itself.  Each entry point below names the
+ * MATLAB signature (reference file:line) it replaces; the MEX gateway that a
+ * maintainer adds on the reference side is `codes_of_ipd_ssn_amg_method_amd/
+ * mex/ipd_mex.cpp`, described in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative IPD_E_* code on failure;
+ *    ipd_last_error() returns the thread-local message of the last failure
+ *    (the MEX shim forwards it through mexErrMsgIdAndTxt, mirroring MATLAB's
+ *    error()).
+ *  - sparse matrices cross the boundary in MATLAB's own layout: compressed
+ *    sparse column, 0-based int64 indices (binary compatible with mwIndex),
+ *    float64 values, row indices ascending, no explicit zeros.
+ *  - dense vectors are float64, matrices column-major; logical vectors are one
+ *    byte per entry (mxLogical).
+ *  - the caller owns every input buffer; nothing is retained after the call
+ *    except by an explicit handle (ipd_amg, ipd_dmat).  Output matrices are
+ *    library-owned host buffers released with ipd_csc_free().
+ *  - pointers are HOST pointers unless the function name ends in `_dev`.
+ *  - all arithmetic is IEEE float64; there is no CPU fallback: every entry
+ *    point fails with IPD_E_HIP when no gfx950 device is usable.
+ */
+#ifndef IPD_AMG_H
+#define IPD_AMG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPD_VERSION 100 /* 0.1.0 */
+
+enum {
+    IPD_OK = 0,
+    IPD_E_ARG = -1,      /* bad argument (the reference's error() guards)    */
+    IPD_E_HIP = -2,      /* HIP runtime failure / no device                  */
+    IPD_E_NOMEM = -3,
+    IPD_E_LIMIT = -4,    /* size above a documented library limit            */
+    IPD_E_NUMERIC = -5,  /* e.g. coarsening stalled, zero pivot              */
+    IPD_E_UNSUPPORTED = -6,
+    IPD_E_COMM = -7      /* RCCL failure                                     */
+};
+
+typedef struct ipd_ctx ipd_ctx;   /* one per process+GPU: device, stream, workspace   */
+typedef struct ipd_rng ipd_rng;   /* MATLAB-compatible rand stream (mt19937ar)        */
+typedef struct ipd_amg ipd_amg;   /* device-resident hierarchy: Ack, Prok, Rk, J      */
+typedef struct ipd_dmat ipd_dmat; /* device-resident sparse matrix (CSR, int32+fp64)  */
+
+/* Host view of a MATLAB sparse matrix (read-only input). */
+typedef struct ipd_csc {
+    int64_t nrows, ncols, nnz;
+    const int64_t* jc; /* ncols+1 column pointers */
+    const int64_t* ir; /* nnz row indices         */
+    const double* pr;  /* nnz values              */
+} ipd_csc;
+
+/* Library-owned output matrix (same layout); release with ipd_csc_free. */
+typedef struct ipd_csc_out {
+    int64_t nrows, ncols, nnz;
+    int64_t* jc;
+    int64_t* ir;
+    double* pr;
+} ipd_csc_out;
+
+/* amg_options struct (Class1/APD_SsN_Class1.m:87-88, AMG/Class_AMG.m:20-34).
+ * Unset numeric fields use the sentinel -1 ("isempty" in MATLAB) and receive
+ * Class_AMG's empty-field defaults. */
+typedef struct ipd_amg_opts {
+    double retol;   /* default 1e-12 */
+    int32_t bigph;  /* default 0     */
+    int32_t maxit;  /* default 50    */
+    double theta;   /* default 1/4   */
+    int32_t smoth;  /* default 3     */
+    int32_t cycle;  /* 'v' or 'w' (ASCII); default 'v'; any other value: no correction (quirk A-8) */
+    int32_t isnsp;  /* default 0     */
+    int32_t inter;  /* default 1 (ignored for inter<2, transfer.m:54 quirk)  */
+    int64_t fnode;  /* required >0 when bigph                                */
+} ipd_amg_opts;
+
+/* pcg_options struct (PCG.m:18-27). */
+typedef struct ipd_pcg_opts {
+    double retol;   /* default 1e-11 */
+    int64_t maxit;  /* default 10000 */
+    int32_t precd;  /* 1 none, 2 Jacobi (device); 3,4,5 -> IPD_E_UNSUPPORTED */
+} ipd_pcg_opts;
+
+/* prob_data struct (Class1/APD_SsN_Class1.m:154-156, Class2/APD_SsN_Class2.m:163-166). */
+typedef struct ipd_prob {
+    int64_t m, n;      /* length(p), length(q)                                */
+    double bk1, tk;
+    const double* p;   /* m */
+    const double* q;   /* n */
+    const double* t;   /* diag(T), n+m entries, or NULL for T = 0             */
+    const ipd_csc* H0; /* (n+m) x (n+m), output of ASAt                       */
+    const double* z;   /* n+m  (n+m+1 for AMG4POT)                            */
+    const uint8_t* s;  /* m*n logical, AMG4POT only                           */
+    const double* phi; /* m*n, AMG4POT only                                   */
+} ipd_prob;
+
+/* ---- library / context -------------------------------------------------- */
+int ipd_version(void);
+const char* ipd_last_error(void);
+int ipd_ctx_create(int device, ipd_ctx** out);
+void ipd_ctx_destroy(ipd_ctx* ctx);
+int ipd_ctx_sync(ipd_ctx* ctx);
+void ipd_csc_free(ipd_csc_out* mat);
+void ipd_amg_opts_init(ipd_amg_opts* o); /* all fields "empty"               */
+void ipd_pcg_opts_init(ipd_pcg_opts* o);
+
+/* ---- rand stream (Hybrid_AMG.m:40,69; AMG/mis_set.m:31,35) --------------- */
+/* mt19937ar seeded like MATLAB rng(seed); seed 5489 == MATLAB's default.    */
+int ipd_rng_create(uint32_t seed, ipd_rng** out);
+/* replays caller-supplied doubles (e.g. MATLAB's own rand output); running
+ * out of numbers is IPD_E_ARG.                                              */
+int ipd_rng_create_replay(const double* values, int64_t count, ipd_rng** out);
+void ipd_rng_destroy(ipd_rng* rng);
+int ipd_rng_rand(ipd_rng* rng, int64_t count, double* out); /* rand(count,1) */
+int64_t ipd_rng_consumed(const ipd_rng* rng);
+
+/* ---- L0/L1: matrix-free A operators and KKT assembly --------------------- */
+/* y = Ax(x,p,q)            Ax.m:2    ; y has n+m entries                     */
+int ipd_ax(ipd_ctx*, const double* x, const double* p, const double* q,
+           int64_t m, int64_t n, double* y);
+/* z = Aty(y,p,q)           Aty.m:2   ; z has m*n entries                     */
+int ipd_aty(ipd_ctx*, const double* y, const double* p, const double* q,
+            int64_t m, int64_t n, double* z);
+/* H = ASAt(s,p,q)          ASAt.m:2                                          */
+int ipd_asat(ipd_ctx*, const uint8_t* s, const double* p, const double* q,
+             int64_t m, int64_t n, ipd_csc_out* H);
+/* y = invAAt(x,p,q,sg1,sg2) invAAt.m:1 (nargin handling is the shim's job)   */
+int ipd_inv_aat(ipd_ctx*, const double* x, const double* p, const double* q,
+                int64_t m, int64_t n, double sg1, double sg2, double* y);
+/* y = invHHt(v,p,q,sg,phi)  Class2/invHHt.m:1 ; v,y have n+m+1 entries       */
+int ipd_inv_hht(ipd_ctx*, const double* v, const double* p, const double* q,
+                int64_t m, int64_t n, double sg, const double* phi, double* y);
+
+/* ---- L2: AMG setup pieces ------------------------------------------------ */
+/* S = strength(A,which)    AMG/strength.m:1                                  */
+int ipd_strength(ipd_ctx*, const ipd_csc* A, int which, ipd_csc_out* S);
+/* [indC,indF] = cf_split(S) AMG/cf_split.m:1 (SubG is rebuilt by the shim)   */
+int ipd_cf_split(ipd_ctx*, const ipd_csc* S, uint8_t* indC, uint8_t* indF);
+/* [isC,isF,As] = mis_set(A,theta)  AMG/mis_set.m:1 ; As may be NULL          */
+int ipd_mis_set(ipd_ctx*, const ipd_csc* A, double theta, ipd_rng* rng,
+                uint8_t* isC, uint8_t* isF, ipd_csc_out* As);
+/* [Ac,Pro] = transfer(A,amg_options) AMG/transfer.m:1 ; level = global J     */
+int ipd_transfer(ipd_ctx*, const ipd_csc* A, const ipd_amg_opts* o, int level,
+                 ipd_rng* rng, ipd_csc_out* Ac, ipd_csc_out* Pro, uint8_t* indC);
+
+/* ---- L3: hierarchy, cycles, PCG ----------------------------------------- */
+/* setup phase of Class_AMG (AMG/Class_AMG.m:41-85); A symmetric              */
+int ipd_amg_setup(ipd_ctx*, const ipd_csc* A, const ipd_amg_opts* o, ipd_rng* rng,
+                  ipd_amg** out);
+void ipd_amg_destroy(ipd_amg* h);
+int ipd_amg_num_levels(const ipd_amg* h);                       /* J          */
+int ipd_amg_level_dims(const ipd_amg* h, int k, int64_t* rows, int64_t* nnz);
+/* download Ack{k} (k>=1), Prok{k} (k>=2), C-mask of level k-1 -> k (k>=2)    */
+int ipd_amg_get_A(const ipd_amg* h, int k, ipd_csc_out* A);
+int ipd_amg_get_P(const ipd_amg* h, int k, ipd_csc_out* P);
+int ipd_amg_get_cmask(const ipd_amg* h, int k, uint8_t* isC /* rows of level k-1 */);
+/* solve phase of Class_AMG (AMG/Class_AMG.m:86-109).  rel_resk/rhok need
+ * maxit+1 entries (may be NULL); *it = number of cycles.                     */
+int ipd_amg_solve(ipd_amg* h, const double* b, const double* guess, double* x,
+                  int32_t* it, double* rel_res, double* rel_resk, double* rhok);
+/* e = MG_Vcycle(r,isnsp,k)   AMG/MG_Vcycle.m:2 ; k is 1-based               */
+int ipd_amg_vcycle(ipd_amg* h, const double* r, int isnsp, int k, double* e);
+/* e = MG_Wcycle(r,isnsp,k,e) AMG/MG_Wcycle.m:2 ; e_inout NULL-able input    */
+int ipd_amg_wcycle(ipd_amg* h, const double* r, int isnsp, int k,
+                   const double* e_in, double* e_out);
+/* [x,it,rel_res,rel_resk,rhok] = Class_AMG(A,b,amg_options) Class_AMG.m:1   */
+int ipd_class_amg(ipd_ctx*, const ipd_csc* A, const double* b, const double* guess,
+                  const ipd_amg_opts* o, ipd_rng* rng, double* x, int32_t* it,
+                  double* rel_res, double* rel_resk, double* rhok);
+/* [d,it,res,resk] = PCG(H,e,pcg_options)   PCG.m:1 ; resk needs maxit slots
+ * or NULL                                                                    */
+int ipd_pcg(ipd_ctx*, const ipd_csc* H, const double* e, const double* guess,
+            const ipd_pcg_opts* o, double* d, int64_t* it, double* res, double* resk);
+
+/* ---- L4: problem-level solvers ------------------------------------------ */
+/* [blocks,sizes,p,r] = components(A)  components.m:1 ; 0-based outputs,
+ * components numbered by smallest member (dmperm's order is unpinned).       */
+int ipd_components(ipd_ctx*, const ipd_csc* A, int64_t* blocks, int64_t* sizes,
+                   int64_t* p, int64_t* r, int64_t* ncomp);
+/* [zeta,itamg,resamg,info] = Hybrid_AMG(prob_data,amg_options) Hybrid_AMG.m:1 */
+int ipd_hybrid_amg(ipd_ctx*, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
+                   double* zeta, int32_t* itamg, double* resamg, int64_t info[2]);
+/* [zeta,...] = AMG4POT(prob_data,amg_options,'amg')  Class2/AMG4POT.m:1       */
+int ipd_amg4pot(ipd_ctx*, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
+                double* zeta, int32_t* itamg, double* resamg, int64_t info[2]);
+
+/* ---- device-resident path (inputs already in HBM) ------------------------ */
+/* raw device memory on the context's GPU */
+int ipd_dmalloc(ipd_ctx*, size_t bytes, void** dptr);
+int ipd_dfree(ipd_ctx*, void* dptr);
+int ipd_h2d(ipd_ctx*, void* dst_dev, const void* src_host, size_t bytes);
+int ipd_d2h(ipd_ctx*, void* dst_host, const void* src_dev, size_t bytes);
+/* device matrices */
+int ipd_dmat_upload(ipd_ctx*, const ipd_csc* A, int symmetric, ipd_dmat** out);
+int ipd_dmat_download(ipd_ctx*, const ipd_dmat* A, ipd_csc_out* out);
+int ipd_dmat_dims(const ipd_dmat* A, int64_t* rows, int64_t* cols, int64_t* nnz);
+void ipd_dmat_destroy(ipd_dmat* A);
+/* y = A*x on device vectors (CSR row walk)                                   */
+int ipd_spmv_dev(ipd_ctx*, const ipd_dmat* A, const double* x_dev, double* y_dev);
+int ipd_ax_dev(ipd_ctx*, const double* x_dev, const double* p_dev, const double* q_dev,
+               int64_t m, int64_t n, double* y_dev);
+int ipd_aty_dev(ipd_ctx*, const double* y_dev, const double* p_dev, const double* q_dev,
+                int64_t m, int64_t n, double* z_dev);
+int ipd_asat_dev(ipd_ctx*, const uint8_t* s_dev, const double* p_dev, const double* q_dev,
+                 int64_t m, int64_t n, ipd_dmat** H);
+int ipd_amg_setup_dev(ipd_ctx*, const ipd_dmat* A, const ipd_amg_opts* o, ipd_rng* rng,
+                      ipd_amg** out);
+int ipd_amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev,
+                      double* x_dev, int32_t* it, double* rel_res, double* rel_resk,
+                      double* rhok);
+/* Hybrid_AMG with H0 already on the device (output of ipd_asat_dev)          */
+int ipd_hybrid_amg_dev(ipd_ctx*, const ipd_dmat* H0, const double* t_dev, const double* p_dev,
+                       const double* q_dev, int64_t m, int64_t n, double bk1, double tk,
+                       const double* z_dev, const ipd_amg_opts* o, ipd_rng* rng,
+                       double* zeta_dev, int32_t* itamg, double* resamg, int64_t info[2]);
+
+/* ---- measurement hooks (bench.py) ---------------------------------------- */
+/* Runs `cycles` iterations of the Class_AMG loop body (residual, one V/W
+ * cycle, norm) on the fixed hierarchy without convergence exit, timed with HIP
+ * events on the context's stream.  Returns total milliseconds and, per cycle,
+ * the algorithmic byte count B_V of SURVEY.md section 8d.                     */
+int ipd_amg_bench_cycles(ipd_amg* h, const double* b_dev, double* x_dev, int cycles,
+                         double* total_ms, double* bytes_per_cycle);
+/* SURVEY 8d byte model of the hierarchy: per-level S(A_k), S(P_k), ...       */
+int ipd_amg_cycle_bytes(const ipd_amg* h, double* bytes_per_cycle);
+
+/* ---- multi-GPU row-block sharding (RCCL over xGMI) ----------------------- */
+#define IPD_COMM_ID_BYTES 128
+int ipd_comm_get_unique_id(uint8_t id[IPD_COMM_ID_BYTES]);
+int ipd_comm_init(ipd_ctx*, const uint8_t id[IPD_COMM_ID_BYTES], int rank, int nranks);
+int ipd_comm_finalize(ipd_ctx*);
+/* Row-block sharded variant of ipd_amg_bench_cycles: every rank holds the same
+ * hierarchy, owns rows [rank*N_k/G, (rank+1)*N_k/G) of every level, and the
+ * iterate is re-assembled with ncclAllGather after each smoother half-sweep.  */
+int ipd_amg_bench_cycles_sharded(ipd_amg* h, const double* b_dev, double* x_dev, int cycles,
+                                 double* total_ms, double* bytes_per_cycle);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPD_AMG_H */

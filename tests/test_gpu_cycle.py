@@ -1,0 +1,137 @@
+"""GPU parity of the solve phase: MG_Vcycle / MG_Wcycle / PCG / Class_AMG.
+Bar (north_star): residual-per-cycle within 1e-10 of the oracle; iteration
+counts identical.  Solution vectors are compared through residuals (the systems
+are nearly singular, SURVEY section 7 hard part iii)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import ipd_oracle as O
+from tests import problems as PR
+from tests.test_gpu_setup import newton_matrix
+
+pytestmark = pytest.mark.gpu
+
+RES_TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def ipd():
+    import codes_of_ipd_ssn_amg_method_amd as m
+    return m
+
+
+def test_pcg(ipd):
+    A = PR.random_sym_graph_laplacian(200, seed=10, eps=0.5)
+    b = np.random.RandomState(11).randn(200)
+    for precd in (1, 2):
+        o = dict(guess=None, retol=1e-11, maxit=1000, precd=precd)
+        d, it, res, resk = ipd.PCG(A, b, o)
+        do, ito, reso, resko = O.PCG(A, b, o)
+        assert abs(it - ito) <= 1
+        assert np.linalg.norm(A @ d - b) <= 1e-9 * np.linalg.norm(b)
+        assert np.allclose(d, do, rtol=1e-8, atol=1e-10)
+        k = min(it, ito) - 2
+        assert np.allclose(resk[:k], resko[:k], rtol=1e-6)
+    d, it, res, _ = ipd.PCG(A, np.zeros(200))
+    assert it == 0 and np.isnan(res) and not d.any()
+    with pytest.raises(ipd.IpdError):
+        ipd.PCG(A, b, dict(precd=4))
+
+
+CASES = [
+    ("tree64", 64, 64, lambda: PR.mask_tree(64, 64, seed=1)),
+    ("tree_rect", 150, 90, lambda: PR.mask_tree(150, 90, seed=2)),
+    ("tree256", 256, 256, lambda: PR.mask_tree(256, 256, seed=3)),
+    ("dense96", 96, 96, lambda: PR.mask_bernoulli(96, 96, 1.0)),
+    ("bern128", 128, 128, lambda: PR.mask_bernoulli(128, 128, 0.2)),
+]
+
+
+def _connected(Ae):
+    return sp.csgraph.connected_components(Ae)[0] == 1
+
+
+@pytest.mark.parametrize("name,m,n,mk", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("isnsp", [0, 1])
+@pytest.mark.parametrize("cycle", ["v", "w"])
+def test_single_cycle_matches_oracle(ipd, name, m, n, mk, isnsp, cycle):
+    s = mk()
+    Ae, pd = newton_matrix(m, n, s)
+    assert _connected(Ae)
+    o = O.amg_options_class1(cycle); o.update(fnode=n, isnsp=isnsp)
+    ho = O.amg_setup(Ae, o, O.matlab_rng())
+    h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+    r = np.random.RandomState(5).randn(m + n)
+    for k in range(1, ho.J + 1):
+        rk = r[:ho.Ack[k].shape[0]]
+        if cycle == "v":
+            eo = O.MG_Vcycle(ho, rk, isnsp, k)
+            e = ipd.MG_Vcycle(h, rk, isnsp, k)
+        else:
+            eo = O.MG_Wcycle(ho, rk, isnsp, k)
+            e = ipd.MG_Wcycle(h, rk, isnsp, k)
+        A = ho.Ack[k]
+        # compare through the residual (near-null-space component is ill-determined)
+        scale = np.linalg.norm(rk)
+        assert np.linalg.norm(A @ (e - eo)) <= 1e-9 * scale, (k, np.linalg.norm(A @ (e - eo)) / scale)
+    if cycle == "w" and ho.J >= 3:
+        e0 = np.random.RandomState(6).randn(ho.Ack[2].shape[0]) * 1e-3
+        rk = r[:ho.Ack[2].shape[0]]
+        eo = O.MG_Wcycle(ho, rk, isnsp, 2, e0)
+        e = ipd.MG_Wcycle(h, rk, isnsp, 2, e0)
+        assert np.linalg.norm(ho.Ack[2] @ (e - eo)) <= 1e-9 * np.linalg.norm(rk)
+    h.close()
+
+
+@pytest.mark.parametrize("name,m,n,mk", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("isnsp", [0, 1])
+@pytest.mark.parametrize("cycle", ["v", "w"])
+def test_class_amg_residual_history(ipd, name, m, n, mk, isnsp, cycle):
+    s = mk()
+    Ae, pd = newton_matrix(m, n, s)
+    f = np.concatenate([pd["q"], -pd["p"]]) * pd["z"]
+    guess = pd["bk1"] * pd["tk"] * np.random.RandomState(4).random_sample(m + n)
+    o = O.amg_options_class1(cycle); o.update(fnode=n, isnsp=isnsp, guess=guess)
+    xo, ito, relo, rko, rhoo = O.Class_AMG(Ae, f, o, O.matlab_rng())
+    x, it, rel, rk, rho = ipd.Class_AMG(Ae, f, o, ipd.MatlabRand())
+    assert it == ito
+    assert len(rk) == len(rko)
+    assert np.max(np.abs(rk - rko)) <= RES_TOL, np.max(np.abs(rk - rko))
+    big = rko > 1e-8
+    assert np.allclose(rk[big], rko[big], rtol=1e-6)
+    assert np.linalg.norm(Ae @ x - f) <= max(10 * relo, 1e-10) * np.linalg.norm(Ae @ guess - f)
+
+
+def test_class_amg_zero_rhs_and_no_cycle_quirk(ipd):
+    m = n = 32
+    Ae, pd = newton_matrix(m, n, PR.mask_tree(m, n, seed=9))
+    o = O.amg_options_class1("v"); o.update(fnode=n, isnsp=1, guess=np.zeros(m + n))
+    x, it, rel, rk, rho = ipd.Class_AMG(Ae, np.zeros(m + n), o, ipd.MatlabRand())
+    assert it == 0 and rel == 0 and not x.any()          # Class_AMG.m:91-92
+    # quirk A-8: a cycle value that is neither 'v' nor 'w' applies no correction
+    o2 = dict(o); o2["cycle"] = 1; o2["maxit"] = 3
+    f = np.ones(m + n)
+    x, it, rel, rk, rho = ipd.Class_AMG(Ae, f, o2, ipd.MatlabRand())
+    assert it == 3 and np.allclose(rk, 1.0) and not x.any()
+
+
+def test_vcycle_linearity_full_size(ipd):
+    """Size-independent property at BASELINE size (m=n=1024, M=2048): one V-cycle
+    is a linear map, e(a r1 + b r2) == a e(r1) + b e(r2)."""
+    m = n = 1024
+    s = PR.mask_tree(m, n, seed=21)
+    Ae, pd = newton_matrix(m, n, s)
+    o = O.amg_options_class1("v"); o.update(fnode=n, isnsp=1)
+    h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+    assert h.level_sizes()[0] == 2048 and h.J >= 4
+    rs = np.random.RandomState(8)
+    r1, r2 = rs.randn(m + n), rs.randn(m + n)
+    e1, e2 = ipd.MG_Vcycle(h, r1, 1), ipd.MG_Vcycle(h, r2, 1)
+    e12 = ipd.MG_Vcycle(h, 0.3 * r1 - 1.7 * r2, 1)
+    lin = 0.3 * e1 - 1.7 * e2
+    A = sp.csr_matrix(Ae)
+    assert np.linalg.norm(A @ (e12 - lin)) <= 1e-9 * np.linalg.norm(A @ lin)
+    # and the cycle contracts the residual
+    assert np.linalg.norm(r1 - A @ e1) < 0.5 * np.linalg.norm(r1)
+    h.close()

@@ -1,0 +1,129 @@
+"""GPU parity of the AMG setup: strength, cf_split, mis_set, transfer, hierarchy.
+Bar: BIT-EXACT against the oracle (C/F masks, Pro, Ac on every level)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import ipd_oracle as O
+from tests import problems as PR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ipd():
+    import codes_of_ipd_ssn_amg_method_amd as m
+    return m
+
+
+def csc_equal(A, B):
+    A = sp.csc_matrix(A); B = sp.csc_matrix(B)
+    A.sort_indices(); B.sort_indices()
+    return (A.shape == B.shape and np.array_equal(A.indptr, B.indptr)
+            and np.array_equal(A.indices, B.indices) and np.array_equal(A.data, B.data))
+
+
+def newton_matrix(m, n, s, t=None):
+    pd = PR.make_prob(m, n, s, t=t)
+    H0 = O.ASAt(s, pd["p"], pd["q"])
+    Ae = O.build_Ae(H0, pd["T"], pd["p"], pd["q"], pd["bk1"], pd["tk"])[0]
+    return Ae, pd
+
+
+@pytest.mark.parametrize("N,deg,seed", [(1, 1, 0), (17, 2, 1), (200, 3, 2), (777, 5, 3)])
+@pytest.mark.parametrize("which", [1, 2])
+def test_strength(ipd, N, deg, seed, which):
+    A = PR.random_sym_graph_laplacian(N, deg=deg, seed=seed)
+    assert csc_equal(ipd.strength(A, which), O.strength(A, which))
+
+
+@pytest.mark.parametrize("N,deg,seed", [(1, 1, 0), (40, 2, 1), (500, 3, 2), (2048, 4, 3)])
+def test_cf_split(ipd, N, deg, seed):
+    A = PR.random_sym_graph_laplacian(N, deg=deg, seed=seed)
+    As = O.strength_mask(A, 0.25)
+    S = sp.csr_matrix(((As + As.T) > 0).astype(float))
+    refC, refF = O.cf_split(S)
+    gotC, gotF = ipd.cf_split(S)
+    assert np.array_equal(gotC, refC) and np.array_equal(gotF, refF)
+
+
+def test_cf_split_path_graph_worst_case(ipd):
+    N = 300     # a path needs ~N/2 dependent rounds
+    S = sp.diags([np.ones(N - 1), np.ones(N - 1)], [-1, 1], format="csr")
+    gotC, gotF = ipd.cf_split(S)
+    assert np.array_equal(gotC, np.arange(N) % 2 == 0) and np.array_equal(gotF, ~gotC)
+
+
+@pytest.mark.parametrize("N,deg,seed", [(30, 2, 1), (400, 3, 2), (1500, 6, 3)])
+def test_mis_set(ipd, N, deg, seed):
+    A = PR.random_sym_graph_laplacian(N, deg=deg, seed=seed)
+    refC, refF, refAs, info = O.mis_set(A, 0.25, O.matlab_rng())
+    rng = ipd.MatlabRand()
+    gotC, gotF, gotAs = ipd.mis_set(A, 0.25, rng)
+    assert np.array_equal(gotC, refC) and np.array_equal(gotF, refF)
+    assert csc_equal(gotAs, refAs)
+    assert rng.consumed == len(info["rand"])
+
+
+def test_mis_set_degenerate_branch(ipd):
+    N = 100   # diagonal matrix: no strong connections -> random N0 picks (mis_set.m:30-34)
+    A = sp.diags(np.arange(1.0, N + 1), format="csr")
+    refC, refF, _, info = O.mis_set(A, 0.25, O.matlab_rng())
+    assert info["branch"] == "degenerate"
+    rng = ipd.MatlabRand()
+    gotC, gotF, _ = ipd.mis_set(A, 0.25, rng)
+    assert np.array_equal(gotC, refC) and np.array_equal(gotF, refF)
+    assert rng.consumed == 11
+
+
+CASES = [
+    ("tree64", 64, 64, lambda: PR.mask_tree(64, 64, seed=1), None),
+    ("tree_rect", 150, 90, lambda: PR.mask_tree(150, 90, seed=2), None),
+    ("bern256", 256, 256, lambda: PR.mask_bernoulli(256, 256, 0.02, seed=3), None),
+    ("dense96", 96, 96, lambda: PR.mask_bernoulli(96, 96, 1.0), None),
+    ("half128", 128, 128, lambda: PR.mask_bernoulli(128, 128, 0.5), None),
+]
+
+
+@pytest.mark.parametrize("name,m,n,mk,t", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("isnsp", [0, 1])
+def test_hierarchy_bit_exact(ipd, name, m, n, mk, t, isnsp):
+    s = mk()
+    Ae, pd = newton_matrix(m, n, s)
+    ncomp = sp.csgraph.connected_components(Ae)[0]
+    if ncomp > 1:   # Class_AMG is only called on connected components
+        lab = sp.csgraph.connected_components(Ae)[1]
+        big = np.argmax(np.bincount(lab))
+        pk = np.flatnonzero(lab == big)
+        Ae = sp.csr_matrix(Ae[pk, :][:, pk])
+        fnode = int((pk < n).sum())
+    else:
+        fnode = n
+    o = O.amg_options_class1("v"); o.update(fnode=fnode, isnsp=isnsp)
+    ho = O.amg_setup(Ae, o, O.matlab_rng())
+    rng = ipd.MatlabRand()
+    h = ipd.AMGHierarchy(Ae, o, rng)
+    assert h.J == ho.J
+    assert h.level_sizes() == ho.level_sizes()
+    for k in range(1, ho.J + 1):
+        assert csc_equal(h.A(k), ho.Ack[k]), f"Ack{{{k}}} differs"
+    for k in range(2, ho.J + 1):
+        assert csc_equal(h.P(k), ho.Prok[k]), f"Prok{{{k}}} differs"
+        assert np.array_equal(h.cmask(k), ho.info[k]["isC"])
+    assert rng.consumed == sum(len(i["mis"]["rand"]) for i in ho.info[2:] if i and i.get("mis"))
+    h.close()
+
+
+def test_transfer_standalone(ipd):
+    A = PR.random_sym_graph_laplacian(300, deg=3, seed=5)
+    o = O.amg_options_class1("v"); o.update(bigph=0, isnsp=0)
+    Ac, Pro, info = O.transfer(A, o, 2, O.matlab_rng())
+    gAc, gPro, gC = ipd.transfer(A, o, 2, ipd.MatlabRand())
+    assert csc_equal(gAc, Ac) and csc_equal(gPro, Pro) and np.array_equal(gC, info["isC"])
+
+
+def test_setup_errors(ipd):
+    A = PR.random_sym_graph_laplacian(50, seed=1)
+    with pytest.raises(ipd.IpdError) as ei:
+        ipd.AMGHierarchy(A, dict(bigph=1, fnode=None, smoth=1))
+    assert "requires Nf > 0" in str(ei.value)       # Class_AMG.m:36-40
