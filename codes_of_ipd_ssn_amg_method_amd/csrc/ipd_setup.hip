@@ -339,7 +339,7 @@ __global__ __launch_bounds__(1024) void k_cf_split(int n, const int* __restrict_
         ++rounds;
         const int p = pending;
         __syncthreads();
-        if (!p) break;
+        if (!p || rounds > n + 2) break;  // every round decides >= 1 node; the bound is a hang guard
     }
     if (threadIdx.x == 0) *rounds_out = rounds;
 }
