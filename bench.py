@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- V-cycle throughput (DoF*cycles/s) + achieved GB/s on the m=n=1024 OT grid.
+
+A "step" is one iteration of the Class_AMG loop body (AMG/Class_AMG.m:96-105:
+residual, one MG_Vcycle, norm) on a fixed hierarchy, with everything resident in
+HBM before the timed region.  Workload = BASELINE.json's metric configuration
+("m=n=1024 OT grid"), regime D of SURVEY.md 8d (the roofline point):
+s ~ Bernoulli(rho), seed 2; bk1=0.0038, tk=0.0255; z ~ N(0,1) seed 3; guess =
+bk1*tk*U(0,1) seed 4; options as the Class 1 driver (smoth 5, theta 1/4, bigph 1,
+isnsp 1), cycle 'v'.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--rho R] [--cycle v|w]
+                  [--mask bernoulli|tree] [--n1 1024] [--no-cpu-baseline]
+
+N>1 is launched by `python -m torch.distributed.run --nproc-per-node N ...`
+(one rank per GPU): `--mode sharded` (default) runs ONE system row-block sharded
+over the N GPUs with RCCL all-gathers of the iterate (strong scaling, the curve
+north_star asks for); `--mode replicas` runs N independent systems (weak scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
+BK1, TK = 0.0038, 0.0255
+
+
+def build_mask(m, n, kind, rho, seed=2):
+    if kind == "bernoulli":
+        return (np.random.RandomState(seed).random_sample(m * n) < rho).astype(np.uint8)
+    from tests.problems import mask_tree
+    return mask_tree(m, n, seed=seed)
+
+
+def build_newton_system(ipd, m, n, s):
+    """One semismooth-Newton system of the Class 1 driver in the rescaled form of
+    Hybrid_AMG.m:17-24: Ae u = f.  H0 comes from the GPU ASAt."""
+    p, q = np.ones(m), np.ones(n)
+    H0 = ipd.ASAt(s, p, q)
+    qp = np.concatenate([q, -p])
+    Q0 = sp.diags(qp)
+    A0 = (Q0 @ H0) @ Q0
+    Ae = sp.csr_matrix(BK1 * (Q0 @ Q0) + (1.0 / TK) * A0)
+    z = np.random.RandomState(3).randn(m + n)
+    f = qp * z
+    guess = BK1 * TK * np.random.RandomState(4).random_sample(m + n)
+    return Ae, f, guess, H0
+
+
+def cpu_baseline(Ae, f, guess, opts, n, budget_s=15.0):
+    """The CPU oracle (SciPy port of the reference's MATLAB path) timed on the host:
+    same Class_AMG loop body, same hierarchy options, bounded sample."""
+    from oracle import ipd_oracle as O
+    o = dict(opts)
+    o.update(fnode=n, guess=guess)
+    t0 = time.perf_counter()
+    h = O.amg_setup(Ae, o, O.matlab_rng())
+    t_setup = time.perf_counter() - t0
+    A = h.Ack[1]
+    x = guess.copy()
+    cycles = 0
+    t0 = time.perf_counter()
+    while True:
+        r = f - A @ x
+        if opts["cycle"] == "w":
+            x = x + O.MG_Wcycle(h, r, opts["isnsp"])
+        else:
+            x = x + O.MG_Vcycle(h, r, opts["isnsp"])
+        np.linalg.norm(A @ x - f)
+        cycles += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or cycles >= 2000:
+            break
+    M = A.shape[0]
+    return dict(value=M * cycles / el, unit="DoF*cycles/s", cores=1, kind="port",
+                sample="%d %s-cycles of the same hierarchy in %.1f s (oracle/ipd_oracle.py, "
+                       "SciPy float64, 1 thread; setup %.1f s excluded)" % (
+                           cycles, opts["cycle"].upper(), el, t_setup),
+                ms_per_cycle=1e3 * el / cycles)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n1", type=int, default=1024)
+    ap.add_argument("--rho", type=float, default=1.0)
+    ap.add_argument("--mask", default="bernoulli", choices=["bernoulli", "tree"])
+    ap.add_argument("--cycle", default="v", choices=["v", "w"])
+    ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    os.environ.setdefault("IPD_DEVICE", str(local_rank))
+
+    # The HIP library is loaded BEFORE torch so that the system ROCm runtime is the
+    # one in the process (torch bundles its own libamdhip64 with the same SONAME).
+    import codes_of_ipd_ssn_amg_method_amd as ipd
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    from ctypes import byref, c_double, c_int
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("gloo")  # control plane only; the data path is RCCL in-library
+
+    m = n = args.n1
+    M = m + n
+    s = build_mask(m, n, args.mask, args.rho)
+    Ae, f, guess, H0 = build_newton_system(ipd, m, n, s)
+    opts = dict(retol=1e-11, bigph=1, maxit=30, theta=0.25, smoth=5, cycle=args.cycle, isnsp=1,
+                inter=1, fnode=n)
+    t0 = time.perf_counter()
+    h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    setup_s = time.perf_counter() - t0
+    ctx = _lib.get_ctx()
+    db = _lib.DeviceBuffer.from_array(f)
+    dx = _lib.DeviceBuffer.from_array(guess)
+
+    sharded = world > 1 and args.mode == "sharded"
+    if sharded:
+        import torch
+        idbuf = np.zeros(_lib.COMM_ID_BYTES, np.uint8)
+        if rank == 0:
+            _lib.check(_lib.lib.ipd_comm_get_unique_id(_lib.bptr(idbuf)))
+        t = torch.from_numpy(idbuf)
+        dist.broadcast(t, 0)
+        _lib.check(_lib.lib.ipd_comm_init(ctx.handle, _lib.bptr(idbuf), c_int(rank), c_int(world)))
+        bench_fn = _lib.lib.ipd_amg_bench_cycles_sharded
+    else:
+        bench_fn = _lib.lib.ipd_amg_bench_cycles
+
+    def run(cycles):
+        ms, bpc = c_double(), c_double()
+        _lib.check(bench_fn(h.handle, db.ptr, dx.ptr, c_int(cycles), byref(ms), byref(bpc)))
+        return ms.value, bpc.value
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+
+    if args.warmup > 0:
+        run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    ev_ms, bytes_per_cycle = run(args.steps)
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+
+    units = args.steps * M * (world if (world > 1 and not sharded) else 1)
+    value = units / wall
+    result = {
+        "metric": "V-cycle throughput (DoF*cycles/sec), m=n=%d OT grid" % m,
+        "value": value, "unit": "DoF*cycles/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True,
+        "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "class1-OT m=n=%d, regime-D mask %s rho=%g, %s-cycle AMG "
+                               "(smoth 5, theta 1/4, bigph, isnsp), fixed hierarchy" % (
+                                   m, args.mask, args.rho, args.cycle.upper()),
+                   "M": M, "E": int(s.sum()), "levels": h.level_sizes(),
+                   "level_nnz": [h.level_dims(k)[1] for k in range(1, h.J + 1)],
+                   "parallelism": ("row-block sharded x%d, RCCL all-gather" % world) if sharded
+                   else ("replicas x%d" % world if world > 1 else "single GPU")},
+        "cycle_bytes_algorithmic": bytes_per_cycle,
+        "cycle_GBps_algorithmic": bytes_per_cycle * args.steps / wall / 1e9,
+        "device_ms_per_step_events": ev_ms / args.steps,
+        "setup_seconds_host_api": setup_s,
+    }
+
+    if rank == 0 and world == 1:
+        # roofline of the dominant kernel (k_smooth): per-launch algorithmic bytes over the
+        # per-launch duration measured with HIP events on the library's stream
+        tot_bytes = tot_ms = 0.0
+        launches = 0
+        per_level = []
+        from ctypes import c_int as _ci
+        for k in range(1, h.J):
+            ms, lps, bps = c_double(), _ci(), c_double()
+            reps = 200
+            _lib.check(_lib.lib.ipd_amg_bench_sweeps(h.handle, _ci(k), _ci(reps), byref(ms),
+                                                     byref(lps), byref(bps)))
+            per_level.append({"level": k, "us_per_launch": 1e3 * ms.value / (reps * lps.value),
+                              "bytes_per_launch": bps.value / lps.value,
+                              "GBps": bps.value * reps / ms.value / 1e6})
+            # weight = launches per cycle of this level (2 nu sweeps)
+            w = 2 * opts["smoth"] * (2 ** (k - 1) if args.cycle == "w" and k + 1 < h.J else 1)
+            tot_bytes += w * bps.value
+            tot_ms += w * ms.value / reps
+            launches += w * lps.value
+        achieved = tot_bytes / tot_ms / 1e6 if tot_ms > 0 else 0.0  # GB/s
+        result["roofline"] = {"bound": "hbm", "kernel": "k_smooth", "achieved": achieved,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                              "traffic": None,
+                              "avg_us_per_launch": 1e3 * tot_ms / launches if launches else None,
+                              "avg_bytes_per_launch": tot_bytes / launches if launches else None,
+                              "per_level": per_level}
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(Ae, f, guess, opts, n)
+            result["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,7 @@ class IpdError(RuntimeError):
 
 IPD_E_ARG, IPD_E_HIP, IPD_E_NOMEM, IPD_E_LIMIT, IPD_E_NUMERIC, IPD_E_UNSUPPORTED, IPD_E_COMM = \
     -1, -2, -3, -4, -5, -6, -7
+COMM_ID_BYTES = 128
 
 
 class ipd_csc(Structure):
@@ -86,7 +87,7 @@ EXPORTS = [
     "ipd_hybrid_amg", "ipd_amg4pot", "ipd_dmalloc", "ipd_dfree", "ipd_h2d", "ipd_d2h",
     "ipd_dmat_upload", "ipd_dmat_download", "ipd_dmat_dims", "ipd_dmat_destroy", "ipd_spmv_dev",
     "ipd_ax_dev", "ipd_aty_dev", "ipd_asat_dev", "ipd_amg_setup_dev", "ipd_amg_solve_dev",
-    "ipd_hybrid_amg_dev", "ipd_amg_bench_cycles", "ipd_amg_cycle_bytes", "ipd_comm_get_unique_id",
+    "ipd_hybrid_amg_dev", "ipd_amg_bench_cycles", "ipd_amg_bench_sweeps", "ipd_amg_cycle_bytes", "ipd_comm_get_unique_id",
     "ipd_comm_init", "ipd_comm_finalize", "ipd_amg_bench_cycles_sharded",
 ]
 
@@ -209,5 +210,39 @@ class MatlabRand:
             if self.handle:
                 lib.ipd_rng_destroy(self.handle)
                 self.handle = c_void_p()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """Raw device allocation on the context's GPU (ipd_dmalloc / ipd_h2d / ipd_d2h)."""
+
+    def __init__(self, nbytes: int, ctx: Context | None = None):
+        self.ctx = ctx or get_ctx()
+        self.nbytes = int(nbytes)
+        self.ptr = c_void_p()
+        check(lib.ipd_dmalloc(self.ctx.handle, c_size_t(self.nbytes), byref(self.ptr)))
+
+    @classmethod
+    def from_array(cls, a: np.ndarray, ctx: Context | None = None) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        buf = cls(a.nbytes, ctx)
+        check(lib.ipd_h2d(buf.ctx.handle, buf.ptr, a.ctypes.data_as(c_void_p), c_size_t(a.nbytes)))
+        return buf
+
+    def to_array(self, dtype, count: int) -> np.ndarray:
+        out = np.empty(int(count), dtype=dtype)
+        check(lib.ipd_d2h(self.ctx.handle, out.ctypes.data_as(c_void_p), self.ptr,
+                          c_size_t(out.nbytes)))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib.ipd_dfree(self.ctx.handle, self.ptr)
+            self.ptr = c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
         except Exception:
             pass

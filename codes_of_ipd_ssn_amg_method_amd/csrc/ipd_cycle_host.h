@@ -1,0 +1,661 @@
+// Host-side orchestration of the cycle (included by ipd_cycle.hip only): launch
+// geometry, the recursive V/W schedule, the Class_AMG loop, the C ABI and the
+// measurement hooks.
+#pragma once
+
+#include <cstdlib>
+
+struct LevelRun {  // per-level run state kept next to Level
+    LevelDev dev;
+    bool e_zero = true;      // the iterate is identically zero and is not materialised
+    int staged = 0;          // N <= STAGE_MAX: gather vectors go through LDS
+    XferArgs restrict_args;  // r_{k+1} = P' rr_k   (stored on level k)
+    XferArgs prolong_args;   // e_k += P e_{k+1}
+    PcgArgs pcg;             // coarsest only
+};
+
+struct CycleState {
+    std::vector<LevelRun> run;  // 1-based
+    double* nrm_part = nullptr;
+    double* hist = nullptr;
+    double* x2 = nullptr;
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};  // captured Class_AMG loop bodies (x->x2, x2->x)
+    const double* gb = nullptr;                    // right-hand side the graphs were captured for
+    ~CycleState() {
+        for (auto& g : gexec)
+            if (g) (void)hipGraphExecDestroy(g);
+    }
+};
+
+static CycleState* state_of(ipd_amg* h) { return h->cyc.get(); }
+
+__global__ void k_level_prepare(int N, int nf, const int* __restrict__ rp,
+                                const int* __restrict__ ci, const double* __restrict__ va,
+                                double* __restrict__ dinv, double* __restrict__ Axi) {
+    // one wave per row: diagonal -> Rk, row sum -> A*1
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < N; r += nwaves) {
+        double s = 0.0, dg = 0.0;
+        for (int t = rp[r] + lane; t < rp[r + 1]; t += 64) {
+            s += va[t];
+            if (ci[t] == r) dg = va[t];
+        }
+        s = wave_sum(s);
+        dg = wave_sum(dg);
+        if (lane == 0) {
+            Axi[r] = s;
+            // Class_AMG.m:56-59 (1./diag) for the bigraph GS, :72/:84 (0.5*(1./diag)) otherwise
+            dinv[r] = nf > 0 ? 1.0 / dg : 0.5 * (1.0 / dg);
+        }
+    }
+}
+
+static int pick_blocks(int nrows, int L, int cu);
+
+// Builds the padded off-diagonal copy when the level is big and regular enough
+// (see ipd_cycle_phases.h, item 2) and adapts the launch geometry to it.
+static void build_padded(ipd_ctx* ctx, Arena& ar, const Csr& A, int rows_per_launch, int cu,
+                         LevelDev* dev) {
+    dev->S = 0;
+    dev->pci = nullptr;
+    dev->pva = nullptr;
+    dev->diag = nullptr;
+    const char* env = std::getenv("IPD_NO_PAD");
+    if (env && env[0] == '1') return;
+    if (A.nr > 65535 || A.nr == 0) return;
+    const double avg_off = (double)(A.nnz - A.nr) / (double)A.nr;
+    if (avg_off < 24.0) return;
+    int* dmax = ctx->scratch->alloc<int>(1);
+    IPD_HIP(hipMemsetAsync(dmax, 0, sizeof(int), ctx->stream));
+    const int grid = std::max(1, std::min(cdiv(A.nr, 4), 4096));
+    hipLaunchKernelGGL(k_offdiag_maxlen, dim3(grid), dim3(256), 0, ctx->stream, A.nr, A.rp, A.ci,
+                       dmax);
+    IPD_KERNEL_CHECK();
+    const int maxlen = ctx->fetch1(dmax);
+    const int S = (maxlen + 3) / 4 * 4;
+    if (S == 0 || (double)S > 1.3 * avg_off + 16.0) return;
+    unsigned short* pci = ar.alloc<unsigned short>((size_t)A.nr * S);
+    double* pva = ar.alloc<double>((size_t)A.nr * S);
+    double* diag = ar.alloc<double>((size_t)A.nr);
+    hipLaunchKernelGGL(k_pad_build, dim3(grid), dim3(256), 0, ctx->stream, A.nr, S, A.rp, A.ci, A.va,
+                       pci, pva, diag);
+    IPD_KERNEL_CHECK();
+    dev->S = S;
+    dev->pci = pci;
+    dev->pva = pva;
+    dev->diag = diag;
+    // one batch (ROW_U entries = 2 vectors) per lane, widened until the chip is filled
+    const int nvec = S / 4;
+    int L = 4;
+    while (L < BT && L * (ROW_U / 4) < nvec) L <<= 1;
+    while (L < BT && (long long)rows_per_launch * L < (long long)cu * BT / 2 && L < nvec) L <<= 1;
+    dev->L = L;
+    dev->G = pick_blocks(rows_per_launch, L, cu);
+}
+
+static int pick_blocks(int nrows, int L, int cu) {
+    return (int)std::max<long long>(1, std::min<long long>(cu, ((long long)nrows * L + BT - 1) / BT));
+}
+
+void amg_prepare_levels(ipd_amg* h) {
+    ipd_ctx* ctx = h->ctx;
+    Arena& ar = *h->arena;
+    std::unique_ptr<CycleState> st(new CycleState());
+    st->run.resize((size_t)h->J + 1);
+    const int cu = ctx->num_cu;
+    for (int k = 1; k <= h->J; ++k) {
+        Level& lv = h->L[k];
+        const int N = lv.A.nr;
+        lv.N = N;
+        lv.nf = (k == 1 && h->opts.bigph) ? (int)h->opts.fnode : 0;
+        IPD_REQUIRE(lv.nf < N, IPD_E_ARG, "fnode must be smaller than the matrix size");
+        lv.dinv = ar.alloc<double>((size_t)N);
+        lv.Axi = ar.alloc<double>((size_t)N);
+        lv.xx = ar.alloc<double>(1);
+        lv.r = ar.alloc<double>((size_t)N);
+        lv.e = ar.alloc<double>((size_t)N);
+        lv.e2 = ar.alloc<double>((size_t)N);
+        lv.w = ar.alloc<double>((size_t)N);
+        lv.rr = ar.alloc<double>((size_t)N);
+        hipLaunchKernelGGL(k_level_prepare, dim3(std::max(1, std::min(cdiv(N, 4), 4096))), dim3(256),
+                           0, ctx->stream, N, lv.nf, lv.A.rp, lv.A.ci, lv.A.va, lv.dinv, lv.Axi);
+        IPD_KERNEL_CHECK();
+        hipLaunchKernelGGL(k_vec_sum, dim3(1), dim3(BT), 0, ctx->stream, (const double*)lv.Axi, N,
+                           lv.xx);
+        IPD_KERNEL_CHECK();
+        // launch geometry: for a GS level the work per launch is half the matrix
+        const int rows_per_launch = lv.nf > 0 ? std::max(1, N / 2) : N;
+        const long long nnz_per_launch = lv.nf > 0 ? std::max(1, lv.A.nnz / 2) : lv.A.nnz;
+        lv.lanes = pick_lanes(nnz_per_launch, rows_per_launch, cu);
+        LevelRun& rn = st->run[(size_t)k];
+        rn.dev.N = N;
+        rn.dev.nf = lv.nf;
+        rn.dev.L = lv.lanes;
+        rn.dev.G = pick_blocks(rows_per_launch, lv.lanes, cu);
+        rn.dev.rp = lv.A.rp;
+        rn.dev.ci = lv.A.ci;
+        rn.dev.va = lv.A.va;
+        rn.dev.dinv = lv.dinv;
+        rn.dev.Axi = lv.Axi;
+        rn.dev.xx = lv.xx;
+        rn.dev.r = lv.r;
+        rn.dev.rr = lv.rr;
+        rn.staged = N <= STAGE_MAX ? 1 : 0;
+        build_padded(ctx, ar, lv.A, rows_per_launch, cu, &rn.dev);
+    }
+    for (int k = 1; k < h->J; ++k) {
+        Level& fine = h->L[k];
+        Level& coarse = h->L[k + 1];
+        LevelRun& rn = st->run[(size_t)k];
+        XferArgs ra;  // restriction: rows of P' (coarse rows), gathers the fine residual
+        ra.nrows = coarse.Pt.nr;
+        ra.ncols = coarse.Pt.nc;
+        ra.L = pick_lanes(coarse.Pt.nnz, coarse.Pt.nr, cu);
+        ra.G = pick_blocks(ra.nrows, ra.L, cu);
+        ra.rp = coarse.Pt.rp;
+        ra.ci = coarse.Pt.ci;
+        ra.va = coarse.Pt.va;
+        ra.x = fine.rr;
+        ra.y = coarse.r;
+        ra.add = 0;
+        ra.staged = ra.ncols <= STAGE_MAX ? 1 : 0;
+        rn.restrict_args = ra;
+        XferArgs pa;  // prolongation: rows of P (fine rows), gathers the coarse correction
+        pa.nrows = coarse.P.nr;
+        pa.ncols = coarse.P.nc;
+        pa.L = pick_lanes(coarse.P.nnz, coarse.P.nr, cu);
+        pa.G = pick_blocks(pa.nrows, pa.L, cu);
+        pa.rp = coarse.P.rp;
+        pa.ci = coarse.P.ci;
+        pa.va = coarse.P.va;
+        pa.x = coarse.e;
+        pa.y = fine.e;
+        pa.add = 1;
+        pa.staged = pa.ncols <= STAGE_MAX ? 1 : 0;
+        rn.prolong_args = pa;
+    }
+    {   // coarsest level: PCG(A,r) with the 2-argument defaults (PCG.m:18-23)
+        Level& cl = h->L[h->J];
+        PcgArgs a;
+        a.N = cl.A.nr;
+        a.L = std::min(pick_lanes(cl.A.nnz, cl.A.nr, 1), 64);
+        a.rp = cl.A.rp;
+        a.ci = cl.A.ci;
+        a.va = cl.A.va;
+        a.rhs = cl.r;
+        a.guess = nullptr;
+        a.d = cl.e;
+        a.work = ar.alloc<double>(4 * (size_t)cl.A.nr);
+        a.tol = 1e-11;
+        a.maxit = 10000;
+        a.precd = 2;
+        a.out = nullptr;
+        a.nresk = 0;
+        st->run[(size_t)h->J].pcg = a;
+    }
+    st->nrm_part = ar.alloc<double>((size_t)cu + 1);
+    st->hist = ar.alloc<double>(8);
+    st->x2 = ar.alloc<double>((size_t)h->L[1].A.nr);
+    h->x = ar.alloc<double>((size_t)h->L[1].A.nr);
+    h->b = ar.alloc<double>((size_t)h->L[1].A.nr);
+    h->cyc = std::shared_ptr<CycleState>(st.release());
+}
+
+// ---------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------
+#define IPD_LAUNCH_SP(kern, staged, pad, grid, dyn, ...)                                          \
+    do {                                                                                          \
+        if (staged) {                                                                             \
+            if (pad)                                                                              \
+                hipLaunchKernelGGL((kern<true, true>), dim3(grid), dim3(BT), dyn, ctx->stream,     \
+                                   __VA_ARGS__);                                                  \
+            else                                                                                  \
+                hipLaunchKernelGGL((kern<true, false>), dim3(grid), dim3(BT), dyn, ctx->stream,    \
+                                   __VA_ARGS__);                                                  \
+        } else {                                                                                  \
+            if (pad)                                                                              \
+                hipLaunchKernelGGL((kern<false, true>), dim3(grid), dim3(BT), 0, ctx->stream,      \
+                                   __VA_ARGS__);                                                  \
+            else                                                                                  \
+                hipLaunchKernelGGL((kern<false, false>), dim3(grid), dim3(BT), 0, ctx->stream,     \
+                                   __VA_ARGS__);                                                  \
+        }                                                                                         \
+        IPD_KERNEL_CHECK();                                                                       \
+    } while (0)
+
+static void launch_smooth(ipd_ctx* ctx, const SmoothArgs& a) {
+    const size_t dyn = a.staged ? sizeof(double) * (size_t)a.lv.N : 0;
+    IPD_LAUNCH_SP(k_smooth, a.staged, a.lv.S > 0, a.lv.G, dyn, a);
+}
+
+static void launch_xfer(ipd_ctx* ctx, const XferArgs& a) {
+    const size_t dyn = a.staged ? sizeof(double) * (size_t)a.ncols : 0;
+    if (a.staged)
+        hipLaunchKernelGGL(k_xfer<true>, dim3(a.G), dim3(BT), dyn, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(k_xfer<false>, dim3(a.G), dim3(BT), 0, ctx->stream, a);
+    IPD_KERNEL_CHECK();
+}
+
+static void launch_resid(ipd_ctx* ctx, const LevelRun& rn, const double* e) {
+    const size_t dyn = rn.staged ? sizeof(double) * (size_t)rn.dev.N : 0;
+    IPD_LAUNCH_SP(k_resid, rn.staged, rn.dev.S > 0, rn.dev.G, dyn, rn.dev, e);
+}
+
+// one smoother sweep on level k: Jacobi = one launch, bigraph GS = two half launches
+static void launch_sweep(ipd_amg* h, CycleState* st, int k, int isnsp, bool post) {
+    ipd_ctx* ctx = h->ctx;
+    Level& lv = h->L[k];
+    LevelRun& rn = st->run[(size_t)k];
+    SmoothArgs a;
+    a.lv = rn.dev;
+    a.eold = lv.e;
+    a.enew = lv.e2;
+    a.win = lv.w;
+    a.wout = lv.w;
+    a.isnsp = isnsp;
+    a.staged = rn.staged;
+    a.eold_zero = rn.e_zero ? 1 : 0;
+    if (lv.nf == 0) {
+        a.row0 = 0;
+        a.row1 = lv.N;
+        a.u0 = a.u1 = 0;
+        a.wout = nullptr;
+        launch_smooth(ctx, a);
+    } else {
+        // pre: F rows then C rows (Rk{1});  post: C rows then F rows (Rk{1}')
+        const int f0 = post ? lv.nf : 0, f1 = post ? lv.N : lv.nf;  // first half rows
+        const int s0 = post ? 0 : lv.nf, s1 = post ? lv.nf : lv.N;  // second half rows
+        a.row0 = f0;
+        a.row1 = f1;
+        a.u0 = a.u1 = 0;
+        launch_smooth(ctx, a);
+        a.row0 = s0;
+        a.row1 = s1;
+        a.u0 = f0;
+        a.u1 = f1;
+        a.wout = nullptr;
+        launch_smooth(ctx, a);
+    }
+    rn.e_zero = false;
+    std::swap(lv.e, lv.e2);
+}
+
+// Solves A_k e = r_k approximately; r in L[k].r, result in L[k].e.
+// keep_e: start from the current L[k].e (second leg of a W cycle); otherwise the
+// start is e = 0, which is never materialised (the first sweep does not read it).
+void amg_cycle(ipd_amg* h, int k, int isnsp, bool wcycle, bool keep_e) {
+    ipd_ctx* ctx = h->ctx;
+    CycleState* st = state_of(h);
+    IPD_REQUIRE(st, IPD_E_ARG, "hierarchy has no cycle state");
+    Level& lv = h->L[k];
+    LevelRun& rn = st->run[(size_t)k];
+    if (k == h->J) {                                   // MG_Vcycle.m:43 / MG_Wcycle.m:44
+        PcgArgs a = rn.pcg;
+        a.rhs = lv.r;
+        a.d = lv.e;
+        hipLaunchKernelGGL(k_pcg, dim3(1), dim3(BT), 0, ctx->stream, a);
+        IPD_KERNEL_CHECK();
+        return;
+    }
+    const int nu = h->opts.smoth;
+    if (!keep_e) {
+        rn.e_zero = true;
+        if (nu == 0) {  // no sweep will overwrite the iterate: materialise the zero
+            IPD_HIP(hipMemsetAsync(lv.e, 0, sizeof(double) * (size_t)lv.N, ctx->stream));
+            rn.e_zero = false;
+        }
+    }
+    for (int s = 0; s < nu; ++s) launch_sweep(h, st, k, isnsp, false);          // :14-25
+    launch_resid(ctx, rn, lv.e);                                                 // :27
+    {
+        launch_xfer(ctx, rn.restrict_args);
+    }
+    amg_cycle(h, k + 1, isnsp, wcycle, false);                                   // :29
+    // MG_Wcycle.m:30 -- the second correction; on the coarsest level it repeats the
+    // identical zero-guess PCG solve, so it is skipped there (same bits).
+    if (wcycle && k + 1 < h->J) amg_cycle(h, k + 1, isnsp, wcycle, true);
+    {
+        XferArgs pa = rn.prolong_args;                                           // :31
+        pa.x = h->L[k + 1].e;
+        pa.y = lv.e;
+        launch_xfer(ctx, pa);
+    }
+    for (int s = 0; s < nu; ++s) launch_sweep(h, st, k, isnsp, true);           // :33-41
+}
+
+static void launch_top(ipd_amg* h, CycleState* st, const double* b, const double* x,
+                       const double* e, double* xnew, bool first) {
+    ipd_ctx* ctx = h->ctx;
+    LevelRun& rn = st->run[1];
+    TopArgs a;
+    a.lv = rn.dev;
+    a.b = b;
+    a.x = x;
+    a.e = e;
+    a.xnew = xnew;
+    a.nrm_part = st->nrm_part;
+    a.staged = rn.staged;
+    const size_t dyn = a.staged ? sizeof(double) * (size_t)rn.dev.N : 0;
+    IPD_LAUNCH_SP(k_top, a.staged, rn.dev.S > 0, rn.dev.G, dyn, a);
+    hipLaunchKernelGGL(k_conv, dim3(1), dim3(BT), 0, ctx->stream, (const double*)st->nrm_part,
+                       rn.dev.G, st->hist, first ? 1 : 0);
+    IPD_KERNEL_CHECK();
+}
+
+// one Class_AMG loop body (Class_AMG.m:96-105): x_out = x_in + cycle(b - A x_in)
+static void enqueue_loop_body(ipd_amg* h, CycleState* st, const double* b, const double* xin,
+                              double* xout) {
+    const bool wc = h->opts.cycle == 'w', vc = h->opts.cycle == 'v';
+    const double* ecorr = nullptr;
+    if (vc || wc) {
+        amg_cycle(h, 1, h->opts.isnsp, wc, false);
+        ecorr = h->L[1].e;
+    }
+    launch_top(h, st, b, xin, ecorr, xout, false);
+}
+
+// Class_AMG.m:86-109
+void amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev, double* x_dev,
+                   int32_t* it_out, double* rel_res_out, double* rel_resk, double* rhok) {
+    ipd_ctx* ctx = h->ctx;
+    CycleState* st = state_of(h);
+    IPD_REQUIRE(st, IPD_E_ARG, "hierarchy has no cycle state");
+    const AmgOpts& o = h->opts;
+    const int N = h->L[1].A.nr;
+    double* xa = h->x;
+    double* xb = st->x2;
+    if (guess_dev)
+        IPD_HIP(hipMemcpyAsync(xa, guess_dev, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+    else
+        IPD_HIP(hipMemsetAsync(xa, 0, sizeof(double) * (size_t)N, ctx->stream));
+    launch_top(h, st, b_dev, xa, nullptr, xb, true);                            // :89
+    std::swap(xa, xb);
+    double hh[5];
+    ctx->fetch(st->hist, hh, 5);
+    int it = 0;
+    double rel_res = 0.0;
+    if (hh[0] == 0.0) {                                                          // :91-92
+        if (rel_resk) rel_resk[0] = 0.0;
+        if (rhok) rhok[0] = INFINITY;
+    } else {
+        it = 1;                                                                  // :94
+        double last_rel = 1.0;
+        if (rel_resk) rel_resk[0] = 1.0;
+        if (rhok) rhok[0] = NAN;
+        while (last_rel > o.retol && it <= o.maxit) {                            // :95
+            enqueue_loop_body(h, st, b_dev, xa, xb);                             // :96-105
+            std::swap(xa, xb);
+            ctx->fetch(st->hist, hh, 5);
+            rel_res = hh[3];
+            last_rel = rel_res;
+            if (rel_resk) rel_resk[it] = rel_res;
+            if (rhok) rhok[it] = hh[4];
+            ++it;
+            if (hh[4] > 1.0) break;                                              // :106
+        }
+        it -= 1;                                                                 // :108
+    }
+    if (x_dev)
+        IPD_HIP(hipMemcpyAsync(x_dev, xa, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+    if (xa != h->x) std::swap(h->x, st->x2);  // keep h->x pointing at the current iterate
+    if (it_out) *it_out = it;
+    if (rel_res_out) *rel_res_out = rel_res;
+    ctx->sync();
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" int ipd_amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev,
+                                 double* x_dev, int32_t* it, double* rel_res, double* rel_resk,
+                                 double* rhok) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && b_dev && x_dev, IPD_E_ARG, "NULL argument");
+        CallScope scope(h->ctx);
+        amg_solve_dev(h, b_dev, guess_dev, x_dev, it, rel_res, rel_resk, rhok);
+    });
+}
+
+extern "C" int ipd_amg_solve(ipd_amg* h, const double* b, const double* guess, double* x,
+                             int32_t* it, double* rel_res, double* rel_resk, double* rhok) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && b && x, IPD_E_ARG, "NULL argument");
+        ipd_ctx* ctx = h->ctx;
+        CallScope scope(ctx);
+        const size_t N = (size_t)h->L[1].A.nr;
+        double* db = ctx->scratch->alloc<double>(N);
+        double* dg = nullptr;
+        double* dx = ctx->scratch->alloc<double>(N);
+        ctx->upload(db, b, N);
+        if (guess) {
+            dg = ctx->scratch->alloc<double>(N);
+            ctx->upload(dg, guess, N);
+        }
+        amg_solve_dev(h, db, dg, dx, it, rel_res, rel_resk, rhok);
+        ctx->fetch(dx, x, N);
+    });
+}
+
+static void run_cycle_api(ipd_amg* h, const double* r, int isnsp, int k, const double* e_in,
+                          double* e_out, bool wc) {
+    IPD_REQUIRE(h && r && e_out, IPD_E_ARG, "NULL argument");
+    IPD_REQUIRE(k >= 1 && k <= h->J, IPD_E_ARG, "level k out of range");
+    ipd_ctx* ctx = h->ctx;
+    CallScope scope(ctx);
+    CycleState* st = state_of(h);
+    IPD_REQUIRE(st, IPD_E_ARG, "hierarchy has no cycle state");
+    Level& lv = h->L[k];
+    const size_t N = (size_t)lv.A.nr;
+    ctx->upload(lv.r, r, N);
+    LevelRun& rn = st->run[(size_t)k];
+    bool keep = false;
+    if (e_in && wc) {  // MG_Wcycle(r,isnsp,k,e): start from the caller's iterate
+        ctx->upload(lv.e, e_in, N);
+        rn.e_zero = false;
+        keep = true;
+    }
+    amg_cycle(h, k, isnsp, wc, keep);
+    ctx->fetch(h->L[k].e, e_out, N);
+}
+
+extern "C" int ipd_amg_vcycle(ipd_amg* h, const double* r, int isnsp, int k, double* e) {
+    return ipd_guard([&] { run_cycle_api(h, r, isnsp, k, nullptr, e, false); });
+}
+
+extern "C" int ipd_amg_wcycle(ipd_amg* h, const double* r, int isnsp, int k, const double* e_in,
+                              double* e_out) {
+    return ipd_guard([&] { run_cycle_api(h, r, isnsp, k, e_in, e_out, true); });
+}
+
+extern "C" int ipd_class_amg(ipd_ctx* ctx, const ipd_csc* A, const double* b, const double* guess,
+                             const ipd_amg_opts* o, ipd_rng* rng, double* x, int32_t* it,
+                             double* rel_res, double* rel_resk, double* rhok) {
+    ipd_amg* h = nullptr;
+    int rc = ipd_amg_setup(ctx, A, o, rng, &h);
+    if (rc != IPD_OK) return rc;
+    rc = ipd_amg_solve(h, b, guess, x, it, rel_res, rel_resk, rhok);
+    ipd_amg_destroy(h);
+    return rc;
+}
+
+extern "C" int ipd_pcg(ipd_ctx* ctx, const ipd_csc* H, const double* e, const double* guess,
+                       const ipd_pcg_opts* o, double* d, int64_t* it, double* res, double* resk) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && H && e && d, IPD_E_ARG, "NULL argument");
+        CallScope scope(ctx);
+        Arena& tmp = *ctx->scratch;
+        double tol = 1e-11;
+        long long maxit = 10000;
+        int precd = 2;  // PCG.m:24-27 defaults
+        if (o) {
+            if (o->retol >= 0) tol = o->retol;
+            if (o->maxit >= 0) maxit = o->maxit;
+            if (o->precd >= 0) precd = o->precd;
+        }
+        Csr hm;
+        csr_upload_from_csc(ctx, tmp, H, true, &hm);
+        const size_t N = (size_t)hm.nr;
+        double* de = tmp.alloc<double>(N);
+        double* dd = tmp.alloc<double>(N);
+        double* dg = nullptr;
+        ctx->upload(de, e, N);
+        if (guess) {
+            dg = tmp.alloc<double>(N);
+            ctx->upload(dg, guess, N);
+        }
+        long long its = 0;
+        pcg_dev(ctx, hm, de, dg, tol, maxit, precd, dd, &its, res, resk);
+        if (it) *it = its;
+        ctx->fetch(dd, d, N);
+    });
+}
+
+// ---------------------------------------------------------------------------
+// measurement hooks
+// ---------------------------------------------------------------------------
+// S(X) = 12 nnz + 4 (rows+1) + 8 rows + 8 cols per CSR SpMV.
+static double spmv_bytes(const Csr& m) {
+    return 12.0 * m.nnz + 4.0 * (m.nr + 1) + 8.0 * m.nr + 8.0 * m.nc;
+}
+
+// B_V with the fused Gauss-Seidel form (one S(A_1) per level-1 sweep, the stated
+// minimum): per level (2 nu + 1) S(A_k) + S(P) + S(P') + 6 nu 8 N_k, weighted by
+// the visit count (1 for V, 2^(k-1) for W), + coarsest PCG + the outer loop's
+// residual S(A_1) + 32 M.
+static double cycle_bytes(const ipd_amg* h) {
+    const bool wc = h->opts.cycle == 'w';
+    const double nu = h->opts.smoth;
+    double total = 0.0;
+    double visits = 1.0;
+    for (int k = 1; k < h->J; ++k) {
+        const Level& lv = h->L[k];
+        const Level& cl = h->L[k + 1];
+        const double per = (2 * nu + 1) * spmv_bytes(lv.A) + spmv_bytes(cl.P) + spmv_bytes(cl.Pt) +
+                           6 * nu * 8.0 * lv.A.nr;
+        total += visits * per;
+        if (wc && k + 1 < h->J) visits *= 2.0;
+    }
+    total += visits * 2.0 * spmv_bytes(h->L[h->J].A);  // >= 1 PCG iteration + initial residual
+    total += spmv_bytes(h->L[1].A) + 32.0 * h->L[1].A.nr;
+    return total;
+}
+
+extern "C" int ipd_amg_cycle_bytes(const ipd_amg* h, double* bytes_per_cycle) {
+    if (!h || !bytes_per_cycle) return IPD_E_ARG;
+    *bytes_per_cycle = cycle_bytes(h);
+    return IPD_OK;
+}
+
+// Captures the two loop bodies (x -> x2 and x2 -> x) as HIP graphs: one graph launch
+// per cycle instead of ~40 kernel launches, so the host never paces the device.
+static void ensure_graphs(ipd_amg* h, CycleState* st, const double* b_dev) {
+    if (st->gexec[0] && st->gb == b_dev) return;
+    ipd_ctx* ctx = h->ctx;
+    for (auto& g : st->gexec)
+        if (g) {
+            IPD_HIP(hipGraphExecDestroy(g));
+            g = nullptr;
+        }
+    double* xs[2] = {h->x, st->x2};
+    for (int v = 0; v < 2; ++v) {
+        hipGraph_t graph = nullptr;
+        IPD_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        try {
+            enqueue_loop_body(h, st, b_dev, xs[v], xs[v ^ 1]);
+        } catch (...) {
+            (void)hipStreamEndCapture(ctx->stream, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+        }
+        IPD_HIP(hipStreamEndCapture(ctx->stream, &graph));
+        hipError_t e = hipGraphInstantiate(&st->gexec[v], graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        IPD_HIP(e);
+    }
+    st->gb = b_dev;
+}
+
+extern "C" int ipd_amg_bench_cycles(ipd_amg* h, const double* b_dev, double* x_dev, int cycles,
+                                    double* total_ms, double* bytes_per_cycle) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && b_dev && x_dev && cycles > 0 && total_ms, IPD_E_ARG, "bad argument");
+        ipd_ctx* ctx = h->ctx;
+        CallScope scope(ctx);
+        CycleState* st = state_of(h);
+        IPD_REQUIRE(st, IPD_E_ARG, "hierarchy has no cycle state");
+        const int N = h->L[1].A.nr;
+        const char* ng = std::getenv("IPD_NO_GRAPH");
+        const bool use_graph = !(ng && ng[0] == '1');
+        IPD_HIP(hipMemcpyAsync(h->x, x_dev, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+        // initial residual (Class_AMG.m:89); x stays in h->x
+        launch_top(h, st, b_dev, h->x, nullptr, st->x2, true);
+        IPD_HIP(hipMemcpyAsync(h->x, st->x2, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+        if (use_graph) ensure_graphs(h, st, b_dev);
+        double* xs[2] = {h->x, st->x2};
+        hipEvent_t ev0, ev1;
+        IPD_HIP(hipEventCreate(&ev0));
+        IPD_HIP(hipEventCreate(&ev1));
+        IPD_HIP(hipEventRecord(ev0, ctx->stream));
+        int v = 0;
+        for (int c = 0; c < cycles; ++c) {
+            if (use_graph)
+                IPD_HIP(hipGraphLaunch(st->gexec[v], ctx->stream));
+            else
+                enqueue_loop_body(h, st, b_dev, xs[v], xs[v ^ 1]);
+            v ^= 1;
+        }
+        IPD_HIP(hipEventRecord(ev1, ctx->stream));
+        IPD_HIP(hipEventSynchronize(ev1));
+        float ms = 0.f;
+        IPD_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        IPD_HIP(hipEventDestroy(ev0));
+        IPD_HIP(hipEventDestroy(ev1));
+        IPD_HIP(hipMemcpyAsync(x_dev, xs[v], sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+        ctx->sync();
+        *total_ms = ms;
+        if (bytes_per_cycle) *bytes_per_cycle = cycle_bytes(h);
+    });
+}
+
+// Times `reps` smoother sweeps of level k (pre-smoothing direction) with HIP events on
+// the context's stream: the per-launch duration of the dominant kernel (k_smooth).
+// launches_per_sweep = 2 for the bigraph Gauss-Seidel level, 1 for Jacobi levels;
+// bytes_per_sweep = S(A_k) + 6*8*N_k (fused-GS form).
+extern "C" int ipd_amg_bench_sweeps(ipd_amg* h, int k, int reps, double* total_ms,
+                                    int* launches_per_sweep, double* bytes_per_sweep) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && total_ms && reps > 0, IPD_E_ARG, "bad argument");
+        IPD_REQUIRE(k >= 1 && k < h->J, IPD_E_ARG, "level must be a smoothed level (1 <= k < J)");
+        ipd_ctx* ctx = h->ctx;
+        CallScope scope(ctx);
+        CycleState* st = state_of(h);
+        Level& lv = h->L[k];
+        LevelRun& rn = st->run[(size_t)k];
+        fill_f64(ctx, lv.r, 1.0, (size_t)lv.N);
+        rn.e_zero = true;
+        for (int w = 0; w < 4; ++w) launch_sweep(h, st, k, h->opts.isnsp, false);
+        hipEvent_t ev0, ev1;
+        IPD_HIP(hipEventCreate(&ev0));
+        IPD_HIP(hipEventCreate(&ev1));
+        IPD_HIP(hipEventRecord(ev0, ctx->stream));
+        for (int s = 0; s < reps; ++s) launch_sweep(h, st, k, h->opts.isnsp, false);
+        IPD_HIP(hipEventRecord(ev1, ctx->stream));
+        IPD_HIP(hipEventSynchronize(ev1));
+        float ms = 0.f;
+        IPD_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        IPD_HIP(hipEventDestroy(ev0));
+        IPD_HIP(hipEventDestroy(ev1));
+        *total_ms = ms;
+        if (launches_per_sweep) *launches_per_sweep = lv.nf > 0 ? 2 : 1;
+        if (bytes_per_sweep) *bytes_per_sweep = spmv_bytes(lv.A) + 6 * 8.0 * lv.A.nr;
+    });
+}

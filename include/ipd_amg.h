@@ -232,6 +232,11 @@ int ipd_hybrid_amg_dev(ipd_ctx*, const ipd_dmat* H0, const double* t_dev, const 
  * the algorithmic byte count B_V of SURVEY.md section 8d.                     */
 int ipd_amg_bench_cycles(ipd_amg* h, const double* b_dev, double* x_dev, int cycles,
                          double* total_ms, double* bytes_per_cycle);
+/* Times `reps` smoother sweeps of level k (1 <= k < J) with HIP events: the
+ * per-launch duration of the dominant kernel.  launches_per_sweep is 2 on the
+ * bigraph Gauss-Seidel level (F half, C half) and 1 on Jacobi levels.          */
+int ipd_amg_bench_sweeps(ipd_amg* h, int k, int reps, double* total_ms,
+                         int* launches_per_sweep, double* bytes_per_sweep);
 /* SURVEY 8d byte model of the hierarchy: per-level S(A_k), S(P_k), ...       */
 int ipd_amg_cycle_bytes(const ipd_amg* h, double* bytes_per_cycle);
 
