@@ -1,7 +1,712 @@
-// Problem-level solvers (placeholder until Hybrid_AMG lands).
+// Problem-level solvers on the device:
+//   Hybrid_AMG.m:12-113 (rescaling, component routing), components.m:32-55,
+//   Class2/AMG4POT.m:27-55 (Sherman-Morrison around two Hybrid_AMG solves).
+//
+// Ae = bk1*Q0^2 + (Q0*T*Q0 + Q0*H0*Q0)/tk is assembled entry by entry with the
+// reference's operation order (no FMA), so it is bit-identical to the oracle's and
+// the hierarchy built on it stays bit-exact.  Connected components are found on the
+// device (hook-and-compress label propagation); the O(M) bookkeeping that turns
+// labels into blocks/sizes/p/r and routes components is host logic.
+#pragma clang fp contract(off)
+
 #include "ipd_amg_internal.h"
-static int unsupported() { ipd_set_error("Hybrid_AMG path not built yet"); return IPD_E_UNSUPPORTED; }
-extern "C" int ipd_components(ipd_ctx*, const ipd_csc*, int64_t*, int64_t*, int64_t*, int64_t*, int64_t*) { return unsupported(); }
-extern "C" int ipd_hybrid_amg(ipd_ctx*, const ipd_prob*, const ipd_amg_opts*, ipd_rng*, double*, int32_t*, double*, int64_t*) { return unsupported(); }
-extern "C" int ipd_amg4pot(ipd_ctx*, const ipd_prob*, const ipd_amg_opts*, ipd_rng*, double*, int32_t*, double*, int64_t*) { return unsupported(); }
-extern "C" int ipd_hybrid_amg_dev(ipd_ctx*, const ipd_dmat*, const double*, const double*, const double*, int64_t, int64_t, double, double, const double*, const ipd_amg_opts*, ipd_rng*, double*, int32_t*, double*, int64_t*) { return unsupported(); }
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+static inline int rows_grid(int nr) { return std::max(1, std::min(cdiv(nr, 4), 4096)); }
+static inline int elems_grid(long long n) {
+    return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
+}
+
+// ---------------------------------------------------------------------------
+// Ae assembly                                             (Hybrid_AMG.m:17-24)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double qp_of(const double* __restrict__ p, const double* __restrict__ q,
+                                        int n, int i) {
+    return i < n ? q[i] : -p[i - n];  // qp = [q; -p]
+}
+
+// row lengths of Ae: the pattern of H0 plus a full diagonal
+__global__ __launch_bounds__(256) void k_ae_count(int M, const int* __restrict__ rp,
+                                                  const int* __restrict__ ci,
+                                                  int* __restrict__ rowlen) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < M; i += nwaves) {
+        bool has = false;
+        for (int t = rp[i] + lane; t < rp[i + 1]; t += 64) has |= (ci[t] == i);
+        const bool hasd = __any(has);
+        if (lane == 0) rowlen[i] = rp[i + 1] - rp[i] + (hasd ? 0 : 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ae_fill(int M, int n, const int* __restrict__ rp,
+                                                 const int* __restrict__ ci,
+                                                 const double* __restrict__ va,
+                                                 const double* __restrict__ p,
+                                                 const double* __restrict__ q,
+                                                 const double* __restrict__ tdiag, double bk1,
+                                                 double inv_tk, const int* __restrict__ orp,
+                                                 int* __restrict__ oci, double* __restrict__ ova) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < M; i += nwaves) {
+        const int b = rp[i], e = rp[i + 1];
+        const double qi = qp_of(p, q, n, i);
+        // number of stored columns below i, and whether the diagonal is stored
+        int below = 0;
+        bool has = false;
+        for (int t = b + lane; t < e; t += 64) {
+            const int j = ci[t];
+            below += (j < i);
+            has |= (j == i);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) below += __shfl_xor(below, d);
+        has = __any(has);
+        const int ob = orp[i];
+        const int shift = has ? 0 : 1;
+        for (int t = b + lane; t < e; t += 64) {
+            const int j = ci[t];
+            const double a0 = (qi * va[t]) * qp_of(p, q, n, j);  // (Q0*H0)*Q0
+            const int pos = ob + (t - b) + (j > i ? shift : 0);
+            oci[pos] = j;
+            if (j == i) {
+                const double qq = qi * qi;                       // Q = Q0*Q0
+                const double kk = tdiag ? (qi * tdiag[i]) * qi : 0.0;  // K = (Q0*T)*Q0
+                const double x = kk + a0;                        // K + A0
+                ova[pos] = bk1 * qq + inv_tk * x;
+            } else {
+                ova[pos] = inv_tk * a0;
+            }
+        }
+        if (!has && lane == 0) {
+            const double qq = qi * qi;
+            const double kk = tdiag ? (qi * tdiag[i]) * qi : 0.0;
+            oci[ob + below] = i;
+            ova[ob + below] = bk1 * qq + inv_tk * kk;
+        }
+    }
+}
+
+// f = Q0*z, dK = diag(K), and zeta = Q0*u at the end
+__global__ void k_scale_qp(int M, int n, const double* __restrict__ p, const double* __restrict__ q,
+                           const double* __restrict__ in, double* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x)
+        out[i] = qp_of(p, q, n, i) * in[i];
+}
+__global__ void k_dk(int M, int n, const double* __restrict__ p, const double* __restrict__ q,
+                     const double* __restrict__ tdiag, double* __restrict__ dK) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+        const double qi = qp_of(p, q, n, i);
+        dK[i] = tdiag ? (qi * tdiag[i]) * qi : 0.0;
+    }
+}
+__global__ void k_has_zero(int m, int n, const double* __restrict__ p, const double* __restrict__ q,
+                           int* __restrict__ flag) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m + n; i += gridDim.x * blockDim.x) {
+        const double v = i < n ? q[i] : p[i - n];
+        if (v == 0.0) *flag = 1;
+    }
+}
+
+static void build_Ae(ipd_ctx* ctx, Arena& dst, const Csr& H0, const double* tdiag, const double* p,
+                     const double* q, int m, int n, double bk1, double tk, Csr* Ae) {
+    const int M = m + n;
+    IPD_REQUIRE(H0.nr == M && H0.nc == M, IPD_E_ARG, "Hybrid_AMG: H0 must be (n+m) x (n+m)");
+    Arena& tmp = *ctx->scratch;
+    int* flag = tmp.alloc<int>(1);
+    IPD_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_has_zero, dim3(elems_grid(M)), dim3(256), 0, ctx->stream, m, n, p, q, flag);
+    int* rowlen = tmp.alloc<int>((size_t)M + 1);
+    hipLaunchKernelGGL(k_ae_count, dim3(rows_grid(M)), dim3(256), 0, ctx->stream, M, H0.rp, H0.ci,
+                       rowlen);
+    IPD_KERNEL_CHECK();
+    Csr a;
+    a.nr = a.nc = M;
+    a.rp = dst.alloc<int>((size_t)M + 1);
+    exclusive_scan_i32(ctx, rowlen, a.rp, M);
+    a.nnz = ctx->fetch1(a.rp + M);
+    IPD_REQUIRE(ctx->fetch1(flag) == 0, IPD_E_ARG, "p or q contains 0 !!!!!");  // Hybrid_AMG.m:18-19
+    a.ci = dst.alloc<int>((size_t)a.nnz);
+    a.va = dst.alloc<double>((size_t)a.nnz);
+    const double inv_tk = 1.0 / tk;
+    hipLaunchKernelGGL(k_ae_fill, dim3(rows_grid(M)), dim3(256), 0, ctx->stream, M, n, H0.rp, H0.ci,
+                       H0.va, p, q, tdiag, bk1, inv_tk, a.rp, a.ci, a.va);
+    IPD_KERNEL_CHECK();
+    *Ae = a;
+}
+
+// ---------------------------------------------------------------------------
+// connected components                                     (components.m:32-55)
+// ---------------------------------------------------------------------------
+// Hook-and-compress in ONE workgroup (M <= a few thousand nodes): every round hooks
+// the larger root of each edge under the smaller one (integer atomicMin), then
+// compresses all paths; O(log M) rounds.  At the end parent[i] is the smallest
+// member of i's component, whatever the interleaving (deterministic).
+__global__ __launch_bounds__(1024) void k_components(int N, const int* __restrict__ rp,
+                                                     const int* __restrict__ ci,
+                                                     int* __restrict__ parent) {
+    __shared__ int changed;
+    for (int i = threadIdx.x; i < N; i += 1024) parent[i] = i;
+    if (threadIdx.x == 0) parent[N] = 1;  // "not converged" until a round makes no hook
+    __syncthreads();
+    for (int round = 0; round < 64; ++round) {
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        // hook: thread-per-row walk keeps (i,j) pairs without an edge list
+        bool any = false;
+        for (int i = threadIdx.x; i < N; i += 1024) {
+            const int pi = parent[i];
+            for (int t = rp[i]; t < rp[i + 1]; ++t) {
+                const int pj = parent[ci[t]];
+                if (pj < pi) {
+                    atomicMin(&parent[pi], pj);
+                    any = true;
+                } else if (pi < pj) {
+                    atomicMin(&parent[pj], pi);
+                    any = true;
+                }
+            }
+        }
+        if (any) changed = 1;
+        __syncthreads();
+        // compress
+        for (int i = threadIdx.x; i < N; i += 1024) {
+            int r = parent[i];
+            while (parent[r] != r) r = parent[r];
+            parent[i] = r;
+        }
+        __syncthreads();
+        const int c = changed;
+        __syncthreads();
+        if (!c) {
+            if (threadIdx.x == 0) parent[N] = 0;
+            break;
+        }
+    }
+}
+
+struct Components {
+    int ncomp = 0;
+    std::vector<int> blocks;  // component of every node (numbered by smallest member)
+    std::vector<int> sizes;
+    std::vector<int> p;       // nodes grouped by component, ascending inside a component
+    std::vector<int> r;       // boundaries, ncomp+1
+};
+
+static void find_components(ipd_ctx* ctx, const Csr& A, Components* out) {
+    IPD_REQUIRE(A.nr == A.nc, IPD_E_ARG, "Adjacency matrix must be square");  // components.m:33
+    const int N = A.nr;
+    int* parent = ctx->scratch->alloc<int>((size_t)N + 1);
+    hipLaunchKernelGGL(k_components, dim3(1), dim3(1024), 0, ctx->stream, N, A.rp, A.ci, parent);
+    IPD_KERNEL_CHECK();
+    std::vector<int> par((size_t)N + 1);
+    ctx->fetch(parent, par.data(), (size_t)N + 1);
+    IPD_REQUIRE(par[(size_t)N] == 0, IPD_E_NUMERIC, "components: did not converge in 64 rounds");
+    out->blocks.assign((size_t)N, 0);
+    std::vector<int> cid((size_t)N, -1);
+    int nc = 0;
+    for (int i = 0; i < N; ++i)
+        if (par[i] == i) cid[i] = nc++;  // roots ascend == smallest members ascend
+    out->ncomp = nc;
+    out->sizes.assign((size_t)nc, 0);
+    for (int i = 0; i < N; ++i) {
+        IPD_REQUIRE(par[i] >= 0 && par[i] <= i && cid[par[i]] >= 0, IPD_E_NUMERIC,
+                    "components: label propagation did not converge");
+        out->blocks[i] = cid[par[i]];
+        out->sizes[(size_t)out->blocks[i]]++;
+    }
+    out->r.assign((size_t)nc + 1, 0);
+    for (int c = 0; c < nc; ++c) out->r[c + 1] = out->r[c] + out->sizes[c];
+    out->p.assign((size_t)N, 0);
+    std::vector<int> cur(out->r.begin(), out->r.end() - 1);
+    for (int i = 0; i < N; ++i) out->p[(size_t)cur[(size_t)out->blocks[i]]++] = i;
+}
+
+// ---------------------------------------------------------------------------
+// sub-matrix of one component: Aek = Ae(pk,pk), pk ascending
+// ---------------------------------------------------------------------------
+__global__ void k_sub_count(int nk, const int* __restrict__ pk, const int* __restrict__ rp,
+                            int* __restrict__ rowlen) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nk; r += gridDim.x * blockDim.x) {
+        const int i = pk[r];
+        rowlen[r] = rp[i + 1] - rp[i];
+    }
+}
+__global__ __launch_bounds__(256) void k_sub_fill(int nk, const int* __restrict__ pk,
+                                                  const int* __restrict__ newidx,
+                                                  const int* __restrict__ rp,
+                                                  const int* __restrict__ ci,
+                                                  const double* __restrict__ va,
+                                                  const int* __restrict__ orp,
+                                                  int* __restrict__ oci, double* __restrict__ ova) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < nk; r += nwaves) {
+        const int i = pk[r];
+        const int b = rp[i], ob = orp[r];
+        for (int t = b + lane; t < rp[i + 1]; t += 64) {
+            oci[ob + (t - b)] = newidx[ci[t]];  // a component is closed: every column is inside
+            ova[ob + (t - b)] = va[t];
+        }
+    }
+}
+__global__ void k_gather(int nk, const int* __restrict__ pk, const double* __restrict__ src,
+                         double* __restrict__ dst) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nk; r += gridDim.x * blockDim.x)
+        dst[r] = src[pk[r]];
+}
+__global__ void k_scatter(int nk, const int* __restrict__ pk, const double* __restrict__ src,
+                          double* __restrict__ dst) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nk; r += gridDim.x * blockDim.x)
+        dst[pk[r]] = src[r];
+}
+__global__ void k_scale(int n, double alpha, const double* __restrict__ in,
+                        double* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = alpha * in[i];
+}
+
+// ---------------------------------------------------------------------------
+// small components: u(pk) = Ae(pk,pk) \ f(pk)              (Hybrid_AMG.m:85-91)
+// ---------------------------------------------------------------------------
+// The system is block diagonal with SPD blocks of at most N0 = 100 rows: one
+// workgroup per block factors its dense copy in LDS (Cholesky) and solves.
+__global__ __launch_bounds__(256) void k_small_blocks(const int* __restrict__ boff,
+                                                      const int* __restrict__ nodes,
+                                                      const int* __restrict__ local,
+                                                      const int* __restrict__ rp,
+                                                      const int* __restrict__ ci,
+                                                      const double* __restrict__ va,
+                                                      const double* __restrict__ f,
+                                                      double* __restrict__ u,
+                                                      int* __restrict__ bad) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int blk = blockIdx.x;
+    const int o = boff[blk], nb = boff[blk + 1] - o;
+    const int ld = nb + 1;
+    double* A = reinterpret_cast<double*>(smem_raw);  // nb x ld, row-major
+    double* y = A + (size_t)nb * ld;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < nb * ld; k += 256) A[k] = 0.0;
+    __syncthreads();
+    for (int li = tid; li < nb; li += 256) {
+        const int i = nodes[o + li];
+        for (int t = rp[i]; t < rp[i + 1]; ++t) A[li * ld + local[ci[t]]] = va[t];
+        y[li] = f[i];
+    }
+    __syncthreads();
+    // right-looking Cholesky, lower triangle
+    for (int k = 0; k < nb; ++k) {
+        const double akk = A[k * ld + k];
+        if (!(akk > 0.0)) {
+            if (tid == 0) *bad = 1;
+            return;  // uniform: every thread reads the same akk
+        }
+        const double lkk = sqrt(akk);
+        __syncthreads();
+        for (int i = k + tid; i < nb; i += 256) A[i * ld + k] = (i == k) ? lkk : A[i * ld + k] / lkk;
+        __syncthreads();
+        const int rem = nb - k - 1;
+        for (int idx = tid; idx < rem * rem; idx += 256) {
+            const int i = k + 1 + idx / rem, j = k + 1 + idx % rem;
+            if (j <= i) A[i * ld + j] -= A[i * ld + k] * A[j * ld + k];
+        }
+        __syncthreads();
+    }
+    // forward and backward substitution by thread 0 of each wave-0 lane set (nb <= 100)
+    if (tid == 0) {
+        for (int i = 0; i < nb; ++i) {
+            double s = y[i];
+            for (int j = 0; j < i; ++j) s -= A[i * ld + j] * y[j];
+            y[i] = s / A[i * ld + i];
+        }
+        for (int i = nb - 1; i >= 0; --i) {
+            double s = y[i];
+            for (int j = i + 1; j < nb; ++j) s -= A[j * ld + i] * y[j];
+            y[i] = s / A[i * ld + i];
+        }
+    }
+    __syncthreads();
+    for (int li = tid; li < nb; li += 256) u[nodes[o + li]] = y[li];
+}
+
+// ---------------------------------------------------------------------------
+// Hybrid_AMG
+// ---------------------------------------------------------------------------
+struct HybridOut {
+    int itamg = 0;
+    double resamg = 0.0;
+    long long num_comp = 0, it_num = 0;
+};
+
+static double host_sum(ipd_ctx* ctx, const double* d, int n) {
+    std::vector<double> h((size_t)n);
+    ctx->fetch(d, h.data(), (size_t)n);
+    double s = 0.0;
+    for (double v : h) s += v;
+    return s;
+}
+
+// Solves Ae u = f for one (sub)system with Class_AMG and returns its statistics.
+static void class_amg_on(ipd_ctx* ctx, const Csr& A, const double* f, AmgOpts o, int isnsp,
+                         long long fnode, double gscale, ipd_rng* rng, double* u_out, int* it,
+                         double* rel_res) {
+    const int N = A.nr;
+    o.isnsp = isnsp;
+    o.fnode = fnode;
+    std::vector<double> g((size_t)N);
+    rng->fill(g.data(), N);                       // Hybrid_AMG.m:40 / :69  bk1*tk*rand(size(f))
+    for (double& v : g) v = gscale * v;
+    double* dg = ctx->scratch->alloc<double>((size_t)N);
+    ctx->upload(dg, g.data(), (size_t)N);
+    std::unique_ptr<ipd_amg, void (*)(ipd_amg*)> h(amg_setup(ctx, A, o, rng), ipd_amg_destroy);
+    int32_t its = 0;
+    double rr = 0.0;
+    amg_solve_dev(h.get(), f, dg, u_out, &its, &rr, nullptr, nullptr);
+    *it = its;
+    *rel_res = rr;
+}
+
+static void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
+                           const double* q, int m, int n, double bk1, double tk, const double* z,
+                           const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out) {
+    IPD_REQUIRE(rng, IPD_E_ARG, "Hybrid_AMG needs a rand stream");
+    IPD_REQUIRE(tk != 0.0, IPD_E_ARG, "tk must be nonzero");
+    const int M = m + n;
+    const int N0 = 100;                                                   // Hybrid_AMG.m:51
+    Arena& tmp = *ctx->scratch;
+    Csr Ae;
+    build_Ae(ctx, tmp, H0, tdiag, p, q, m, n, bk1, tk, &Ae);            // :17-24
+    double* f = tmp.alloc<double>((size_t)M);
+    double* u = tmp.alloc<double>((size_t)M);
+    double* dK = tmp.alloc<double>((size_t)M);
+    const int g = elems_grid(M);
+    hipLaunchKernelGGL(k_scale_qp, dim3(g), dim3(256), 0, ctx->stream, M, n, p, q, z, f);
+    hipLaunchKernelGGL(k_dk, dim3(g), dim3(256), 0, ctx->stream, M, n, p, q, tdiag, dK);
+    IPD_KERNEL_CHECK();
+    IPD_HIP(hipMemsetAsync(u, 0, sizeof(double) * (size_t)M, ctx->stream));
+    // components of A0 = Q0*H0*Q0: same pattern as H0 (qp has no zeros)     :27
+    Components cc;
+    find_components(ctx, H0, &cc);
+    out->num_comp = cc.ncomp;
+    std::vector<double> hdK;
+    if (tdiag) {
+        hdK.resize((size_t)M);
+        ctx->fetch(dK, hdK.data(), (size_t)M);
+    }
+    auto sum_dk = [&](const int* idx, int cnt) {
+        if (!tdiag) return 0.0;
+        double s = 0.0;
+        for (int k = 0; k < cnt; ++k) s += hdK[(size_t)(idx ? idx[k] : k)];
+        return s;
+    };
+    const double gscale = bk1 * tk;
+    if (cc.ncomp == 1) {                                                  // :30-48
+        const int isnsp = sum_dk(nullptr, M) != 0.0 ? 0 : 1;
+        int it = 0;
+        double rr = 0.0;
+        class_amg_on(ctx, Ae, f, opts, isnsp, n, gscale, rng, u, &it, &rr);
+        out->itamg = it;
+        out->resamg = rr;
+        out->it_num = 1;
+    } else {                                                              // :50-107
+        out->itamg = 0;
+        out->resamg = 0.0;
+        out->it_num = 0;
+        std::vector<int> newidx((size_t)M);
+        int* d_pk = tmp.alloc<int>((size_t)M);
+        int* d_new = tmp.alloc<int>((size_t)M);
+        for (int k = 0; k < cc.ncomp; ++k) {                              // :55 large components
+            if (cc.sizes[k] <= N0) continue;
+            const int nk = cc.sizes[k];
+            const int* pk = cc.p.data() + cc.r[k];  // ascending: F side first (quirk A-9)
+            std::fill(newidx.begin(), newidx.end(), -1);
+            int fnode = 0;
+            for (int r = 0; r < nk; ++r) {
+                newidx[(size_t)pk[r]] = r;
+                fnode += pk[r] < n;                                       // :68 sum(pk<=n)
+            }
+            ctx->upload(d_pk, pk, (size_t)nk);
+            ctx->upload(d_new, newidx.data(), (size_t)M);
+            Csr Ak;
+            Ak.nr = Ak.nc = nk;
+            int* rowlen = tmp.alloc<int>((size_t)nk + 1);
+            Ak.rp = tmp.alloc<int>((size_t)nk + 1);
+            hipLaunchKernelGGL(k_sub_count, dim3(elems_grid(nk)), dim3(256), 0, ctx->stream, nk,
+                               d_pk, Ae.rp, rowlen);
+            IPD_KERNEL_CHECK();
+            exclusive_scan_i32(ctx, rowlen, Ak.rp, nk);
+            Ak.nnz = ctx->fetch1(Ak.rp + nk);
+            Ak.ci = tmp.alloc<int>((size_t)Ak.nnz);
+            Ak.va = tmp.alloc<double>((size_t)Ak.nnz);
+            hipLaunchKernelGGL(k_sub_fill, dim3(rows_grid(nk)), dim3(256), 0, ctx->stream, nk, d_pk,
+                               d_new, Ae.rp, Ae.ci, Ae.va, Ak.rp, Ak.ci, Ak.va);
+            double* fk = tmp.alloc<double>((size_t)nk);
+            double* dk = tmp.alloc<double>((size_t)nk);
+            hipLaunchKernelGGL(k_gather, dim3(elems_grid(nk)), dim3(256), 0, ctx->stream, nk, d_pk,
+                               f, fk);
+            IPD_KERNEL_CHECK();
+            const int isnsp = sum_dk(pk, nk) != 0.0 ? 0 : 1;              // :60-66
+            IPD_REQUIRE(fnode > 0 && fnode < nk, IPD_E_NUMERIC,
+                        "Hybrid_AMG: a large component lies on one side of the bigraph");
+            int it = 0;
+            double rr = 0.0;
+            class_amg_on(ctx, Ak, fk, opts, isnsp, fnode, gscale, rng, dk, &it, &rr);
+            hipLaunchKernelGGL(k_scatter, dim3(elems_grid(nk)), dim3(256), 0, ctx->stream, nk, d_pk,
+                               dk, u);                                    // :77 u(pk) = dk
+            IPD_KERNEL_CHECK();
+            out->itamg = std::max(out->itamg, it);
+            out->resamg = std::max(out->resamg, rr);
+            out->it_num = k + 1;                                          // :80 (1-based)
+        }
+        // small components, all together                                   :85-91
+        std::vector<int> nodes, boff(1, 0), local((size_t)M, 0);
+        int maxnb = 0;
+        for (int k = 0; k < cc.ncomp; ++k) {
+            if (cc.sizes[k] > N0) continue;
+            for (int r = cc.r[k]; r < cc.r[k + 1]; ++r) {
+                local[(size_t)cc.p[r]] = r - cc.r[k];
+                nodes.push_back(cc.p[r]);
+            }
+            boff.push_back((int)nodes.size());
+            maxnb = std::max(maxnb, cc.sizes[k]);
+        }
+        if (!nodes.empty()) {
+            const int nblk = (int)boff.size() - 1;
+            int* d_boff = tmp.alloc<int>(boff.size());
+            int* d_nodes = tmp.alloc<int>(nodes.size());
+            int* d_local = tmp.alloc<int>((size_t)M);
+            int* bad = tmp.alloc<int>(1);
+            ctx->upload(d_boff, boff.data(), boff.size());
+            ctx->upload(d_nodes, nodes.data(), nodes.size());
+            ctx->upload(d_local, local.data(), (size_t)M);
+            IPD_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+            const size_t lds = sizeof(double) * ((size_t)maxnb * (maxnb + 1) + maxnb);
+            static bool attr_set = false;
+            if (!attr_set) {
+                IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_blocks),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_small_blocks, dim3(nblk), dim3(256), lds, ctx->stream, d_boff,
+                               d_nodes, d_local, Ae.rp, Ae.ci, Ae.va, f, u, bad);
+            IPD_KERNEL_CHECK();
+            IPD_REQUIRE(ctx->fetch1(bad) == 0, IPD_E_NUMERIC,
+                        "Hybrid_AMG: a small diagonal block is not positive definite");
+        }
+    }
+    hipLaunchKernelGGL(k_scale_qp, dim3(g), dim3(256), 0, ctx->stream, M, n, p, q,
+                       (const double*)u, zeta);                           // :113 zeta = Q0*u
+    IPD_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// AMG4POT                                              (Class2/AMG4POT.m:27-55)
+// ---------------------------------------------------------------------------
+__global__ void k_mask_mul(size_t len, const uint8_t* __restrict__ s,
+                           const double* __restrict__ phi, double* __restrict__ out,
+                           double* __restrict__ part) {
+    // out = s.*phi ; part[block] = sum phi.*(s.*phi)
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < len; i += (size_t)gridDim.x * 256) {
+        const double v = s[i] ? phi[i] : 0.0;
+        out[i] = v;
+        acc += phi[i] * v;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+static double host_dot(ipd_ctx* ctx, const double* a, const double* b, int n) {
+    std::vector<double> ha((size_t)n), hb((size_t)n);
+    ctx->fetch(a, ha.data(), (size_t)n);
+    ctx->fetch(b, hb.data(), (size_t)n);
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += ha[(size_t)i] * hb[(size_t)i];
+    return s;
+}
+
+__global__ void k_axpby(int n, double a, const double* __restrict__ x, double b,
+                        const double* __restrict__ y, double* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = a * x[i] + b * y[i];
+}
+
+static void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
+                        const double* q, int m, int n, double bk1, double tk, const double* z,
+                        const uint8_t* s, const double* phi, const AmgOpts& opts, ipd_rng* rng,
+                        double* zeta, HybridOut* out) {
+    const int M = m + n;
+    const size_t mn = (size_t)m * n;
+    Arena& tmp = *ctx->scratch;
+    const double epss = bk1, sg = 1.0 / tk;                               // :31
+    double* sphi = tmp.alloc<double>(mn);
+    const int nb = (int)std::max<size_t>(1, std::min<size_t>((mn + 255) / 256, 1024));
+    double* part = tmp.alloc<double>((size_t)nb);
+    hipLaunchKernelGGL(k_mask_mul, dim3(nb), dim3(256), 0, ctx->stream, mn, s, phi, sphi, part);
+    IPD_KERNEL_CHECK();
+    const double phi_e = epss + sg * host_sum(ctx, part, nb);             // :33
+    double* v = tmp.alloc<double>((size_t)M);
+    kkt_ax(ctx, sphi, p, q, m, n, v);                                     // :34 v = Ax(s.*phi)
+    const double z2 = ctx->fetch1(z + M);
+    double* w = tmp.alloc<double>((size_t)M);
+    hipLaunchKernelGGL(k_axpby, dim3(elems_grid(M)), dim3(256), 0, ctx->stream, M, 1.0, z,
+                       -(sg / phi_e * z2), (const double*)v, w);          // w = z1 - sg/phi_e*z2*v
+    IPD_KERNEL_CHECK();
+    double* vv = tmp.alloc<double>((size_t)M);
+    double* ww = tmp.alloc<double>((size_t)M);
+    HybridOut o1, o2;
+    hybrid_amg_dev(ctx, H0, tdiag, p, q, m, n, bk1, tk, v, opts, rng, vv, &o1);   // :46
+    hybrid_amg_dev(ctx, H0, tdiag, p, q, m, n, bk1, tk, w, opts, rng, ww, &o2);   // :47
+    const double vvv = host_dot(ctx, v, vv, M);
+    const double vww = host_dot(ctx, v, ww, M);
+    const double tt = sg * sg / (phi_e - sg * sg * vvv);                  // :53
+    hipLaunchKernelGGL(k_axpby, dim3(elems_grid(M)), dim3(256), 0, ctx->stream, M, 1.0,
+                       (const double*)ww, tt * vww, (const double*)vv, zeta);  // zeta1
+    IPD_KERNEL_CHECK();
+    const double vz1 = host_dot(ctx, v, zeta, M);
+    const double zeta2 = (z2 - sg * vz1) / phi_e;                         // :54
+    ctx->upload(zeta + M, &zeta2, 1);
+    out->itamg = std::max(o1.itamg, o2.itamg);                            // :55
+    out->resamg = std::max(o1.resamg, o2.resamg);
+    out->num_comp = std::max(o1.num_comp, o2.num_comp);
+    out->it_num = std::max(o1.it_num, o2.it_num);
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" int ipd_components(ipd_ctx* ctx, const ipd_csc* A, int64_t* blocks, int64_t* sizes,
+                              int64_t* p, int64_t* r, int64_t* ncomp) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && A && blocks && sizes && p && r && ncomp, IPD_E_ARG, "NULL argument");
+        IPD_REQUIRE(A->nrows == A->ncols, IPD_E_ARG, "Adjacency matrix must be square");
+        CallScope scope(ctx);
+        Csr a;
+        csr_upload_from_csc(ctx, *ctx->scratch, A, true, &a);  // undirected graph: pattern symmetric
+        Components cc;
+        find_components(ctx, a, &cc);
+        *ncomp = cc.ncomp;
+        for (int i = 0; i < a.nr; ++i) {
+            blocks[i] = cc.blocks[(size_t)i];
+            p[i] = cc.p[(size_t)i];
+        }
+        for (int c = 0; c < cc.ncomp; ++c) sizes[c] = cc.sizes[(size_t)c];
+        for (int c = 0; c <= cc.ncomp; ++c) r[c] = cc.r[(size_t)c];
+    });
+}
+
+static void check_prob(const ipd_prob* pd, bool pot) {
+    IPD_REQUIRE(pd && pd->p && pd->q && pd->H0 && pd->z, IPD_E_ARG, "prob_data: NULL field");
+    IPD_REQUIRE(pd->m > 0 && pd->n > 0 && pd->m + pd->n < (int64_t(1) << 30), IPD_E_ARG,
+                "prob_data: bad m/n");
+    if (pot) IPD_REQUIRE(pd->s && pd->phi, IPD_E_ARG, "AMG4POT needs prob_data.s and .phi");
+}
+
+extern "C" int ipd_hybrid_amg(ipd_ctx* ctx, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
+                              double* zeta, int32_t* itamg, double* resamg, int64_t info[2]) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && zeta, IPD_E_ARG, "NULL argument");
+        check_prob(pd, false);
+        CallScope scope(ctx);
+        Arena& tmp = *ctx->scratch;
+        const int m = (int)pd->m, n = (int)pd->n, M = m + n;
+        Csr H0;
+        csr_upload_from_csc(ctx, tmp, pd->H0, true, &H0);
+        double* dp = tmp.alloc<double>((size_t)m);
+        double* dq = tmp.alloc<double>((size_t)n);
+        double* dz = tmp.alloc<double>((size_t)M);
+        double* dt = nullptr;
+        ctx->upload(dp, pd->p, (size_t)m);
+        ctx->upload(dq, pd->q, (size_t)n);
+        ctx->upload(dz, pd->z, (size_t)M);
+        if (pd->t) {
+            dt = tmp.alloc<double>((size_t)M);
+            ctx->upload(dt, pd->t, (size_t)M);
+        }
+        double* dzeta = tmp.alloc<double>((size_t)M);
+        HybridOut ho;
+        hybrid_amg_dev(ctx, H0, dt, dp, dq, m, n, pd->bk1, pd->tk, dz, amg_fill_defaults(o), rng,
+                       dzeta, &ho);
+        ctx->fetch(dzeta, zeta, (size_t)M);
+        if (itamg) *itamg = ho.itamg;
+        if (resamg) *resamg = ho.resamg;
+        if (info) {
+            info[0] = ho.num_comp;
+            info[1] = ho.it_num;
+        }
+    });
+}
+
+extern "C" int ipd_hybrid_amg_dev(ipd_ctx* ctx, const ipd_dmat* H0, const double* t_dev,
+                                  const double* p_dev, const double* q_dev, int64_t m, int64_t n,
+                                  double bk1, double tk, const double* z_dev,
+                                  const ipd_amg_opts* o, ipd_rng* rng, double* zeta_dev,
+                                  int32_t* itamg, double* resamg, int64_t info[2]) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && H0 && p_dev && q_dev && z_dev && zeta_dev, IPD_E_ARG, "NULL argument");
+        IPD_REQUIRE(m > 0 && n > 0, IPD_E_ARG, "bad m/n");
+        CallScope scope(ctx);
+        HybridOut ho;
+        hybrid_amg_dev(ctx, H0->m, t_dev, p_dev, q_dev, (int)m, (int)n, bk1, tk, z_dev,
+                       amg_fill_defaults(o), rng, zeta_dev, &ho);
+        ctx->sync();
+        if (itamg) *itamg = ho.itamg;
+        if (resamg) *resamg = ho.resamg;
+        if (info) {
+            info[0] = ho.num_comp;
+            info[1] = ho.it_num;
+        }
+    });
+}
+
+extern "C" int ipd_amg4pot(ipd_ctx* ctx, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
+                           double* zeta, int32_t* itamg, double* resamg, int64_t info[2]) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && zeta, IPD_E_ARG, "NULL argument");
+        check_prob(pd, true);
+        CallScope scope(ctx);
+        Arena& tmp = *ctx->scratch;
+        const int m = (int)pd->m, n = (int)pd->n, M = m + n;
+        const size_t mn = (size_t)m * n;
+        Csr H0;
+        csr_upload_from_csc(ctx, tmp, pd->H0, true, &H0);
+        double* dp = tmp.alloc<double>((size_t)m);
+        double* dq = tmp.alloc<double>((size_t)n);
+        double* dz = tmp.alloc<double>((size_t)M + 1);
+        double* dphi = tmp.alloc<double>(mn);
+        uint8_t* ds = tmp.alloc<uint8_t>(mn);
+        double* dt = nullptr;
+        ctx->upload(dp, pd->p, (size_t)m);
+        ctx->upload(dq, pd->q, (size_t)n);
+        ctx->upload(dz, pd->z, (size_t)M + 1);
+        ctx->upload(dphi, pd->phi, mn);
+        ctx->upload(ds, pd->s, mn);
+        if (pd->t) {
+            dt = tmp.alloc<double>((size_t)M);
+            ctx->upload(dt, pd->t, (size_t)M);
+        }
+        double* dzeta = tmp.alloc<double>((size_t)M + 1);
+        HybridOut ho;
+        amg4pot_dev(ctx, H0, dt, dp, dq, m, n, pd->bk1, pd->tk, dz, ds, dphi, amg_fill_defaults(o),
+                    rng, dzeta, &ho);
+        ctx->fetch(dzeta, zeta, (size_t)M + 1);
+        if (itamg) *itamg = ho.itamg;
+        if (resamg) *resamg = ho.resamg;
+        if (info) {
+            info[0] = ho.num_comp;
+            info[1] = ho.it_num;
+        }
+    });
+}
