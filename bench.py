@@ -212,9 +212,22 @@ def main():
             tot_ms += w * ms.value / reps
             launches += w * lps.value
         achieved = tot_bytes / tot_ms / 1e6 if tot_ms > 0 else 0.0  # GB/s
+        # HBM traffic per launch of the same kernel from the committed rocprofv3 PMC passes
+        # (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, gfx950 x2 read
+        # correction applied by tools/summarize_pmc.py); null when no profile is present
+        traffic = None
+        import glob
+        for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))[-1:]:
+            try:
+                pm = json.load(open(pf))
+                for kname, d in pm.items():
+                    if "k_smooth" in kname and "hbm_traffic_bytes_per_launch" in d:
+                        traffic = d["hbm_traffic_bytes_per_launch"]
+            except Exception:
+                traffic = None
         result["roofline"] = {"bound": "hbm", "kernel": "k_smooth", "achieved": achieved,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                              "traffic": None,
+                              "traffic": traffic,
                               "avg_us_per_launch": 1e3 * tot_ms / launches if launches else None,
                               "avg_bytes_per_launch": tot_bytes / launches if launches else None,
                               "per_level": per_level}

@@ -127,25 +127,25 @@ template <bool STAGED, bool PAD>
 __global__ __launch_bounds__(BT) void k_smooth(SmoothArgs a) {
     __shared__ PhaseLds lds;
     extern __shared__ __attribute__((aligned(16))) double xs_dyn[];
-    phase_smooth<STAGED, PAD>(a, blockIdx.x, &lds, xs_dyn);
+    phase_smooth<STAGED, PAD>(a, blockIdx.x, gridDim.x, &lds, xs_dyn);
 }
 template <bool STAGED, bool PAD>
-__global__ __launch_bounds__(BT) void k_resid(LevelDev lv, const double* e) {
+__global__ __launch_bounds__(BT) void k_resid(LevelDev lv, const double* e, int row0, int row1) {
     __shared__ PhaseLds lds;
     extern __shared__ __attribute__((aligned(16))) double xs_dyn[];
-    phase_resid<STAGED, PAD>(lv, e, blockIdx.x, &lds, xs_dyn);
+    phase_resid<STAGED, PAD>(lv, e, row0, row1, blockIdx.x, gridDim.x, &lds, xs_dyn);
 }
 template <bool STAGED>
 __global__ __launch_bounds__(BT) void k_xfer(XferArgs a) {
     __shared__ PhaseLds lds;
     extern __shared__ __attribute__((aligned(16))) double xs_dyn[];
-    phase_xfer<STAGED>(a, blockIdx.x, &lds, xs_dyn);
+    phase_xfer<STAGED>(a, blockIdx.x, gridDim.x, &lds, xs_dyn);
 }
 template <bool STAGED, bool PAD>
 __global__ __launch_bounds__(BT) void k_top(TopArgs a) {
     __shared__ PhaseLds lds;
     extern __shared__ __attribute__((aligned(16))) double xs_dyn[];
-    phase_top<STAGED, PAD>(a, blockIdx.x, &lds, xs_dyn);
+    phase_top<STAGED, PAD>(a, blockIdx.x, gridDim.x, &lds, xs_dyn);
 }
 
 // padded off-diagonal copy of a CSR matrix: one wave per row
@@ -198,11 +198,17 @@ __global__ __launch_bounds__(256) void k_pad_build(int N, int S, const int* __re
 
 // hist[0] = res0 (set on the first call), hist[1] = res, hist[2] = previous res,
 // hist[3] = rel_res, hist[4] = rhok                        Class_AMG.m:89,103-105
-__global__ __launch_bounds__(BT) void k_conv(const double* nrm_part, int npart, double* hist,
+__global__ __launch_bounds__(BT) void k_conv(const double* __restrict__ r, int n, double* hist,
                                              int first) {
     __shared__ double red[16];
     double s = 0.0;
-    for (int k = threadIdx.x; k < npart; k += BT) s += nrm_part[k];
+    for (int k0 = threadIdx.x; k0 < n; k0 += 4 * BT) {  // 4 independent loads in flight
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (k0 + u * BT < n) ? r[k0 + u * BT] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += v[u] * v[u];
+    }
     const double tot = block_sum(s, red);
     if (threadIdx.x == 0) {
         const double res = sqrt(tot);

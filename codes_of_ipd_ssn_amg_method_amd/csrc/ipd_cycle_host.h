@@ -16,8 +16,15 @@ struct LevelRun {  // per-level run state kept next to Level
 
 struct CycleState {
     std::vector<LevelRun> run;  // 1-based
-    double* nrm_part = nullptr;
     double* hist = nullptr;
+    // row-block sharding: `shard_ranks` owners per row range.  In emulate mode
+    // one process plays all owners back to back on the shared vectors (the all-gather is
+    // then implicit) -- used by the single-GPU test of the slicing logic.
+    int shard_ranks = 1;
+    int shard_rank = 0;
+    bool shard_emulate = false;
+    int shard_min_rows = 256;
+    int num_cu = 256;
     double* x2 = nullptr;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};  // captured Class_AMG loop bodies (x->x2, x2->x)
     const double* gb = nullptr;                    // right-hand side the graphs were captured for
@@ -160,6 +167,8 @@ void amg_prepare_levels(ipd_amg* h) {
         ra.x = fine.rr;
         ra.y = coarse.r;
         ra.add = 0;
+        ra.row0 = 0;
+        ra.row1 = ra.nrows;
         ra.staged = ra.ncols <= STAGE_MAX ? 1 : 0;
         rn.restrict_args = ra;
         XferArgs pa;  // prolongation: rows of P (fine rows), gathers the coarse correction
@@ -173,6 +182,8 @@ void amg_prepare_levels(ipd_amg* h) {
         pa.x = coarse.e;
         pa.y = fine.e;
         pa.add = 1;
+        pa.row0 = 0;
+        pa.row1 = pa.nrows;
         pa.staged = pa.ncols <= STAGE_MAX ? 1 : 0;
         rn.prolong_args = pa;
     }
@@ -195,7 +206,7 @@ void amg_prepare_levels(ipd_amg* h) {
         a.nresk = 0;
         st->run[(size_t)h->J].pcg = a;
     }
-    st->nrm_part = ar.alloc<double>((size_t)cu + 1);
+    st->num_cu = cu;
     st->hist = ar.alloc<double>(8);
     st->x2 = ar.alloc<double>((size_t)h->L[1].A.nr);
     h->x = ar.alloc<double>((size_t)h->L[1].A.nr);
@@ -226,23 +237,52 @@ void amg_prepare_levels(ipd_amg* h) {
         IPD_KERNEL_CHECK();                                                                       \
     } while (0)
 
-static void launch_smooth(ipd_ctx* ctx, const SmoothArgs& a) {
-    const size_t dyn = a.staged ? sizeof(double) * (size_t)a.lv.N : 0;
-    IPD_LAUNCH_SP(k_smooth, a.staged, a.lv.S > 0, a.lv.G, dyn, a);
+// Runs `launch(r0, r1)` over the row range [lo, hi) of a level.  Unsharded: one call.
+// Sharded: this rank's slice only, followed by one grouped RCCL all-gather of the
+// vectors the launch produced (each rank wrote its own slice of every one of them).
+template <class F>
+static void run_rows(ipd_ctx* ctx, CycleState* st, int lo, int hi, F launch,
+                     std::initializer_list<double*> produced) {
+    const int G = st->shard_ranks;
+    const int rows = hi - lo;
+    if (G <= 1 || rows % G != 0 || rows < st->shard_min_rows) {  // replicated level
+        launch(lo, hi);
+        return;
+    }
+    const int cnt = rows / G;
+    if (st->shard_emulate) {
+        for (int vr = 0; vr < G; ++vr) launch(lo + vr * cnt, lo + (vr + 1) * cnt);
+        return;
+    }
+    launch(lo + st->shard_rank * cnt, lo + (st->shard_rank + 1) * cnt);
+    double* bases[4];
+    int nv = 0;
+    for (double* v : produced)
+        if (v) bases[nv++] = v + lo;
+    comm_allgather_inplace(ctx, bases, nv, cnt);
 }
 
-static void launch_xfer(ipd_ctx* ctx, const XferArgs& a) {
+static void launch_smooth(ipd_ctx* ctx, const SmoothArgs& a, int cu) {
+    const size_t dyn = a.staged ? sizeof(double) * (size_t)a.lv.N : 0;
+    const int grid = pick_blocks(a.row1 - a.row0, a.lv.L, cu);
+    IPD_LAUNCH_SP(k_smooth, a.staged, a.lv.S > 0, grid, dyn, a);
+}
+
+static void launch_xfer(ipd_ctx* ctx, const XferArgs& a, int cu) {
     const size_t dyn = a.staged ? sizeof(double) * (size_t)a.ncols : 0;
+    const int grid = pick_blocks(a.row1 - a.row0, a.L, cu);
     if (a.staged)
-        hipLaunchKernelGGL(k_xfer<true>, dim3(a.G), dim3(BT), dyn, ctx->stream, a);
+        hipLaunchKernelGGL(k_xfer<true>, dim3(grid), dim3(BT), dyn, ctx->stream, a);
     else
-        hipLaunchKernelGGL(k_xfer<false>, dim3(a.G), dim3(BT), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_xfer<false>, dim3(grid), dim3(BT), 0, ctx->stream, a);
     IPD_KERNEL_CHECK();
 }
 
-static void launch_resid(ipd_ctx* ctx, const LevelRun& rn, const double* e) {
+static void launch_resid(ipd_ctx* ctx, const LevelRun& rn, const double* e, int r0, int r1,
+                         int cu) {
     const size_t dyn = rn.staged ? sizeof(double) * (size_t)rn.dev.N : 0;
-    IPD_LAUNCH_SP(k_resid, rn.staged, rn.dev.S > 0, rn.dev.G, dyn, rn.dev, e);
+    const int grid = pick_blocks(r1 - r0, rn.dev.L, cu);
+    IPD_LAUNCH_SP(k_resid, rn.staged, rn.dev.S > 0, grid, dyn, rn.dev, e, r0, r1);
 }
 
 // one smoother sweep on level k: Jacobi = one launch, bigraph GS = two half launches
@@ -259,26 +299,26 @@ static void launch_sweep(ipd_amg* h, CycleState* st, int k, int isnsp, bool post
     a.isnsp = isnsp;
     a.staged = rn.staged;
     a.eold_zero = rn.e_zero ? 1 : 0;
+    const int cu = st->num_cu;
+    auto go = [&](int r0, int r1) {
+        a.row0 = r0;
+        a.row1 = r1;
+        launch_smooth(ctx, a, cu);
+    };
     if (lv.nf == 0) {
-        a.row0 = 0;
-        a.row1 = lv.N;
         a.u0 = a.u1 = 0;
         a.wout = nullptr;
-        launch_smooth(ctx, a);
+        run_rows(ctx, st, 0, lv.N, go, {a.enew});
     } else {
         // pre: F rows then C rows (Rk{1});  post: C rows then F rows (Rk{1}')
         const int f0 = post ? lv.nf : 0, f1 = post ? lv.N : lv.nf;  // first half rows
         const int s0 = post ? 0 : lv.nf, s1 = post ? lv.nf : lv.N;  // second half rows
-        a.row0 = f0;
-        a.row1 = f1;
         a.u0 = a.u1 = 0;
-        launch_smooth(ctx, a);
-        a.row0 = s0;
-        a.row1 = s1;
+        run_rows(ctx, st, f0, f1, go, {a.enew, a.wout});
         a.u0 = f0;
         a.u1 = f1;
         a.wout = nullptr;
-        launch_smooth(ctx, a);
+        run_rows(ctx, st, s0, s1, go, {a.enew});
     }
     rn.e_zero = false;
     std::swap(lv.e, lv.e2);
@@ -293,8 +333,9 @@ void amg_cycle(ipd_amg* h, int k, int isnsp, bool wcycle, bool keep_e) {
     IPD_REQUIRE(st, IPD_E_ARG, "hierarchy has no cycle state");
     Level& lv = h->L[k];
     LevelRun& rn = st->run[(size_t)k];
+    const int cu = st->num_cu;
     if (k == h->J) {                                   // MG_Vcycle.m:43 / MG_Wcycle.m:44
-        PcgArgs a = rn.pcg;
+        PcgArgs a = rn.pcg;                            // replicated on every rank
         a.rhs = lv.r;
         a.d = lv.e;
         hipLaunchKernelGGL(k_pcg, dim3(1), dim3(BT), 0, ctx->stream, a);
@@ -310,9 +351,17 @@ void amg_cycle(ipd_amg* h, int k, int isnsp, bool wcycle, bool keep_e) {
         }
     }
     for (int s = 0; s < nu; ++s) launch_sweep(h, st, k, isnsp, false);          // :14-25
-    launch_resid(ctx, rn, lv.e);                                                 // :27
+    run_rows(ctx, st, 0, lv.N,                                                   // :27
+             [&](int r0, int r1) { launch_resid(ctx, rn, lv.e, r0, r1, cu); }, {lv.rr});
     {
-        launch_xfer(ctx, rn.restrict_args);
+        XferArgs ra = rn.restrict_args;
+        run_rows(ctx, st, 0, ra.nrows,
+                 [&](int r0, int r1) {
+                     ra.row0 = r0;
+                     ra.row1 = r1;
+                     launch_xfer(ctx, ra, cu);
+                 },
+                 {ra.y});
     }
     amg_cycle(h, k + 1, isnsp, wcycle, false);                                   // :29
     // MG_Wcycle.m:30 -- the second correction; on the coarsest level it repeats the
@@ -322,7 +371,13 @@ void amg_cycle(ipd_amg* h, int k, int isnsp, bool wcycle, bool keep_e) {
         XferArgs pa = rn.prolong_args;                                           // :31
         pa.x = h->L[k + 1].e;
         pa.y = lv.e;
-        launch_xfer(ctx, pa);
+        run_rows(ctx, st, 0, pa.nrows,
+                 [&](int r0, int r1) {
+                     pa.row0 = r0;
+                     pa.row1 = r1;
+                     launch_xfer(ctx, pa, cu);
+                 },
+                 {pa.y});
     }
     for (int s = 0; s < nu; ++s) launch_sweep(h, st, k, isnsp, true);           // :33-41
 }
@@ -337,12 +392,18 @@ static void launch_top(ipd_amg* h, CycleState* st, const double* b, const double
     a.x = x;
     a.e = e;
     a.xnew = xnew;
-    a.nrm_part = st->nrm_part;
     a.staged = rn.staged;
     const size_t dyn = a.staged ? sizeof(double) * (size_t)rn.dev.N : 0;
-    IPD_LAUNCH_SP(k_top, a.staged, rn.dev.S > 0, rn.dev.G, dyn, a);
-    hipLaunchKernelGGL(k_conv, dim3(1), dim3(BT), 0, ctx->stream, (const double*)st->nrm_part,
-                       rn.dev.G, st->hist, first ? 1 : 0);
+    run_rows(ctx, st, 0, rn.dev.N,
+             [&](int r0, int r1) {
+                 a.row0 = r0;
+                 a.row1 = r1;
+                 const int grid = pick_blocks(r1 - r0, rn.dev.L, st->num_cu);
+                 IPD_LAUNCH_SP(k_top, a.staged, rn.dev.S > 0, grid, dyn, a);
+             },
+             {rn.dev.r, xnew});
+    hipLaunchKernelGGL(k_conv, dim3(1), dim3(BT), 0, ctx->stream, (const double*)rn.dev.r, rn.dev.N,
+                       st->hist, first ? 1 : 0);
     IPD_KERNEL_CHECK();
 }
 
@@ -657,5 +718,63 @@ extern "C" int ipd_amg_bench_sweeps(ipd_amg* h, int k, int reps, double* total_m
         *total_ms = ms;
         if (launches_per_sweep) *launches_per_sweep = lv.nf > 0 ? 2 : 1;
         if (bytes_per_sweep) *bytes_per_sweep = spmv_bytes(lv.A) + 6 * 8.0 * lv.A.nr;
+    });
+}
+
+// Row-block sharded loop body (eager launches; RCCL calls are not graph-captured).
+extern "C" int ipd_amg_bench_cycles_sharded(ipd_amg* h, const double* b_dev, double* x_dev,
+                                            int cycles, double* total_ms,
+                                            double* bytes_per_cycle) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && b_dev && x_dev && cycles > 0 && total_ms, IPD_E_ARG, "bad argument");
+        ipd_ctx* ctx = h->ctx;
+        CallScope scope(ctx);
+        CycleState* st = state_of(h);
+        IPD_REQUIRE(st, IPD_E_ARG, "hierarchy has no cycle state");
+        const char* emu = std::getenv("IPD_SHARD_EMULATE");
+        const int emu_ranks = emu ? std::atoi(emu) : 0;
+        struct Restore {
+            CycleState* st;
+            ~Restore() {
+                st->shard_ranks = 1;
+                st->shard_rank = 0;
+                st->shard_emulate = false;
+            }
+        } restore{st};
+        if (emu_ranks > 1) {
+            st->shard_ranks = emu_ranks;
+            st->shard_emulate = true;
+        } else {
+            st->shard_ranks = comm_size(ctx);
+            st->shard_rank = comm_rank(ctx);
+            IPD_REQUIRE(st->shard_ranks == 1 || ctx->comm, IPD_E_COMM, "call ipd_comm_init first");
+        }
+        const int N = h->L[1].A.nr;
+        IPD_HIP(hipMemcpyAsync(h->x, x_dev, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+        launch_top(h, st, b_dev, h->x, nullptr, st->x2, true);
+        IPD_HIP(hipMemcpyAsync(h->x, st->x2, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+        double* xs[2] = {h->x, st->x2};
+        hipEvent_t ev0, ev1;
+        IPD_HIP(hipEventCreate(&ev0));
+        IPD_HIP(hipEventCreate(&ev1));
+        IPD_HIP(hipEventRecord(ev0, ctx->stream));
+        int v = 0;
+        for (int c = 0; c < cycles; ++c) {
+            enqueue_loop_body(h, st, b_dev, xs[v], xs[v ^ 1]);
+            v ^= 1;
+        }
+        IPD_HIP(hipEventRecord(ev1, ctx->stream));
+        IPD_HIP(hipEventSynchronize(ev1));
+        float ms = 0.f;
+        IPD_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        IPD_HIP(hipEventDestroy(ev0));
+        IPD_HIP(hipEventDestroy(ev1));
+        IPD_HIP(hipMemcpyAsync(x_dev, xs[v], sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+        ctx->sync();
+        *total_ms = ms;
+        if (bytes_per_cycle) *bytes_per_cycle = cycle_bytes(h);
     });
 }

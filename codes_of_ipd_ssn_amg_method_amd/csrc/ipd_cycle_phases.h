@@ -244,7 +244,7 @@ struct SmoothArgs {
 };
 
 template <bool STAGED, bool PAD>
-__device__ __forceinline__ void phase_smooth(const SmoothArgs& a, int b, PhaseLds* lds,
+__device__ __forceinline__ void phase_smooth(const SmoothArgs& a, int b, int G, PhaseLds* lds,
                                              double* xs) {
     const LevelDev& lv = a.lv;
     const int tid = threadIdx.x;
@@ -252,7 +252,7 @@ __device__ __forceinline__ void phase_smooth(const SmoothArgs& a, int b, PhaseLd
     const int g = tid / L, gl = tid - g * L;
     const bool uni = L >= 64;
     const int nrows = a.row1 - a.row0;
-    const int niter = (nrows + lv.G * gpb - 1) / (lv.G * gpb);
+    const int niter = (nrows + G * gpb - 1) / (G * gpb);
     const double* __restrict__ eold = a.eold;
     const double* __restrict__ win = a.win;
     const int u0 = a.u0, u1 = a.u1;
@@ -305,7 +305,7 @@ __device__ __forceinline__ void phase_smooth(const SmoothArgs& a, int b, PhaseLd
     bool need_c = nsp;
     for (int it = 0; it < niter; ++it) {
         if (it > 0) {
-            row = uniform_if(a.row0 + (it * lv.G + b) * gpb + g, uni);
+            row = uniform_if(a.row0 + (it * G + b) * gpb + g, uni);
             valid = row < a.row1;
             owner = valid && gl == 0;
             row_open<PAD>(lv, row, valid && !skip, owner && !skip, gl, L, rc, bt);
@@ -342,16 +342,17 @@ __device__ __forceinline__ void phase_smooth(const SmoothArgs& a, int b, PhaseLd
 // ---------------------------------------------------------------------------
 template <bool STAGED, bool PAD>
 __device__ __forceinline__ void phase_resid(const LevelDev& lv, const double* __restrict__ e,
-                                            int b, PhaseLds* lds, double* xs) {
+                                            int row0, int row1, int b, int G, PhaseLds* lds,
+                                            double* xs) {
     const int tid = threadIdx.x;
     const int L = lv.L, gpb = BT / L;
     const int g = tid / L, gl = tid - g * L;
     const bool uni = L >= 64;
-    const int niter = (lv.N + lv.G * gpb - 1) / (lv.G * gpb);
+    const int niter = (row1 - row0 + G * gpb - 1) / (G * gpb);
     auto xglobal = [&](int j) { return e[j]; };
     auto xlds = [&](int j) { return xs[j]; };
-    int row = uniform_if(b * gpb + g, uni);
-    bool valid = row < lv.N;
+    int row = uniform_if(row0 + b * gpb + g, uni);
+    bool valid = row < row1;
     bool owner = valid && gl == 0;
     RowCursor rc;
     RowBatch bt;
@@ -367,8 +368,8 @@ __device__ __forceinline__ void phase_resid(const LevelDev& lv, const double* __
     }
     for (int it = 0; it < niter; ++it) {
         if (it > 0) {
-            row = uniform_if((it * lv.G + b) * gpb + g, uni);
-            valid = row < lv.N;
+            row = uniform_if(row0 + (it * G + b) * gpb + g, uni);
+            valid = row < row1;
             owner = valid && gl == 0;
             row_open<PAD>(lv, row, valid, owner, gl, L, rc, bt);
             if (owner) {
@@ -392,6 +393,7 @@ __device__ __forceinline__ void phase_resid(const LevelDev& lv, const double* __
 // ---------------------------------------------------------------------------
 struct XferArgs {
     int nrows, ncols, L, G;
+    int row0, row1;  // rows produced by this launch (a rank's slice when sharded)
     const int* rp;
     const int* ci;
     const double* va;
@@ -402,12 +404,13 @@ struct XferArgs {
 };
 
 template <bool STAGED>
-__device__ __forceinline__ void phase_xfer(const XferArgs& a, int b, PhaseLds* lds, double* xs) {
+__device__ __forceinline__ void phase_xfer(const XferArgs& a, int b, int G, PhaseLds* lds,
+                                           double* xs) {
     const int tid = threadIdx.x;
     const int L = a.L, gpb = BT / L;
     const int g = tid / L, gl = tid - g * L;
     const bool uni = L >= 64;
-    const int niter = (a.nrows + a.G * gpb - 1) / (a.G * gpb);
+    const int niter = (a.row1 - a.row0 + G * gpb - 1) / (G * gpb);
     const double* __restrict__ x = a.x;
     auto xglobal = [&](int j) { return x[j]; };
     auto xlds = [&](int j) { return xs[j]; };
@@ -415,8 +418,8 @@ __device__ __forceinline__ void phase_xfer(const XferArgs& a, int b, PhaseLds* l
     lv.rp = a.rp;
     lv.ci = a.ci;
     lv.va = a.va;
-    int row = uniform_if(b * gpb + g, uni);
-    bool valid = row < a.nrows;
+    int row = uniform_if(a.row0 + b * gpb + g, uni);
+    bool valid = row < a.row1;
     bool owner = valid && gl == 0;
     RowCursor rc;
     RowBatch bt;
@@ -429,8 +432,8 @@ __device__ __forceinline__ void phase_xfer(const XferArgs& a, int b, PhaseLds* l
     }
     for (int it = 0; it < niter; ++it) {
         if (it > 0) {
-            row = uniform_if((it * a.G + b) * gpb + g, uni);
-            valid = row < a.nrows;
+            row = uniform_if(a.row0 + (it * G + b) * gpb + g, uni);
+            valid = row < a.row1;
             owner = valid && gl == 0;
             row_open<false>(lv, row, valid, owner, gl, L, rc, bt);
             y0 = (owner && a.add) ? a.y[row] : 0.0;
@@ -444,7 +447,7 @@ __device__ __forceinline__ void phase_xfer(const XferArgs& a, int b, PhaseLds* l
 }
 
 // ---------------------------------------------------------------------------
-// top of the Class_AMG loop: x_new = x + e ; r = b - A x_new ; partials of r'r
+// top of the Class_AMG loop: x_new = x + e ; r = b - A x_new  (k_conv then forms ||r||)
 // ---------------------------------------------------------------------------
 struct TopArgs {
     LevelDev lv;
@@ -452,24 +455,25 @@ struct TopArgs {
     const double* x;
     const double* e;   // NULL -> x_new = x
     double* xnew;
-    double* nrm_part;  // G partial sums of r_i^2
+    int row0, row1;  // rows produced by this launch
     int staged;
 };
 
 template <bool STAGED, bool PAD>
-__device__ __forceinline__ void phase_top(const TopArgs& a, int b, PhaseLds* lds, double* xs) {
+__device__ __forceinline__ void phase_top(const TopArgs& a, int b, int G, PhaseLds* lds,
+                                          double* xs) {
     const LevelDev& lv = a.lv;
     const int tid = threadIdx.x;
     const int L = lv.L, gpb = BT / L;
     const int g = tid / L, gl = tid - g * L;
     const bool uni = L >= 64;
-    const int niter = (lv.N + lv.G * gpb - 1) / (lv.G * gpb);
+    const int niter = (a.row1 - a.row0 + G * gpb - 1) / (G * gpb);
     const double* __restrict__ x = a.x;
     const double* __restrict__ e = a.e;
     auto xglobal = [&](int j) { return e ? x[j] + e[j] : x[j]; };
     auto xlds = [&](int j) { return xs[j]; };
-    int row = uniform_if(b * gpb + g, uni);
-    bool valid = row < lv.N;
+    int row = uniform_if(a.row0 + b * gpb + g, uni);
+    bool valid = row < a.row1;
     bool owner = valid && gl == 0;
     RowCursor rc;
     RowBatch bt;
@@ -483,11 +487,10 @@ __device__ __forceinline__ void phase_top(const TopArgs& a, int b, PhaseLds* lds
         vec_pass(lv.N, [&](int j) { return xglobal(j); }, [&](int j, double v) { xs[j] = v; });
         __syncthreads();
     }
-    double p2 = 0.0;
     for (int it = 0; it < niter; ++it) {
         if (it > 0) {
-            row = uniform_if((it * lv.G + b) * gpb + g, uni);
-            valid = row < lv.N;
+            row = uniform_if(a.row0 + (it * G + b) * gpb + g, uni);
+            valid = row < a.row1;
             owner = valid && gl == 0;
             row_open<PAD>(lv, row, valid, owner, gl, L, rc, bt);
             if (owner) {
@@ -504,8 +507,6 @@ __device__ __forceinline__ void phase_top(const TopArgs& a, int b, PhaseLds* lds
             const double ri = bv - s;
             lv.r[row] = ri;
             a.xnew[row] = xo;
-            p2 += ri * ri;
         }
     }
-    block_totals_to(p2, a.nrm_part + b, 0.0, nullptr, lds);
 }

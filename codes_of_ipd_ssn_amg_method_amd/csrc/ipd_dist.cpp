@@ -1,18 +1,80 @@
-// Multi-GPU row-block sharding over RCCL (placeholder until the sharded cycle lands).
+// Multi-GPU row-block sharding: the RCCL communicator (one rank per GPU over xGMI)
+// and the in-place all-gather that re-assembles a vector whose row blocks were
+// produced by different ranks.  The control plane (unique-id
+// broadcast, barriers) is the caller's: bench.py uses torch.distributed for it.
+#include <rccl/rccl.h>
+
 #include "ipd_amg_internal.h"
 
-void ipd_comm_cleanup(ipd_ctx*) {}
+struct RcclState {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+};
 
-extern "C" int ipd_comm_get_unique_id(uint8_t*) {
-    ipd_set_error("RCCL sharding not built yet");
-    return IPD_E_UNSUPPORTED;
+#define IPD_NCCL(expr)                                                                    \
+    do {                                                                                  \
+        ncclResult_t r__ = (expr);                                                        \
+        if (r__ != ncclSuccess)                                                           \
+            throw IpdError(IPD_E_COMM, std::string(#expr) + ": " + ncclGetErrorString(r__)); \
+    } while (0)
+
+void ipd_comm_cleanup(ipd_ctx* ctx) {
+    if (ctx && ctx->comm) {
+        if (ctx->comm->comm) (void)ncclCommDestroy(ctx->comm->comm);
+        delete ctx->comm;
+        ctx->comm = nullptr;
+    }
 }
-extern "C" int ipd_comm_init(ipd_ctx*, const uint8_t*, int, int) {
-    ipd_set_error("RCCL sharding not built yet");
-    return IPD_E_UNSUPPORTED;
+
+int comm_rank(const ipd_ctx* ctx) { return ctx->comm ? ctx->comm->rank : 0; }
+int comm_size(const ipd_ctx* ctx) { return ctx->comm ? ctx->comm->nranks : 1; }
+
+// Every rank wrote base[rank*count .. (rank+1)*count) of each vector; afterwards every
+// rank holds all nranks*count entries.  The vectors of one call travel as ONE grouped
+// RCCL launch (messages are a few KiB: the cost is latency, not bandwidth).
+void comm_allgather_inplace(ipd_ctx* ctx, double* const* bases, int nvec, int count) {
+    RcclState* c = ctx->comm;
+    IPD_REQUIRE(c && c->comm, IPD_E_COMM, "communicator not initialised (ipd_comm_init)");
+    if (c->nranks == 1 || count == 0 || nvec == 0) return;
+    IPD_NCCL(ncclGroupStart());
+    for (int v = 0; v < nvec; ++v)
+        IPD_NCCL(ncclAllGather(bases[v] + (size_t)c->rank * count, bases[v], (size_t)count,
+                               ncclDouble, c->comm, ctx->stream));
+    IPD_NCCL(ncclGroupEnd());
 }
-extern "C" int ipd_comm_finalize(ipd_ctx*) { return IPD_OK; }
-extern "C" int ipd_amg_bench_cycles_sharded(ipd_amg*, const double*, double*, int, double*, double*) {
-    ipd_set_error("RCCL sharding not built yet");
-    return IPD_E_UNSUPPORTED;
+
+extern "C" int ipd_comm_get_unique_id(uint8_t id[IPD_COMM_ID_BYTES]) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(id, IPD_E_ARG, "id is NULL");
+        static_assert(sizeof(ncclUniqueId) == IPD_COMM_ID_BYTES, "unique id size");
+        ncclUniqueId u;
+        IPD_NCCL(ncclGetUniqueId(&u));
+        std::memcpy(id, &u, sizeof(u));
+    });
+}
+
+extern "C" int ipd_comm_init(ipd_ctx* ctx, const uint8_t id[IPD_COMM_ID_BYTES], int rank,
+                             int nranks) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && id && nranks >= 1 && rank >= 0 && rank < nranks, IPD_E_ARG,
+                    "bad communicator arguments");
+        ctx->set_device();
+        ipd_comm_cleanup(ctx);
+        std::unique_ptr<RcclState> st(new RcclState());
+        st->rank = rank;
+        st->nranks = nranks;
+        ncclUniqueId u;
+        std::memcpy(&u, id, sizeof(u));
+        IPD_NCCL(ncclCommInitRank(&st->comm, nranks, u, rank));
+        ctx->comm = st.release();
+    });
+}
+
+extern "C" int ipd_comm_finalize(ipd_ctx* ctx) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx, IPD_E_ARG, "ctx is NULL");
+        ctx->set_device();
+        ctx->sync();
+        ipd_comm_cleanup(ctx);
+    });
 }

@@ -175,7 +175,11 @@ struct CallScope {
     }
 };
 
-void ipd_comm_cleanup(ipd_ctx* ctx);  // ipd_dist.cpp
+// ipd_dist.cpp: RCCL communicator of the context (one rank per GPU)
+void ipd_comm_cleanup(ipd_ctx* ctx);
+int comm_rank(const ipd_ctx* ctx);
+int comm_size(const ipd_ctx* ctx);
+void comm_allgather_inplace(ipd_ctx* ctx, double* const* bases, int nvec, int count);
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -1,0 +1,84 @@
+"""Row-block sharding of the cycle on ONE GPU:
+ * emulate mode plays G owners back to back on the shared vectors, so the slicing
+   logic (ranges, grids, the union of the slices) is exercised for G = 2, 4, 8 and
+   must reproduce the unsharded iterate BIT FOR BIT;
+ * a real RCCL communicator of size 1 exercises the communicator plumbing."""
+import os
+from ctypes import byref, c_double, c_int
+
+import numpy as np
+import pytest
+
+from oracle import ipd_oracle as O
+from tests import problems as PR
+from tests.test_gpu_setup import newton_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ipd():
+    import codes_of_ipd_ssn_amg_method_amd as m
+    return m
+
+
+def _run(lib, fn, h, f, x0, cycles):
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    db = _lib.DeviceBuffer.from_array(f)
+    dx = _lib.DeviceBuffer.from_array(x0)
+    ms, bpc = c_double(), c_double()
+    _lib.check(fn(h.handle, db.ptr, dx.ptr, c_int(cycles), byref(ms), byref(bpc)))
+    x = dx.to_array(np.float64, len(x0))
+    db.free()
+    dx.free()
+    return x
+
+
+@pytest.mark.parametrize("mask,cycle", [("dense", "v"), ("tree", "v"), ("tree", "w")])
+def test_sharded_emulation_is_bit_exact(ipd, mask, cycle):
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    m = n = 512
+    s = PR.mask_bernoulli(m, n, 1.0) if mask == "dense" else PR.mask_tree(m, n, seed=3)
+    Ae, pd = newton_matrix(m, n, s)
+    f = np.concatenate([pd["q"], -pd["p"]]) * pd["z"]
+    x0 = np.random.RandomState(4).random_sample(m + n) * 1e-4
+    o = O.amg_options_class1(cycle)
+    o.update(fnode=n, isnsp=1)
+    h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+    ref = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles, h, f, x0, 3)
+    os.environ["IPD_NO_GRAPH"] = "1"
+    eager = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles, h, f, x0, 3)
+    os.environ.pop("IPD_NO_GRAPH")
+    assert np.array_equal(ref, eager)           # graph replay == eager launches
+    for G in (2, 4, 8):
+        os.environ["IPD_SHARD_EMULATE"] = str(G)
+        try:
+            got = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles_sharded, h, f, x0, 3)
+        finally:
+            os.environ.pop("IPD_SHARD_EMULATE")
+        assert np.array_equal(got, ref), G
+    A = Ae
+    assert np.linalg.norm(A @ ref - f) < 1e-3 * np.linalg.norm(A @ x0 - f)
+    h.close()
+
+
+def test_rccl_communicator_of_one(ipd):
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    m = n = 256
+    Ae, pd = newton_matrix(m, n, PR.mask_tree(m, n, seed=5))
+    f = np.concatenate([pd["q"], -pd["p"]]) * pd["z"]
+    x0 = np.zeros(m + n)
+    o = O.amg_options_class1("v")
+    o.update(fnode=n, isnsp=1)
+    h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+    ref = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles, h, f, x0, 2)
+    ident = np.zeros(_lib.COMM_ID_BYTES, np.uint8)
+    _lib.check(_lib.lib.ipd_comm_get_unique_id(_lib.bptr(ident)))
+    ctx = _lib.get_ctx()
+    _lib.check(_lib.lib.ipd_comm_init(ctx.handle, _lib.bptr(ident), c_int(0), c_int(1)))
+    try:
+        got = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles_sharded, h, f, x0, 2)
+    finally:
+        _lib.check(_lib.lib.ipd_comm_finalize(ctx.handle))
+    assert np.array_equal(got, ref)
+    h.close()
