@@ -61,7 +61,9 @@ def _load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
             "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
-    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    # RTLD_LOCAL on purpose: torch bundles ROCm libraries with the same SONAMEs; exporting ours
+    # globally and importing torch afterwards aborts at interpreter exit (double free)
+    return C.CDLL(LIB_PATH)
 
 
 lib = _load()
