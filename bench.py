@@ -37,8 +37,8 @@ BK1, TK = 0.0038, 0.0255
 def build_mask(m, n, kind, rho, seed=2):
     if kind == "bernoulli":
         return (np.random.RandomState(seed).random_sample(m * n) < rho).astype(np.uint8)
-    from tests.problems import mask_tree
-    return mask_tree(m, n, seed=seed)
+    from tests.problems import mask_hub, mask_tree
+    return mask_hub(m, n, seed=seed) if kind == "hub" else mask_tree(m, n, seed=seed)
 
 
 def build_newton_system(ipd, m, n, s):
@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n1", type=int, default=1024)
     ap.add_argument("--rho", type=float, default=1.0)
-    ap.add_argument("--mask", default="bernoulli", choices=["bernoulli", "tree"])
+    ap.add_argument("--mask", default="bernoulli", choices=["bernoulli", "tree", "hub"])
     ap.add_argument("--cycle", default="v", choices=["v", "w"])
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

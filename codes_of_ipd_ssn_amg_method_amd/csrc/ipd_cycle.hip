@@ -23,103 +23,7 @@
 
 #include <cmath>
 
-static constexpr int BT = 1024;  // threads per block of every phase kernel
-
-// ---------------------------------------------------------------------------
-// device-side level descriptor
-// ---------------------------------------------------------------------------
-struct LevelDev {
-    int N, nf, L, G;  // rows, F-block size (0 = Jacobi), lanes/row, blocks per launch
-    // CSR (always present)
-    const int* rp;
-    const int* ci;
-    const double* va;
-    // padded copy of the off-diagonal part (S > 0): row r occupies [r*S, (r+1)*S),
-    // 16-bit columns, padding entries have value 0; the diagonal lives in `diag`
-    int S;
-    const unsigned short* pci;
-    const double* pva;
-    const double* diag;
-    const double* dinv;
-    const double* Axi;
-    const double* xx;
-    double* r;
-    double* rr;
-};
-
-// ---------------------------------------------------------------------------
-// reductions
-// ---------------------------------------------------------------------------
-// Cross-lane sums use DPP (ALU-rate row operations) instead of __shfl_xor: hipcc lowers
-// a double shuffle to two ds_bpermute round trips through the LDS pipe (~150 cycles a
-// step, 6 dependent steps per wave sum, measured 0.4 us), which dominated the
-// reduction phase of these few-microsecond kernels.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_get(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-// after this every lane holds the sum of its aligned 16-lane row
-__device__ __forceinline__ double row16_sum(double v) {
-    v += dpp_get<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
-    v += dpp_get<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
-    v += dpp_get<0x141, 0xf>(v);  // row_half_mirror
-    v += dpp_get<0x140, 0xf>(v);  // row_mirror
-    return v;
-}
-
-// sum over the 64 lanes of the wave, result in every lane
-__device__ __forceinline__ double wave_sum(double v) {
-    v = row16_sum(v);
-    v += dpp_get<0x142, 0xa>(v);  // row_bcast15 -> rows 1,3
-    v += dpp_get<0x143, 0xc>(v);  // row_bcast31 -> rows 2,3 ; lane 63 holds the total
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-
-// sum over aligned groups of L lanes, L in {4,8,16,32,64}; result in every lane of the group
-__device__ __forceinline__ double subwave_sum(double v, int L) {
-    v += dpp_get<0xB1, 0xf>(v);
-    v += dpp_get<0x4E, 0xf>(v);
-    if (L >= 8) v += dpp_get<0x141, 0xf>(v);
-    if (L >= 16) v += dpp_get<0x140, 0xf>(v);
-    if (L >= 32) v += __shfl_xor(v, 16);
-    if (L >= 64) v += __shfl_xor(v, 32);
-    return v;
-}
-
-// sum over the whole 1024-thread block, result in every thread
-__device__ __forceinline__ double block_sum(double v, double* red /*16 doubles of LDS*/) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < BT / 64; ++k) s += red[k];
-    return s;
-}
-
-// sum within aligned groups of L threads (L = 4..1024, power of two); every
-// thread of the block must call it.  Result valid in the group's first thread.
-__device__ __forceinline__ double group_sum(double v, int L, double* red /*16 doubles*/) {
-    if (L <= 64) return subwave_sum(v, L);
-    v = wave_sum(v);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[w] = v;
-    __syncthreads();
-    const int wpg = L >> 6;  // waves per group
-    const int g0 = (threadIdx.x / L) * wpg;
-    double s = 0.0;
-    for (int k = 0; k < wpg; ++k) s += red[g0 + k];
-    return s;
-}
-
+#include "ipd_cycle_dev.h"
 #include "ipd_cycle_phases.h"
 
 // Dynamic LDS = the staged gather vector (N doubles) when STAGED, else nothing.
@@ -198,21 +102,30 @@ __global__ __launch_bounds__(256) void k_pad_build(int N, int S, const int* __re
 
 // hist[0] = res0 (set on the first call), hist[1] = res, hist[2] = previous res,
 // hist[3] = rel_res, hist[4] = rhok                        Class_AMG.m:89,103-105
-__global__ __launch_bounds__(BT) void k_conv(const double* __restrict__ r, int n, double* hist,
-                                             int first) {
-    __shared__ double red[16];
+struct ConvArgs {
+    const double* r;
+    int n;
+    double* hist;
+    int first;
+};
+
+__device__ __forceinline__ void conv_block(const ConvArgs& a, double* red) {
     double s = 0.0;
-    for (int k0 = threadIdx.x; k0 < n; k0 += 4 * BT) {  // 4 independent loads in flight
+    for (int k0 = threadIdx.x; k0 < a.n; k0 += 4 * BT) {  // 4 independent loads in flight
         double v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (k0 + u * BT < n) ? r[k0 + u * BT] : 0.0;
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * BT;
+            v[u] = a.r[k < a.n ? k : a.n - 1];
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s += v[u] * v[u];
+        for (int u = 0; u < 4; ++u) s += (k0 + u * BT < a.n) ? v[u] * v[u] : 0.0;
     }
     const double tot = block_sum(s, red);
     if (threadIdx.x == 0) {
+        double* hist = a.hist;
         const double res = sqrt(tot);
-        if (first) {
+        if (a.first) {
             hist[0] = res;
             hist[1] = res;
             hist[2] = res;
@@ -226,6 +139,11 @@ __global__ __launch_bounds__(BT) void k_conv(const double* __restrict__ r, int n
             hist[4] = res / prev;
         }
     }
+}
+
+__global__ __launch_bounds__(BT) void k_conv(ConvArgs a) {
+    __shared__ double red[16];
+    conv_block(a, red);
 }
 
 // sum of a vector into one slot (entry point of ipd_amg_vcycle / wcycle)
@@ -351,13 +269,95 @@ __global__ __launch_bounds__(BT) void k_pcg(PcgArgs a) {
     pcg_block(a, red);
 }
 
+// ---------------------------------------------------------------------------
+// fused single-workgroup program
+// ---------------------------------------------------------------------------
+// Phases whose row range fits one workgroup (a few thousand nonzeros) cost far more as
+// launches (2.3 us floor + 3-10 us of latency each, and only 1-8 CUs busy) than as
+// work.  The host therefore strings consecutive small phases -- e.g. the ten Gauss-
+// Seidel half sweeps, the residual and the restriction of a small fine level, or
+// restriction + coarsest PCG + prolongation -- into ONE launch of this kernel: one
+// workgroup interprets the descriptor list, with a workgroup barrier between phases.
+// Descriptors travel as kernel arguments (no upload, captured by value in graphs).
+struct ResidDesc {
+    LevelDev lv;
+    const double* e;
+    int row0, row1;
+};
+enum : int { PH_SMOOTH = 1, PH_RESID, PH_XFER, PH_TOP, PH_PCG, PH_CONV };
+struct PhaseDesc {
+    int type;
+    int pad_;
+    union U {
+        SmoothArgs s;
+        ResidDesc r;
+        XferArgs x;
+        TopArgs t;
+        PcgArgs p;
+        ConvArgs c;
+    } u;
+};
+static constexpr int FUSED_MAX = 16;
+struct FusedProg {
+    int n;
+    int pad_;
+    PhaseDesc d[FUSED_MAX];
+};
+static_assert(sizeof(FusedProg) <= 3900, "fused program must fit the 4 KiB kernel-argument segment");
+
+__global__ __launch_bounds__(BT) void k_fused(FusedProg prog) {
+    __shared__ PhaseLds lds;
+    __shared__ double red[16];
+    extern __shared__ __attribute__((aligned(16))) double xs_dyn[];
+    for (int i = 0; i < prog.n; ++i) {
+        const PhaseDesc& d = prog.d[i];
+        switch (d.type) {
+            case PH_SMOOTH:
+                if (d.u.s.lv.S > 0)
+                    phase_smooth<true, true>(d.u.s, 0, 1, &lds, xs_dyn);
+                else
+                    phase_smooth<true, false>(d.u.s, 0, 1, &lds, xs_dyn);
+                break;
+            case PH_RESID:
+                if (d.u.r.lv.S > 0)
+                    phase_resid<true, true>(d.u.r.lv, d.u.r.e, d.u.r.row0, d.u.r.row1, 0, 1, &lds,
+                                            xs_dyn);
+                else
+                    phase_resid<true, false>(d.u.r.lv, d.u.r.e, d.u.r.row0, d.u.r.row1, 0, 1, &lds,
+                                             xs_dyn);
+                break;
+            case PH_XFER:
+                phase_xfer<true>(d.u.x, 0, 1, &lds, xs_dyn);
+                break;
+            case PH_TOP:
+                if (d.u.t.lv.S > 0)
+                    phase_top<true, true>(d.u.t, 0, 1, &lds, xs_dyn);
+                else
+                    phase_top<true, false>(d.u.t, 0, 1, &lds, xs_dyn);
+                break;
+            case PH_PCG:
+                pcg_block(d.u.p, red);
+                break;
+            case PH_CONV:
+                conv_block(d.u.c, red);
+                break;
+            default:
+                break;
+        }
+        __syncthreads();
+    }
+}
+
 // lanes per row: 3..6 entries per lane (one ROW_U batch), widened while the launch
 // would leave most of the chip idle
 static int pick_lanes(long long nnz, int nrows, int blocks_target) {
-    if (nrows <= 0) return 4;
+    if (nrows <= 0) return 1;
     const double avg = (double)nnz / (double)nrows;
-    int L = 4;
+    int L = 1;  // short rows: one lane walks the whole row in a single ROW_U batch
     while (L < BT && (double)L * 6.0 < avg) L <<= 1;
+    // widen while most of the chip would idle (tools/ubench_small.hip: a 1024-row launch of
+    // short rows costs the same 6.5 us on 1, 4 or 16 workgroups, so spreading is free and
+    // keeps one CU's load-issue rate from becoming the limit)
     while (L < BT && (long long)nrows * L < (long long)blocks_target * BT / 2 &&
            (double)L * 2.0 <= avg)
         L <<= 1;

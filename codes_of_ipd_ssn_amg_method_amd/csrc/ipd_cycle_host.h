@@ -25,6 +25,11 @@ struct CycleState {
     bool shard_emulate = false;
     int shard_min_rows = 256;
     int num_cu = 256;
+    // fused single-workgroup program under construction (flushed before any big launch)
+    FusedProg pending;
+    size_t pending_lds = 0;
+    bool fuse_enabled = true;
+    CycleState() { pending.n = 0; }
     double* x2 = nullptr;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};  // captured Class_AMG loop bodies (x->x2, x2->x)
     const double* gb = nullptr;                    // right-hand side the graphs were captured for
@@ -207,6 +212,10 @@ void amg_prepare_levels(ipd_amg* h) {
         st->run[(size_t)h->J].pcg = a;
     }
     st->num_cu = cu;
+    {
+        const char* nf = std::getenv("IPD_NO_FUSE");
+        st->fuse_enabled = !(nf && nf[0] == '1');
+    }
     st->hist = ar.alloc<double>(8);
     st->x2 = ar.alloc<double>((size_t)h->L[1].A.nr);
     h->x = ar.alloc<double>((size_t)h->L[1].A.nr);
@@ -237,12 +246,40 @@ void amg_prepare_levels(ipd_amg* h) {
         IPD_KERNEL_CHECK();                                                                       \
     } while (0)
 
+// ---- fused-program emitter -----------------------------------------------------------
+// A phase is "small" when one workgroup covers its rows in ONE pass and its matrix slice
+// is a few thousand entries: then it costs 1-3 us inside a fused program against >= 5 us
+// as a launch of its own.  Larger phases lose inside a single workgroup (one CU issues
+// ~60 B/clk of loads: tools/ubench_small.hip) and stay separate launches.
+static bool phase_is_small(const CycleState* st, int rows, int L, double nnz_est, int stage_len) {
+    return st->fuse_enabled && stage_len <= STAGE_MAX && (long long)rows * L <= (long long)BT &&
+           nnz_est <= 6000.0;
+}
+
+static void flush_fused(ipd_ctx* ctx, CycleState* st) {
+    if (st->pending.n == 0) return;
+    hipLaunchKernelGGL(k_fused, dim3(1), dim3(BT), st->pending_lds, ctx->stream, st->pending);
+    IPD_KERNEL_CHECK();
+    st->pending.n = 0;
+    st->pending_lds = 0;
+}
+
+static PhaseDesc& push_phase(ipd_ctx* ctx, CycleState* st, int type, int stage_len) {
+    if (st->pending.n == FUSED_MAX) flush_fused(ctx, st);
+    PhaseDesc& d = st->pending.d[st->pending.n++];
+    d.type = type;
+    d.pad_ = 0;
+    st->pending_lds = std::max(st->pending_lds, sizeof(double) * (size_t)stage_len);
+    return d;
+}
+
 // Runs `launch(r0, r1)` over the row range [lo, hi) of a level.  Unsharded: one call.
 // Sharded: this rank's slice only, followed by one grouped RCCL all-gather of the
 // vectors the launch produced (each rank wrote its own slice of every one of them).
 template <class F>
 static void run_rows(ipd_ctx* ctx, CycleState* st, int lo, int hi, F launch,
                      std::initializer_list<double*> produced) {
+    flush_fused(ctx, st);  // big launch: everything queued before it must run first
     const int G = st->shard_ranks;
     const int rows = hi - lo;
     if (G <= 1 || rows % G != 0 || rows < st->shard_min_rows) {  // replicated level
@@ -300,12 +337,34 @@ static void launch_sweep(ipd_amg* h, CycleState* st, int k, int isnsp, bool post
     a.staged = rn.staged;
     a.eold_zero = rn.e_zero ? 1 : 0;
     const int cu = st->num_cu;
+    const int rows_launch = lv.nf > 0 ? std::max(lv.nf, lv.N - lv.nf) : lv.N;
+    const bool small = a.staged && phase_is_small(st, rows_launch, a.lv.L,
+                                                  (double)lv.A.nnz * rows_launch / std::max(lv.N, 1),
+                                                  lv.N);
     auto go = [&](int r0, int r1) {
         a.row0 = r0;
         a.row1 = r1;
-        launch_smooth(ctx, a, cu);
+        if (small)
+            push_phase(ctx, st, PH_SMOOTH, lv.N).u.s = a;
+        else
+            launch_smooth(ctx, a, cu);
     };
-    if (lv.nf == 0) {
+    if (small) {  // replicated on every rank, queued into the fused program
+        if (lv.nf == 0) {
+            a.u0 = a.u1 = 0;
+            a.wout = nullptr;
+            go(0, lv.N);
+        } else {
+            const int f0 = post ? lv.nf : 0, f1 = post ? lv.N : lv.nf;
+            const int s0 = post ? 0 : lv.nf, s1 = post ? lv.nf : lv.N;
+            a.u0 = a.u1 = 0;
+            go(f0, f1);
+            a.u0 = f0;
+            a.u1 = f1;
+            a.wout = nullptr;
+            go(s0, s1);
+        }
+    } else if (lv.nf == 0) {
         a.u0 = a.u1 = 0;
         a.wout = nullptr;
         run_rows(ctx, st, 0, lv.N, go, {a.enew});
@@ -338,23 +397,39 @@ void amg_cycle(ipd_amg* h, int k, int isnsp, bool wcycle, bool keep_e) {
         PcgArgs a = rn.pcg;                            // replicated on every rank
         a.rhs = lv.r;
         a.d = lv.e;
-        hipLaunchKernelGGL(k_pcg, dim3(1), dim3(BT), 0, ctx->stream, a);
-        IPD_KERNEL_CHECK();
+        if (st->fuse_enabled) {
+            push_phase(ctx, st, PH_PCG, 0).u.p = a;
+        } else {
+            hipLaunchKernelGGL(k_pcg, dim3(1), dim3(BT), 0, ctx->stream, a);
+            IPD_KERNEL_CHECK();
+        }
         return;
     }
     const int nu = h->opts.smoth;
     if (!keep_e) {
         rn.e_zero = true;
         if (nu == 0) {  // no sweep will overwrite the iterate: materialise the zero
+            flush_fused(ctx, st);
             IPD_HIP(hipMemsetAsync(lv.e, 0, sizeof(double) * (size_t)lv.N, ctx->stream));
             rn.e_zero = false;
         }
     }
     for (int s = 0; s < nu; ++s) launch_sweep(h, st, k, isnsp, false);          // :14-25
-    run_rows(ctx, st, 0, lv.N,                                                   // :27
-             [&](int r0, int r1) { launch_resid(ctx, rn, lv.e, r0, r1, cu); }, {lv.rr});
+    if (rn.staged && phase_is_small(st, lv.N, rn.dev.L, (double)lv.A.nnz, lv.N)) {  // :27
+        ResidDesc& rd = push_phase(ctx, st, PH_RESID, lv.N).u.r;
+        rd.lv = rn.dev;
+        rd.e = lv.e;
+        rd.row0 = 0;
+        rd.row1 = lv.N;
+    } else {
+        run_rows(ctx, st, 0, lv.N,
+                 [&](int r0, int r1) { launch_resid(ctx, rn, lv.e, r0, r1, cu); }, {lv.rr});
+    }
     {
         XferArgs ra = rn.restrict_args;
+        if (ra.staged && phase_is_small(st, ra.nrows, ra.L, (double)h->L[k + 1].Pt.nnz, ra.ncols))
+            push_phase(ctx, st, PH_XFER, ra.ncols).u.x = ra;
+        else
         run_rows(ctx, st, 0, ra.nrows,
                  [&](int r0, int r1) {
                      ra.row0 = r0;
@@ -371,6 +446,9 @@ void amg_cycle(ipd_amg* h, int k, int isnsp, bool wcycle, bool keep_e) {
         XferArgs pa = rn.prolong_args;                                           // :31
         pa.x = h->L[k + 1].e;
         pa.y = lv.e;
+        if (pa.staged && phase_is_small(st, pa.nrows, pa.L, (double)h->L[k + 1].P.nnz, pa.ncols))
+            push_phase(ctx, st, PH_XFER, pa.ncols).u.x = pa;
+        else
         run_rows(ctx, st, 0, pa.nrows,
                  [&](int r0, int r1) {
                      pa.row0 = r0;
@@ -394,17 +472,32 @@ static void launch_top(ipd_amg* h, CycleState* st, const double* b, const double
     a.xnew = xnew;
     a.staged = rn.staged;
     const size_t dyn = a.staged ? sizeof(double) * (size_t)rn.dev.N : 0;
-    run_rows(ctx, st, 0, rn.dev.N,
-             [&](int r0, int r1) {
-                 a.row0 = r0;
-                 a.row1 = r1;
-                 const int grid = pick_blocks(r1 - r0, rn.dev.L, st->num_cu);
-                 IPD_LAUNCH_SP(k_top, a.staged, rn.dev.S > 0, grid, dyn, a);
-             },
-             {rn.dev.r, xnew});
-    hipLaunchKernelGGL(k_conv, dim3(1), dim3(BT), 0, ctx->stream, (const double*)rn.dev.r, rn.dev.N,
-                       st->hist, first ? 1 : 0);
-    IPD_KERNEL_CHECK();
+    if (a.staged && phase_is_small(st, rn.dev.N, rn.dev.L, (double)h->L[1].A.nnz, rn.dev.N)) {
+        a.row0 = 0;
+        a.row1 = rn.dev.N;
+        push_phase(ctx, st, PH_TOP, rn.dev.N).u.t = a;
+    } else {
+        run_rows(ctx, st, 0, rn.dev.N,
+                 [&](int r0, int r1) {
+                     a.row0 = r0;
+                     a.row1 = r1;
+                     const int grid = pick_blocks(r1 - r0, rn.dev.L, st->num_cu);
+                     IPD_LAUNCH_SP(k_top, a.staged, rn.dev.S > 0, grid, dyn, a);
+                 },
+                 {rn.dev.r, xnew});
+    }
+    ConvArgs ca;
+    ca.r = rn.dev.r;
+    ca.n = rn.dev.N;
+    ca.hist = st->hist;
+    ca.first = first ? 1 : 0;
+    if (st->fuse_enabled) {
+        push_phase(ctx, st, PH_CONV, 0).u.c = ca;
+    } else {
+        hipLaunchKernelGGL(k_conv, dim3(1), dim3(BT), 0, ctx->stream, ca);
+        IPD_KERNEL_CHECK();
+    }
+    flush_fused(ctx, st);  // the loop body ends here: nothing stays queued across calls
 }
 
 // one Class_AMG loop body (Class_AMG.m:96-105): x_out = x_in + cycle(b - A x_in)
@@ -522,6 +615,7 @@ static void run_cycle_api(ipd_amg* h, const double* r, int isnsp, int k, const d
         keep = true;
     }
     amg_cycle(h, k, isnsp, wc, keep);
+    flush_fused(ctx, st);
     ctx->fetch(h->L[k].e, e_out, N);
 }
 
@@ -704,11 +798,13 @@ extern "C" int ipd_amg_bench_sweeps(ipd_amg* h, int k, int reps, double* total_m
         fill_f64(ctx, lv.r, 1.0, (size_t)lv.N);
         rn.e_zero = true;
         for (int w = 0; w < 4; ++w) launch_sweep(h, st, k, h->opts.isnsp, false);
+        flush_fused(ctx, st);
         hipEvent_t ev0, ev1;
         IPD_HIP(hipEventCreate(&ev0));
         IPD_HIP(hipEventCreate(&ev1));
         IPD_HIP(hipEventRecord(ev0, ctx->stream));
         for (int s = 0; s < reps; ++s) launch_sweep(h, st, k, h->opts.isnsp, false);
+        flush_fused(ctx, st);
         IPD_HIP(hipEventRecord(ev1, ctx->stream));
         IPD_HIP(hipEventSynchronize(ev1));
         float ms = 0.f;

@@ -34,22 +34,36 @@ struct PhaseLds {
     double out[2 * (BT / 64)];
 };
 
-// One batch of a row: ROW_U (column, value) pairs held by a lane; column -1 = none.
+// One batch of a row: ROW_U (column, value) pairs held by a lane (absent: column 0, value 0).
 struct RowBatch {
     int j[ROW_U];
     double a[ROW_U];
 };
 
+// All loads below are UNCONDITIONAL with clamped addresses: a load under a per-lane
+// condition becomes its own exec-masked basic block, the compiler then waits for it
+// before issuing the next one, and a batch degenerates into one memory round trip
+// per entry (seen in the ISA: s_and_saveexec / global_load / s_waitcnt chains).
+// Entries that do not exist get column 0 and value 0, so they add 0 * x[0].
+
 // CSR: lane `gl` of `L` holds entries t, t+L, ... of [t, e1)
 __device__ __forceinline__ void batch_load_csr(RowBatch& bt, const int* __restrict__ ci,
                                                const double* __restrict__ va, int t, int e1,
                                                int L) {
+    int jj[ROW_U];
+    double aa[ROW_U];
 #pragma unroll
     for (int u = 0; u < ROW_U; ++u) {
         const int tt = t + u * L;
-        const bool ok = tt < e1;
-        bt.j[u] = ok ? ci[tt] : -1;
-        bt.a[u] = ok ? va[tt] : 0.0;
+        const int tc = tt < e1 ? tt : 0;
+        jj[u] = ci[tc];
+        aa[u] = va[tc];
+    }
+#pragma unroll
+    for (int u = 0; u < ROW_U; ++u) {
+        const bool ok = t + u * L < e1;
+        bt.j[u] = ok ? jj[u] : 0;
+        bt.a[u] = ok ? aa[u] : 0.0;
     }
 }
 
@@ -60,7 +74,7 @@ __device__ __forceinline__ void batch_load_pad(RowBatch& bt, const unsigned shor
 #pragma unroll
     for (int u = 0; u < ROW_U / 4; ++u) {
         const int vv = v + u * L;
-        if (vv < nvec) {
+        if (vv < nvec) {  // wave-uniform for all but the last vector of a row
             const size_t off = base + 4 * (size_t)vv;
             const ushort4 c4 = *reinterpret_cast<const ushort4*>(pci + off);
             const double2 a01 = *reinterpret_cast<const double2*>(pva + off);
@@ -76,7 +90,7 @@ __device__ __forceinline__ void batch_load_pad(RowBatch& bt, const unsigned shor
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                bt.j[4 * u + q] = -1;
+                bt.j[4 * u + q] = 0;
                 bt.a[4 * u + q] = 0.0;
             }
         }
@@ -87,7 +101,7 @@ template <class XV>
 __device__ __forceinline__ double batch_dot(const RowBatch& bt, XV xval) {
     double y[ROW_U];
 #pragma unroll
-    for (int u = 0; u < ROW_U; ++u) y[u] = bt.j[u] >= 0 ? xval(bt.j[u]) : 0.0;
+    for (int u = 0; u < ROW_U; ++u) y[u] = xval(bt.j[u]);
     double s = 0.0;
 #pragma unroll
     for (int u = 0; u < ROW_U; ++u) s += bt.a[u] * y[u];
@@ -107,18 +121,16 @@ struct RowCursor {
 template <bool PAD>
 __device__ __forceinline__ void row_open(const LevelDev& lv, int row, bool valid, bool owner,
                                          int gl, int L, RowCursor& rc, RowBatch& bt) {
+    const int rowc = valid ? row : 0;  // clamped: loads stay unconditional
     if (PAD) {
-        rc.base = (size_t)row * lv.S;
+        rc.base = (size_t)rowc * lv.S;
         rc.nvec = valid ? lv.S / 4 : 0;
-        rc.dg = owner ? lv.diag[row] : 0.0;
+        rc.dg = owner ? lv.diag[rowc] : 0.0;
         batch_load_pad(bt, lv.pci, lv.pva, rc.base, gl, rc.nvec, L);
     } else {
-        rc.e0 = rc.e1 = 0;
+        rc.e0 = lv.rp[rowc];
+        rc.e1 = valid ? lv.rp[rowc + 1] : rc.e0;
         rc.dg = 0.0;
-        if (valid) {
-            rc.e0 = lv.rp[row];
-            rc.e1 = lv.rp[row + 1];
-        }
         batch_load_csr(bt, lv.ci, lv.va, rc.e0 + gl, rc.e1, L);
     }
 }
@@ -212,7 +224,7 @@ __device__ __forceinline__ void vec_pass(int N, LOAD load, USE use) {
 #pragma unroll
         for (int u = 0; u < VEC_U; ++u) {
             const int jj = j0 + u * BT;
-            if (jj < N) v[u] = load(jj);
+            v[u] = load(jj < N ? jj : N - 1);  // unconditional, clamped (see batch_load_*)
         }
 #pragma unroll
         for (int u = 0; u < VEC_U; ++u) {
@@ -289,7 +301,7 @@ __device__ __forceinline__ void phase_smooth(const SmoothArgs& a, int b, int G, 
             [&](int j) {
                 Q q;
                 q.e = ez ? 0.0 : eold[j];
-                q.w = (st && j >= u0 && j < u1) ? win[j] : 0.0;
+                q.w = (st && u1 > u0) ? win[j] : 0.0;  // uniform condition: no per-lane branch
                 q.r = nsp ? lv.r[j] : 0.0;
                 q.a = nsp ? lv.Axi[j] : 0.0;
                 return q;

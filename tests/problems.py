@@ -16,16 +16,39 @@ def mask_bernoulli(m, n, rho, seed=2):
 
 
 def mask_tree(m, n, extra=0.05, seed=2, connect=True):
+    """Tree-like active set, nnz ~ 2(m+n): every row and every column picks a random
+    partner, a few extras; `connect` threads a path row i - column pi(i) - row i+1
+    through a random permutation so that the graph is connected WITHOUT hub nodes
+    (bounded degrees, as in the measured active sets of SURVEY appendix B)."""
     rs = np.random.RandomState(seed)
     Y = np.zeros((m, n), np.uint8)
     Y[np.arange(m), rs.randint(0, n, m)] = 1
     Y[rs.randint(0, m, n), np.arange(n)] = 1
     k = int(extra * (m + n))
     Y[rs.randint(0, m, k), rs.randint(0, n, k)] = 1
-    if connect:  # a path through the rows makes the graph connected
-        for i in range(m - 1):
-            j = int(np.flatnonzero(Y[i])[0])
-            Y[i + 1, j] = 1
+    if connect:
+        pi = rs.permutation(max(m, n)) % n
+        for i in range(m):
+            Y[i, pi[i]] = 1
+            if i + 1 < m:
+                Y[i + 1, pi[i]] = 1
+        for j in range(n):  # columns no row reached hang off a random row
+            if not Y[:, j].any():
+                Y[rs.randint(0, m), j] = 1
+    return Y.reshape(-1, order="F").copy()
+
+
+def mask_hub(m, n, seed=2):
+    """Active set with a few high-degree columns: level 2 fills in (up to ~75 % dense),
+    the peak-E behaviour SURVEY appendix B reports for the level-2 operator."""
+    rs = np.random.RandomState(seed)
+    Y = np.zeros((m, n), np.uint8)
+    Y[np.arange(m), rs.randint(0, n, m)] = 1
+    Y[rs.randint(0, m, n), np.arange(n)] = 1
+    hubs = rs.choice(n, size=max(1, n // 64), replace=False)
+    for j in hubs:
+        Y[rs.random_sample(m) < 0.3, j] = 1
+    Y[:, hubs[0]] = 1            # connects everything
     return Y.reshape(-1, order="F").copy()
 
 
