@@ -654,7 +654,7 @@ extern "C" int ipd_pcg(ipd_ctx* ctx, const ipd_csc* H, const double* e, const do
             if (o->precd >= 0) precd = o->precd;
         }
         Csr hm;
-        csr_upload_from_csc(ctx, tmp, H, true, &hm);
+        csr_upload_from_csc(ctx, tmp, H, false, &hm);  // true rows of H
         const size_t N = (size_t)hm.nr;
         double* de = tmp.alloc<double>(N);
         double* dd = tmp.alloc<double>(N);

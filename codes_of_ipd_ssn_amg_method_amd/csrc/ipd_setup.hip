@@ -768,7 +768,9 @@ extern "C" int ipd_transfer(ipd_ctx* ctx, const ipd_csc* A, const ipd_amg_opts* 
         AmgOpts opts = amg_fill_defaults(o);
         Arena out(&ctx->pool);
         Csr a, c, p, pt;
-        csr_upload_from_csc(ctx, out, A, true, &a);
+        // true rows of A (= transpose of the CSC arrays): a product like Q0*H0*Q0 is symmetric
+        // only up to the last bit, and the setup must see exactly MATLAB's rows
+        csr_upload_from_csc(ctx, out, A, false, &a);
         uint8_t* cmask = out.alloc<uint8_t>((size_t)a.nr);
         amg_transfer(ctx, out, a, opts, level, rng, &c, &p, &pt, cmask);
         csr_download_as_csc(ctx, c, false, Ac);
@@ -794,7 +796,7 @@ extern "C" int ipd_amg_setup(ipd_ctx* ctx, const ipd_csc* A, const ipd_amg_opts*
         CallScope scope(ctx);
         Arena up(&ctx->pool);
         Csr a;
-        csr_upload_from_csc(ctx, up, A, true, &a);
+        csr_upload_from_csc(ctx, up, A, false, &a);  // true rows (see ipd_transfer)
         *out = amg_setup(ctx, a, amg_fill_defaults(o), rng);
         ctx->sync();
     });
