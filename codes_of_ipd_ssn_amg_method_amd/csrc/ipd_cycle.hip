@@ -399,4 +399,526 @@ void pcg_dev(ipd_ctx* ctx, const Csr& H, const double* e, const double* guess, d
     }
 }
 
+// ---------------------------------------------------------------------------
+// whole Class_AMG solve phase in ONE workgroup
+// ---------------------------------------------------------------------------
+// Realistic Newton systems have tiny hierarchies (every level a few thousand nonzeros,
+// SURVEY F4/F5): a W cycle is then several hundred dependent micro-phases and the
+// multi-launch path is bound by launch latency and by the host (measured 1.9 ms per
+// W cycle at M = 1000).  Here one workgroup interprets the V/W recursion itself
+// (MG_Vcycle.m:12-45, MG_Wcycle.m:13-46), the stationary iteration and its stopping
+// rules (Class_AMG.m:86-109): one launch and one read-back per solve.
+static constexpr int SOLVE_ML = 24;
+struct SolveLevel {
+    LevelDev lv;
+    double* e;
+    double* e2;
+    double* w;
+    XferArgs rest;  // r_{k+1} = P' rr_k      (valid for k < J)
+    XferArgs prol;  // e_k += P e_{k+1}
+    int nnzA, nnzP;  // sizes for the LDS cache copy
+};
+struct SolveDesc {
+    int J, nu, isnsp, wcycle, anycycle, maxit;
+    int k_lds;        // levels k_lds..J (and the transfers between them) are cached in LDS
+    int k_tiny;       // levels k_tiny..J have <= 64 rows: their whole sub-cycle runs in ONE wave
+    int stage_bytes;  // size of the gather staging area at the start of dynamic LDS
+    double retol;
+    PcgArgs pcg;
+    SolveLevel L[SOLVE_ML + 1];
+};
+
+struct SolveCtx {  // per-thread copies of uniform state
+    const SolveDesc* D;
+    PhaseLds* lds;
+    double* red;
+    double* xs;
+    unsigned swapmask;  // bit k: the current iterate of level k lives in e2
+    unsigned zeromask;  // bit k: the iterate of level k is identically zero (not materialised)
+};
+
+__device__ __forceinline__ double* sol_e(const SolveCtx& c, int k) {
+    return ((c.swapmask >> k) & 1u) ? c.D->L[k].e2 : c.D->L[k].e;
+}
+__device__ __forceinline__ double* sol_e2(const SolveCtx& c, int k) {
+    return ((c.swapmask >> k) & 1u) ? c.D->L[k].e : c.D->L[k].e2;
+}
+
+__device__ __forceinline__ void sol_smooth_call(SolveCtx& c, const SmoothArgs& a) {
+    phase_smooth<true, false>(a, 0, 1, c.lds, c.xs);  // descriptors carry S = 0: CSR walk only
+    __syncthreads();
+}
+
+__device__ __forceinline__ void sol_sweep(SolveCtx& c, int k, bool post) {
+    const SolveLevel& L = c.D->L[k];
+    SmoothArgs a;
+    a.lv = L.lv;
+    a.eold = sol_e(c, k);
+    a.enew = sol_e2(c, k);
+    a.win = L.w;
+    a.wout = L.w;
+    a.isnsp = c.D->isnsp;
+    a.staged = 1;
+    a.eold_zero = (c.zeromask >> k) & 1u;
+    const int nf = L.lv.nf, N = L.lv.N;
+    if (nf == 0) {
+        a.row0 = 0;
+        a.row1 = N;
+        a.u0 = a.u1 = 0;
+        a.wout = nullptr;
+        sol_smooth_call(c, a);
+    } else {
+        const int f0 = post ? nf : 0, f1 = post ? N : nf;
+        const int s0 = post ? 0 : nf, s1 = post ? nf : N;
+        a.row0 = f0;
+        a.row1 = f1;
+        a.u0 = a.u1 = 0;
+        sol_smooth_call(c, a);
+        a.row0 = s0;
+        a.row1 = s1;
+        a.u0 = f0;
+        a.u1 = f1;
+        a.wout = nullptr;
+        sol_smooth_call(c, a);
+    }
+    c.swapmask ^= (1u << k);
+    c.zeromask &= ~(1u << k);
+}
+
+// ---- wave-level sub-cycle: levels with <= 64 rows, everything LDS-resident ------------
+// A W cycle visits level k 2^(k-1) times, so most of its phases run on the deepest,
+// tiniest levels (a dozen rows).  There a 1024-thread phase is all fixed cost (barriers,
+// descriptor reads), so ONE wave runs the whole sub-cycle below level k_tiny: lane i owns
+// row i, vectors live in LDS, a wave is its own barrier (LDS operations of one wave
+// execute in order; the fence only stops the compiler from reordering them).
+__device__ __forceinline__ void tiny_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double tiny_rowdot(const int* rp, const int* ci, const double* va,
+                                              int row, bool valid, const double* x) {
+    double s = 0.0;
+    if (valid)
+        for (int t = rp[row]; t < rp[row + 1]; ++t) s += va[t] * x[ci[t]];
+    return s;
+}
+
+__device__ __forceinline__ void tiny_sweep(SolveCtx& c, int k) {  // Jacobi levels only (k >= 2)
+    const SolveLevel& L = c.D->L[k];
+    const int i = threadIdx.x, N = L.lv.N;
+    const bool valid = i < N, ez = (c.zeromask >> k) & 1u;
+    const double* e = sol_e(c, k);
+    double* en = sol_e2(c, k);
+    const double eo = (valid && !ez) ? e[i] : 0.0;
+    const double rv = valid ? L.lv.r[i] : 0.0;
+    const double ax = valid ? L.lv.Axi[i] : 0.0;
+    double cc = 0.0;
+    if (c.D->isnsp) cc = wave_sum(rv - ax * eo) / L.lv.xx[0];
+    const double sd = ez ? 0.0 : tiny_rowdot(L.lv.rp, L.lv.ci, L.lv.va, i, valid, e);
+    if (valid) en[i] = eo + L.lv.dinv[i] * (rv - sd - ax * cc) + cc;
+    tiny_sync();
+    c.swapmask ^= (1u << k);
+    c.zeromask &= ~(1u << k);
+}
+
+__device__ __forceinline__ void tiny_pcg(SolveCtx& c, int k) {  // PCG.m:68-87, Jacobi, zero guess
+    const SolveLevel& L = c.D->L[k];
+    const PcgArgs& a = c.D->pcg;
+    const int i = threadIdx.x, N = L.lv.N;
+    const bool valid = i < N;
+    double* pv = a.work;  // p shared through LDS
+    double dg = 1.0;
+    if (valid)
+        for (int t = L.lv.rp[i]; t < L.lv.rp[i + 1]; ++t)
+            if (L.lv.ci[t] == i) dg = L.lv.va[t];
+    double r = valid ? L.lv.r[i] : 0.0;
+    double p = a.precd == 2 ? r / dg : r;
+    double d = 0.0;
+    double delta_new = wave_sum(valid ? r * p : 0.0);
+    const double delta_0 = delta_new, thresh = a.tol * a.tol * delta_0;
+    long long it = 0;
+    while (it < a.maxit && delta_new > thresh) {
+        const double delta_old = delta_new;
+        if (valid) pv[i] = p;
+        tiny_sync();
+        const double q = tiny_rowdot(L.lv.rp, L.lv.ci, L.lv.va, i, valid, pv);
+        tiny_sync();
+        const double alpha = delta_old / wave_sum(valid ? q * p : 0.0);
+        d += alpha * p;
+        r -= alpha * q;
+        const double w = a.precd == 2 ? r / dg : r;
+        delta_new = wave_sum(valid ? r * w : 0.0);
+        p = w + (delta_new / delta_old) * p;
+        ++it;
+    }
+    if (valid) sol_e(c, k)[i] = d;
+    tiny_sync();
+    c.zeromask &= ~(1u << k);
+}
+
+// sub-cycle rooted at level k0 >= k_tiny (r_{k0} is in LDS); executed by wave 0 only
+__device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
+    const SolveDesc* D = c.D;
+    const int J = D->J, nu = D->nu, i = threadIdx.x;
+    unsigned visited = 0;
+    int k = k0;
+    bool entering = true, keep = keep0;
+    for (int guard = 0; guard < (1 << 22); ++guard) {
+        if (entering) {
+            if (k == J) {
+                tiny_pcg(c, J);
+                if (k == k0) return;
+                entering = false;
+                k = J - 1;
+                continue;
+            }
+            const SolveLevel& L = D->L[k];
+            if (!keep) {
+                c.zeromask |= (1u << k);
+                if (nu == 0) {
+                    if (i < L.lv.N) sol_e(c, k)[i] = 0.0;
+                    tiny_sync();
+                    c.zeromask &= ~(1u << k);
+                }
+            }
+            for (int s = 0; s < nu; ++s) tiny_sweep(c, k);
+            {   // residual, then restriction into the child's right-hand side
+                const bool valid = i < L.lv.N;
+                const double sd = tiny_rowdot(L.lv.rp, L.lv.ci, L.lv.va, i, valid, sol_e(c, k));
+                if (valid) L.lv.rr[i] = L.lv.r[i] - sd;
+                tiny_sync();
+                const bool cv = i < L.rest.nrows;
+                const double rc = tiny_rowdot(L.rest.rp, L.rest.ci, L.rest.va, i, cv, L.lv.rr);
+                if (cv) L.rest.y[i] = rc;
+                tiny_sync();
+            }
+            visited &= ~(1u << (k + 1));
+            k = k + 1;
+            keep = false;
+        } else {
+            const bool again = D->wcycle && (k + 1 < J) && !((visited >> (k + 1)) & 1u);
+            if (again) {
+                visited |= (1u << (k + 1));
+                k = k + 1;
+                keep = true;
+                entering = true;
+                continue;
+            }
+            const SolveLevel& L = D->L[k];
+            {
+                const bool valid = i < L.lv.N;
+                double* e = sol_e(c, k);
+                const double sd = tiny_rowdot(L.prol.rp, L.prol.ci, L.prol.va, i, valid, sol_e(c, k + 1));
+                if (valid) e[i] = e[i] + sd;
+                tiny_sync();
+            }
+            for (int s = 0; s < nu; ++s) tiny_sweep(c, k);
+            if (k == k0) return;
+            k = k - 1;
+        }
+    }
+}
+
+// one V or W cycle on r_1 (in L[1].lv.r); the correction ends up in sol_e(c, 1)
+__device__ __forceinline__ void sol_cycle(SolveCtx& c) {
+    const SolveDesc* D = c.D;
+    const int J = D->J, nu = D->nu;
+    unsigned visited = 0;  // bit k: level k has completed one visit under its current parent
+    int k = 1;
+    bool entering = true, keep = false;
+    for (int guard = 0; guard < (1 << 22); ++guard) {
+        if (entering && k >= D->k_tiny && k > 1) {
+            // the whole sub-cycle below here runs in wave 0; 2*nu sweeps per visit leave the
+            // e/e2 roles of every level unchanged, so the other waves need no state update
+            if (threadIdx.x < 64) {
+                SolveCtx t = c;
+                tiny_cycle(t, k, keep);
+            }
+            __syncthreads();
+            c.zeromask &= ~(1u << k);
+            entering = false;
+            k = k - 1;
+            continue;
+        }
+        if (entering) {
+            if (k == J) {  // coarsest: PCG(A, r)                         MG_Vcycle.m:43
+                PcgArgs a = D->pcg;
+                a.rhs = D->L[J].lv.r;
+                a.d = sol_e(c, J);
+                pcg_block(a, c.red);
+                __syncthreads();
+                c.zeromask &= ~(1u << J);
+                if (J == 1) return;
+                entering = false;
+                k = J - 1;
+                continue;
+            }
+            if (!keep) {
+                c.zeromask |= (1u << k);
+                if (nu == 0) {  // no sweep will write the iterate: materialise the zero
+                    double* e = sol_e(c, k);
+                    for (int i = threadIdx.x; i < D->L[k].lv.N; i += BT) e[i] = 0.0;
+                    __syncthreads();
+                    c.zeromask &= ~(1u << k);
+                }
+            }
+            for (int s = 0; s < nu; ++s) sol_sweep(c, k, false);          // :14-25
+            {
+                const LevelDev& lv = D->L[k].lv;                          // :27
+                phase_resid<true, false>(lv, sol_e(c, k), 0, lv.N, 0, 1, c.lds, c.xs);
+                __syncthreads();
+                phase_xfer<true>(D->L[k].rest, 0, 1, c.lds, c.xs);
+                __syncthreads();
+            }
+            visited &= ~(1u << (k + 1));
+            k = k + 1;
+            keep = false;
+            entering = true;
+        } else {  // back in level k from its child k+1
+            const bool again = D->wcycle && (k + 1 < J) && !((visited >> (k + 1)) & 1u);
+            if (again) {  // MG_Wcycle.m:30: second correction starting from the first one
+                visited |= (1u << (k + 1));
+                k = k + 1;
+                keep = true;
+                entering = true;
+                continue;
+            }
+            XferArgs pa = D->L[k].prol;                                    // :31
+            pa.x = sol_e(c, k + 1);
+            pa.y = sol_e(c, k);
+            phase_xfer<true>(pa, 0, 1, c.lds, c.xs);
+            __syncthreads();
+            for (int s = 0; s < nu; ++s) sol_sweep(c, k, true);           // :33-41
+            if (k == 1) return;
+            k = k - 1;
+        }
+    }
+}
+
+__device__ __forceinline__ void sol_top(SolveCtx& c, const double* b, const double* x,
+                                        const double* e, double* xnew, double* hist, int first) {
+    TopArgs a;
+    a.lv = c.D->L[1].lv;
+    a.b = b;
+    a.x = x;
+    a.e = e;
+    a.xnew = xnew;
+    a.row0 = 0;
+    a.row1 = a.lv.N;
+    a.staged = 1;
+    phase_top<true, false>(a, 0, 1, c.lds, c.xs);
+    __syncthreads();
+    ConvArgs ca;
+    ca.r = a.lv.r;
+    ca.n = a.lv.N;
+    ca.hist = hist;
+    ca.first = first;
+    conv_block(ca, c.red);
+    __syncthreads();
+}
+
+// out[0] = it, out[1] = rel_res, out[2] = res0; rel_resk at out[4 ..], rhok at out[4+maxit+2 ..]
+// fixed_cycles > 0: run exactly that many loop bodies without the stopping rules (bench hook)
+template <bool CACHED>
+__global__ __launch_bounds__(BT) void k_solve_small(const SolveDesc* __restrict__ D_global,
+                                                    const double* __restrict__ b, double* xa,
+                                                    double* xb, double* hist, double* out,
+                                                    int fixed_cycles) {
+    __shared__ PhaseLds lds;
+    __shared__ double red[16];
+    extern __shared__ __attribute__((aligned(16))) char dyn_raw[];
+    // dynamic LDS: [ staging vector | descriptor copy | cached levels ]
+    const SolveDesc* D = D_global;
+    SolveDesc* LD = reinterpret_cast<SolveDesc*>(dyn_raw + D->stage_bytes);
+    if (CACHED) {
+        const int* src = reinterpret_cast<const int*>(D);
+        int* dst = reinterpret_cast<int*>(LD);
+        for (int i = threadIdx.x; i < (int)(sizeof(SolveDesc) / 4); i += BT) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (CACHED) {   // Copy the deepest levels into LDS: they are tiny but a W cycle visits level k
+        // 2^(k-1) times, so their phases must not pay global-memory latency.  Every thread
+        // walks the same carve sequence; pointers in the LDS descriptor are patched by thread 0.
+        size_t off = (size_t)D->stage_bytes + ((sizeof(SolveDesc) + 15) / 16) * 16;
+        auto carve = [&](size_t bytes) {
+            char* p = dyn_raw + off;
+            off += (bytes + 15) / 16 * 16;
+            return p;
+        };
+        auto copy_i = [&](const int* src, size_t n) {
+            int* d = reinterpret_cast<int*>(carve(n * 4));
+            for (size_t i = threadIdx.x; i < n; i += BT) d[i] = src[i];
+            return d;
+        };
+        auto copy_d = [&](const double* src, size_t n) {
+            double* d = reinterpret_cast<double*>(carve(n * 8));
+            for (size_t i = threadIdx.x; i < n; i += BT) d[i] = src[i];
+            return d;
+        };
+        auto copy_h = [&](const unsigned short* src, size_t n) {
+            unsigned short* d = reinterpret_cast<unsigned short*>(carve(n * 2));
+            for (size_t i = threadIdx.x; i < n; i += BT) d[i] = src[i];
+            return d;
+        };
+        const bool t0 = threadIdx.x == 0;
+        for (int k = D->k_lds; k <= D->J; ++k) {
+            const SolveLevel& G = D->L[k];
+            SolveLevel& T = LD->L[k];
+            const size_t N = (size_t)G.lv.N;
+            const int* rp = copy_i(G.lv.rp, N + 1);
+            const int* ci = copy_i(G.lv.ci, (size_t)G.nnzA);
+            const double* va = copy_d(G.lv.va, (size_t)G.nnzA);
+            const double* dinv = copy_d(G.lv.dinv, N);
+            const double* Axi = copy_d(G.lv.Axi, N);
+            const double* xx = copy_d(G.lv.xx, 1);
+            const unsigned short* pci = nullptr;
+            const double* pva = nullptr;
+            const double* diag = nullptr;
+            if (G.lv.S > 0) {
+                pci = copy_h(G.lv.pci, N * G.lv.S);
+                pva = copy_d(G.lv.pva, N * G.lv.S);
+                diag = copy_d(G.lv.diag, N);
+            }
+            double* r = reinterpret_cast<double*>(carve(N * 8));
+            double* rr = reinterpret_cast<double*>(carve(N * 8));
+            double* e = reinterpret_cast<double*>(carve(N * 8));
+            double* e2 = reinterpret_cast<double*>(carve(N * 8));
+            double* w = reinterpret_cast<double*>(carve(N * 8));
+            if (t0) {
+                T.lv.rp = rp;
+                T.lv.ci = ci;
+                T.lv.va = va;
+                T.lv.dinv = dinv;
+                T.lv.Axi = Axi;
+                T.lv.xx = xx;
+                T.lv.pci = pci;
+                T.lv.pva = pva;
+                T.lv.diag = diag;
+                T.lv.r = r;
+                T.lv.rr = rr;
+                T.e = e;
+                T.e2 = e2;
+                T.w = w;
+            }
+            if (k < D->J) {  // transfers between two cached levels
+                const size_t Nc = (size_t)G.rest.nrows;
+                const int* trp = copy_i(G.rest.rp, Nc + 1);
+                const int* tci = copy_i(G.rest.ci, (size_t)G.nnzP);
+                const double* tva = copy_d(G.rest.va, (size_t)G.nnzP);
+                const int* prp = copy_i(G.prol.rp, N + 1);
+                const int* pci2 = copy_i(G.prol.ci, (size_t)G.nnzP);
+                const double* pva2 = copy_d(G.prol.va, (size_t)G.nnzP);
+                if (t0) {
+                    T.rest.rp = trp;
+                    T.rest.ci = tci;
+                    T.rest.va = tva;
+                    T.prol.rp = prp;
+                    T.prol.ci = pci2;
+                    T.prol.va = pva2;
+                }
+            }
+        }
+        __syncthreads();
+        if (t0) {  // vectors that cross level boundaries, and the coarsest PCG
+            for (int k = 1; k < D->J; ++k) {
+                LD->L[k].rest.x = LD->L[k].lv.rr;
+                LD->L[k].rest.y = LD->L[k + 1].lv.r;
+            }
+            const int J = D->J;
+            if (J >= D->k_lds) {
+                LD->pcg.rp = LD->L[J].lv.rp;
+                LD->pcg.ci = LD->L[J].lv.ci;
+                LD->pcg.va = LD->L[J].lv.va;
+            }
+        }
+        if (D->J >= D->k_lds) {
+            double* work = reinterpret_cast<double*>(carve(4 * (size_t)D->L[D->J].lv.N * 8));
+            if (t0) LD->pcg.work = work;
+        }
+        __syncthreads();
+    }
+    SolveCtx c;
+    // without cached levels the descriptor stays in global memory: its (uniform) fields
+    // are then fetched with scalar loads and live in SGPRs instead of VGPRs
+    c.D = CACHED ? LD : D_global;
+    c.lds = &lds;
+    c.red = red;
+    c.xs = reinterpret_cast<double*>(dyn_raw);
+    c.swapmask = 0;
+    c.zeromask = 0;
+    D = c.D;
+    const int N = D->L[1].lv.N;
+    const int maxit = D->maxit;
+    double* const x_home = xa;
+    double* relk = out + 4;
+    double* rhok = out + 4 + (maxit + 2);
+    sol_top(c, b, xa, nullptr, xb, hist, 1);                              // Class_AMG.m:89
+    {
+        double* t = xa;
+        xa = xb;
+        xb = t;
+    }
+    const double res0 = hist[0];
+    int it = 0;
+    double rel_res = 0.0;
+    if (fixed_cycles > 0) {
+        for (int cyc = 0; cyc < fixed_cycles; ++cyc) {
+            const double* ecorr = nullptr;
+            if (D->anycycle) {
+                sol_cycle(c);
+                ecorr = sol_e(c, 1);
+            }
+            sol_top(c, b, xa, ecorr, xb, hist, 0);
+            double* t = xa;
+            xa = xb;
+            xb = t;
+        }
+        it = fixed_cycles;
+        rel_res = hist[3];
+    } else if (res0 == 0.0) {                                             // :91-92
+        if (threadIdx.x == 0) {
+            relk[0] = 0.0;
+            rhok[0] = INFINITY;
+        }
+    } else {
+        it = 1;                                                           // :94
+        double last_rel = 1.0;
+        if (threadIdx.x == 0) {
+            relk[0] = 1.0;
+            rhok[0] = NAN;
+        }
+        while (last_rel > D->retol && it <= maxit) {                      // :95
+            const double* ecorr = nullptr;
+            if (D->anycycle) {
+                sol_cycle(c);                                             // :96-102
+                ecorr = sol_e(c, 1);
+            }
+            sol_top(c, b, xa, ecorr, xb, hist, 0);                        // :103-105
+            double* t = xa;
+            xa = xb;
+            xb = t;
+            rel_res = hist[3];
+            const double rho = hist[4];
+            if (threadIdx.x == 0) {
+                relk[it] = rel_res;
+                rhok[it] = rho;
+            }
+            last_rel = rel_res;
+            ++it;
+            if (rho > 1.0) break;                                         // :106
+            __syncthreads();  // hist is rewritten by the next conv_block
+        }
+        it -= 1;                                                          // :108
+    }
+    __syncthreads();
+    if (xa != x_home)
+        for (int i = threadIdx.x; i < N; i += BT) x_home[i] = xa[i];
+    if (threadIdx.x == 0) {
+        out[0] = (double)it;
+        out[1] = rel_res;
+        out[2] = res0;
+    }
+}
+
 #include "ipd_cycle_host.h"

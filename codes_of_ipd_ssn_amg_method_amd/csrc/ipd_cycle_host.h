@@ -30,6 +30,12 @@ struct CycleState {
     size_t pending_lds = 0;
     bool fuse_enabled = true;
     CycleState() { pending.n = 0; }
+    // single-workgroup whole-solve kernel (small hierarchies): device descriptor + outputs
+    SolveDesc* d_solve = nullptr;
+    double* solve_out = nullptr;
+    size_t solve_lds = 0;
+    bool small_ok = false;
+    bool solve_cached = false;
     double* x2 = nullptr;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};  // captured Class_AMG loop bodies (x->x2, x2->x)
     const double* gb = nullptr;                    // right-hand side the graphs were captured for
@@ -220,6 +226,121 @@ void amg_prepare_levels(ipd_amg* h) {
     st->x2 = ar.alloc<double>((size_t)h->L[1].A.nr);
     h->x = ar.alloc<double>((size_t)h->L[1].A.nr);
     h->b = ar.alloc<double>((size_t)h->L[1].A.nr);
+    // ---- single-workgroup solver: eligible when every level is small and stageable ----
+    {
+        const char* ns = std::getenv("IPD_NO_SMALL");
+        bool ok = !(ns && ns[0] == '1') && h->J <= SOLVE_ML;
+        size_t maxlen = 1;
+        for (int k = 1; k <= h->J && ok; ++k) {
+            const Level& lv = h->L[k];
+            // one workgroup is one CU: beyond ~1000 short rows per level the multi-launch
+            // path (many CUs per phase) wins again (measured: M = 1000 W-cycle solve 9.5 ms
+            // here vs 17 ms multi-launch; M = 2048: 8.0 ms here vs 5.6 ms multi-launch)
+            ok = ok && lv.A.nr <= 1024 && lv.A.nnz <= 40000;
+            maxlen = std::max(maxlen, (size_t)lv.A.nr);
+            if (k >= 2) ok = ok && lv.P.nnz <= 40000;
+        }
+        if (ok) {
+            std::unique_ptr<SolveDesc> sd(new SolveDesc());
+            std::memset(sd.get(), 0, sizeof(SolveDesc));
+            sd->J = h->J;
+            sd->nu = h->opts.smoth;
+            sd->isnsp = h->opts.isnsp;
+            sd->wcycle = h->opts.cycle == 'w';
+            sd->anycycle = (h->opts.cycle == 'w' || h->opts.cycle == 'v');
+            sd->maxit = h->opts.maxit;
+            sd->retol = h->opts.retol;
+            sd->pcg = st->run[(size_t)h->J].pcg;
+            for (int k = 1; k <= h->J; ++k) {
+                SolveLevel& sl = sd->L[k];
+                sl.lv = st->run[(size_t)k].dev;
+                sl.lv.S = 0;  // the single-workgroup solver walks the CSR arrays only
+                // in one workgroup a row is walked by few lanes: re-pick without widening
+                const Level& lv = h->L[k];
+                if (sl.lv.S == 0) {
+                    const double avg = (double)lv.A.nnz / std::max(lv.A.nr, 1);
+                    int L = 1;
+                    while (L < 64 && (double)L * 6.0 < avg) L <<= 1;
+                    sl.lv.L = L;
+                }
+                sl.lv.G = 1;
+                sl.e = lv.e;
+                sl.e2 = lv.e2;
+                sl.w = lv.w;
+                if (k < h->J) {
+                    sl.rest = st->run[(size_t)k].restrict_args;
+                    sl.prol = st->run[(size_t)k].prolong_args;
+                    for (XferArgs* xa : {&sl.rest, &sl.prol}) {
+                        const double avg = (double)(xa == &sl.rest ? h->L[k + 1].Pt.nnz : h->L[k + 1].P.nnz) /
+                                           std::max(xa->nrows, 1);
+                        int L = 1;
+                        while (L < 64 && (double)L * 6.0 < avg) L <<= 1;
+                        xa->L = L;
+                        xa->G = 1;
+                        xa->staged = 1;
+                        xa->row0 = 0;
+                        xa->row1 = xa->nrows;
+                    }
+                }
+            }
+            // LDS cache plan: deepest levels first, while they fit
+            auto r16 = [](size_t b) { return (b + 15) / 16 * 16; };
+            const size_t stage = r16(sizeof(double) * maxlen);
+            size_t used = stage + r16(sizeof(SolveDesc)) + 256;
+            const size_t budget = 150 * 1024;
+            int k_lds = h->J + 1;
+            for (int k = h->J; k >= 1; --k) {
+                const Level& lv = h->L[k];
+                SolveLevel& sl = sd->L[k];
+                sl.nnzA = lv.A.nnz;
+                sl.nnzP = k < h->J ? h->L[k + 1].P.nnz : 0;
+                const size_t N = (size_t)lv.A.nr;
+                size_t bytes = r16(4 * (N + 1)) + r16(4 * (size_t)lv.A.nnz) + r16(8 * (size_t)lv.A.nnz) +
+                               7 * r16(8 * N) + 16;
+                if (k < h->J) {
+                    const size_t Nc = (size_t)h->L[k + 1].A.nr, np = (size_t)sl.nnzP;
+                    bytes += r16(4 * (Nc + 1)) + r16(4 * (N + 1)) + 2 * (r16(4 * np) + r16(8 * np));
+                }
+                if (k == h->J) bytes += r16(4 * 8 * N);
+                if (used + bytes > budget) break;
+                used += bytes;
+                k_lds = k;
+            }
+            {
+                const char* nc = std::getenv("IPD_NO_LDSCACHE");
+                if (nc && nc[0] == '1') {
+                    k_lds = h->J + 1;
+                    used = stage + 256;
+                }
+            }
+            sd->k_lds = k_lds;
+            st->solve_cached = k_lds <= h->J;
+            {   // tiny levels: <= 64 rows, cached, Jacobi (k >= 2)
+                int kt = h->J + 1;
+                const char* nt = std::getenv("IPD_NO_TINY");
+                if (!(nt && nt[0] == '1'))
+                    for (int k = h->J; k >= std::max(2, k_lds); --k) {
+                        if (h->L[k].A.nr > 64) break;
+                        kt = k;
+                    }
+                sd->k_tiny = kt;
+            }
+            sd->stage_bytes = (int)stage;
+            st->solve_lds = used;
+            static bool attr_set = false;
+            if (!attr_set) {
+                IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+                IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+                attr_set = true;
+            }
+            st->d_solve = reinterpret_cast<SolveDesc*>(ar.alloc_bytes(sizeof(SolveDesc)));
+            ctx->upload_bytes(st->d_solve, sd.get(), sizeof(SolveDesc));
+            st->solve_out = ar.alloc<double>(4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2));
+            st->small_ok = true;
+        }
+    }
     h->cyc = std::shared_ptr<CycleState>(st.release());
 }
 
@@ -512,6 +633,8 @@ static void enqueue_loop_body(ipd_amg* h, CycleState* st, const double* b, const
     launch_top(h, st, b, xin, ecorr, xout, false);
 }
 
+static void ensure_graphs(ipd_amg* h, CycleState* st, const double* b_dev);
+
 // Class_AMG.m:86-109
 void amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev, double* x_dev,
                    int32_t* it_out, double* rel_res_out, double* rel_resk, double* rhok) {
@@ -527,6 +650,31 @@ void amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev, dou
                                ctx->stream));
     else
         IPD_HIP(hipMemsetAsync(xa, 0, sizeof(double) * (size_t)N, ctx->stream));
+    if (st->small_ok && st->shard_ranks == 1) {
+        // small hierarchy: the whole solve phase is one single-workgroup launch
+        if (st->solve_cached)
+            hipLaunchKernelGGL(k_solve_small<true>, dim3(1), dim3(BT), st->solve_lds, ctx->stream,
+                               (const SolveDesc*)st->d_solve, b_dev, xa, xb, st->hist,
+                               st->solve_out, 0);
+        else
+            hipLaunchKernelGGL(k_solve_small<false>, dim3(1), dim3(BT), st->solve_lds, ctx->stream,
+                               (const SolveDesc*)st->d_solve, b_dev, xa, xb, st->hist,
+                               st->solve_out, 0);
+        IPD_KERNEL_CHECK();
+        const size_t nout = 4 + 2 * ((size_t)o.maxit + 2);
+        std::vector<double> out(nout);
+        ctx->fetch(st->solve_out, out.data(), nout);
+        const int its = (int)out[0];
+        if (rel_resk) std::memcpy(rel_resk, out.data() + 4, sizeof(double) * ((size_t)its + 1));
+        if (rhok) std::memcpy(rhok, out.data() + 4 + (o.maxit + 2), sizeof(double) * ((size_t)its + 1));
+        if (x_dev)
+            IPD_HIP(hipMemcpyAsync(x_dev, xa, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+        if (it_out) *it_out = its;
+        if (rel_res_out) *rel_res_out = out[1];
+        ctx->sync();
+        return;
+    }
     launch_top(h, st, b_dev, xa, nullptr, xb, true);                            // :89
     std::swap(xa, xb);
     double hh[5];
@@ -541,7 +689,16 @@ void amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev, dou
         double last_rel = 1.0;
         if (rel_resk) rel_resk[0] = 1.0;
         if (rhok) rhok[0] = NAN;
+        // Optional replay of the loop body from two captured HIP graphs (IPD_SOLVE_GRAPH=1).
+        // Measured: no gain for a solve -- the device, not the host, is the bottleneck at
+        // ~3 us per dependent launch, and instantiating ~600 nodes costs ~1 ms per hierarchy.
+        const char* sg = std::getenv("IPD_SOLVE_GRAPH");
+        const bool use_graph = (sg && sg[0] == '1') && st->shard_ranks == 1;
+        if (use_graph) ensure_graphs(h, st, b_dev);
         while (last_rel > o.retol && it <= o.maxit) {                            // :95
+            if (use_graph)
+                IPD_HIP(hipGraphLaunch(st->gexec[xa == h->x ? 0 : 1], ctx->stream));
+            else
             enqueue_loop_body(h, st, b_dev, xa, xb);                             // :96-105
             std::swap(xa, xb);
             ctx->fetch(st->hist, hh, 5);
@@ -745,6 +902,35 @@ extern "C" int ipd_amg_bench_cycles(ipd_amg* h, const double* b_dev, double* x_d
         CycleState* st = state_of(h);
         IPD_REQUIRE(st, IPD_E_ARG, "hierarchy has no cycle state");
         const int N = h->L[1].A.nr;
+        if (st->small_ok) {  // one launch runs all the cycles (no stopping rules)
+            IPD_HIP(hipMemcpyAsync(h->x, x_dev, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+            hipEvent_t e0, e1;
+            IPD_HIP(hipEventCreate(&e0));
+            IPD_HIP(hipEventCreate(&e1));
+            IPD_HIP(hipEventRecord(e0, ctx->stream));
+            if (st->solve_cached)
+                hipLaunchKernelGGL(k_solve_small<true>, dim3(1), dim3(BT), st->solve_lds,
+                                   ctx->stream, (const SolveDesc*)st->d_solve, b_dev, h->x, st->x2,
+                                   st->hist, st->solve_out, cycles);
+            else
+                hipLaunchKernelGGL(k_solve_small<false>, dim3(1), dim3(BT), st->solve_lds,
+                                   ctx->stream, (const SolveDesc*)st->d_solve, b_dev, h->x, st->x2,
+                                   st->hist, st->solve_out, cycles);
+            IPD_KERNEL_CHECK();
+            IPD_HIP(hipEventRecord(e1, ctx->stream));
+            IPD_HIP(hipEventSynchronize(e1));
+            float msf = 0.f;
+            IPD_HIP(hipEventElapsedTime(&msf, e0, e1));
+            IPD_HIP(hipEventDestroy(e0));
+            IPD_HIP(hipEventDestroy(e1));
+            IPD_HIP(hipMemcpyAsync(x_dev, h->x, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+            ctx->sync();
+            *total_ms = msf;
+            if (bytes_per_cycle) *bytes_per_cycle = cycle_bytes(h);
+            return;
+        }
         const char* ng = std::getenv("IPD_NO_GRAPH");
         const bool use_graph = !(ng && ng[0] == '1');
         IPD_HIP(hipMemcpyAsync(h->x, x_dev, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,

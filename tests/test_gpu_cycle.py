@@ -138,3 +138,29 @@ def test_vcycle_linearity_full_size(ipd):
     # and the cycle contracts the residual
     assert np.linalg.norm(r1 - A @ e1) < 0.5 * np.linalg.norm(r1)
     h.close()
+
+
+@pytest.mark.parametrize("cycle", ["v", "w"])
+@pytest.mark.parametrize("isnsp", [0, 1])
+def test_single_workgroup_solver_matches_multi_launch_path(ipd, cycle, isnsp):
+    """Small hierarchies are solved by ONE single-workgroup launch (k_solve_small); it must
+    reproduce the multi-launch path (and hence the oracle) to the same tolerance."""
+    import os
+    m = n = 200
+    s = PR.mask_tree(m, n, seed=11)
+    Ae, pd = newton_matrix(m, n, s)
+    f = np.concatenate([pd["q"], -pd["p"]]) * pd["z"]
+    guess = pd["bk1"] * pd["tk"] * np.random.RandomState(4).random_sample(m + n)
+    o = O.amg_options_class1(cycle)
+    o.update(fnode=n, isnsp=isnsp, guess=guess)
+    xs, its, rels, rks, rhos = ipd.Class_AMG(Ae, f, o, ipd.MatlabRand())
+    os.environ["IPD_NO_SMALL"] = "1"
+    try:
+        xm, itm, relm, rkm, rhom = ipd.Class_AMG(Ae, f, o, ipd.MatlabRand())
+    finally:
+        os.environ.pop("IPD_NO_SMALL")
+    xo, ito, relo, rko, rhoo = O.Class_AMG(Ae, f, o, O.matlab_rng())
+    k = min(len(rks), len(rkm), len(rko))
+    assert np.max(np.abs(rks[:k] - rkm[:k])) <= RES_TOL and np.max(np.abs(rks[:k] - rko[:k])) <= RES_TOL
+    assert abs(its - itm) <= 1 and abs(its - ito) <= 1
+    assert abs(np.linalg.norm(Ae @ xs - f) - np.linalg.norm(Ae @ xm - f)) <= 1e-9 * np.linalg.norm(f)

@@ -44,7 +44,11 @@ def test_sharded_emulation_is_bit_exact(ipd, mask, cycle):
     x0 = np.random.RandomState(4).random_sample(m + n) * 1e-4
     o = O.amg_options_class1(cycle)
     o.update(fnode=n, isnsp=1)
-    h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+    os.environ["IPD_NO_SMALL"] = "1"   # compare like with like: the multi-launch path
+    try:
+        h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+    finally:
+        os.environ.pop("IPD_NO_SMALL")
     ref = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles, h, f, x0, 3)
     os.environ["IPD_NO_GRAPH"] = "1"
     eager = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles, h, f, x0, 3)
@@ -70,7 +74,11 @@ def test_rccl_communicator_of_one(ipd):
     x0 = np.zeros(m + n)
     o = O.amg_options_class1("v")
     o.update(fnode=n, isnsp=1)
-    h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+    os.environ["IPD_NO_SMALL"] = "1"
+    try:
+        h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+    finally:
+        os.environ.pop("IPD_NO_SMALL")
     ref = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles, h, f, x0, 2)
     ident = np.zeros(_lib.COMM_ID_BYTES, np.uint8)
     _lib.check(_lib.lib.ipd_comm_get_unique_id(_lib.bptr(ident)))
