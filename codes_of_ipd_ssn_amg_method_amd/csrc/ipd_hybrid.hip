@@ -158,11 +158,11 @@ __global__ __launch_bounds__(1024) void k_components(int N, const int* __restric
     for (int round = 0; round < 64; ++round) {
         if (threadIdx.x == 0) changed = 0;
         __syncthreads();
-        // hook: thread-per-row walk keeps (i,j) pairs without an edge list
+        // hook: one wave per row (hub rows have ~1000 entries), lanes over its entries
         bool any = false;
-        for (int i = threadIdx.x; i < N; i += 1024) {
+        for (int i = threadIdx.x >> 6; i < N; i += 16) {
             const int pi = parent[i];
-            for (int t = rp[i]; t < rp[i + 1]; ++t) {
+            for (int t = rp[i] + (threadIdx.x & 63); t < rp[i + 1]; t += 64) {
                 const int pj = parent[ci[t]];
                 if (pj < pi) {
                     atomicMin(&parent[pi], pj);

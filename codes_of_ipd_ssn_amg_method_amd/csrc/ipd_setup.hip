@@ -371,57 +371,77 @@ static void amg_cf_split(ipd_ctx* ctx, const Csr& S, uint8_t* isC, uint8_t* isF)
 // level 1 of a bigraph: F = first nf rows, W = (-Aff)\Afc with Aff diagonal
 // (transfer.m:20-25); one lane per row, sequential, so the row sum used by the
 // isnsp normalisation (:22-24) is accumulated in ascending column order.
-__global__ void k_bigph_count(int N, int nf, const int* __restrict__ rp,
-                              const int* __restrict__ ci, int* __restrict__ rowlen,
-                              int* __restrict__ bad) {
-    THREAD_ELEMS(i, N) {
+__global__ __launch_bounds__(256) void k_bigph_count(int N, int nf, const int* __restrict__ rp,
+                                                     const int* __restrict__ ci,
+                                                     int* __restrict__ rowlen,
+                                                     int* __restrict__ bad) {
+    WAVE_ROWS(i, N) {
         if (i >= nf) {
-            rowlen[i] = 1;
-        } else {
-            int c = 0;
-            for (int t = rp[i]; t < rp[i + 1]; ++t) {
-                const int j = ci[t];
-                if (j >= nf)
-                    ++c;
-                else if (j != i)
-                    *bad = 1;  // Aff is not diagonal
-            }
-            rowlen[i] = c;
+            if (lane == 0) rowlen[i] = 1;
+            continue;
         }
+        int c = 0;
+        for (int t = rp[i] + lane; t < rp[i + 1]; t += 64) {
+            const int j = ci[t];
+            if (j >= nf)
+                ++c;
+            else if (j != i)
+                *bad = 1;  // Aff is not diagonal
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+        if (lane == 0) rowlen[i] = c;
     }
 }
 
-__global__ void k_bigph_fill(int N, int nf, int isnsp, const int* __restrict__ rp,
-                             const int* __restrict__ ci, const double* __restrict__ va,
-                             const int* __restrict__ prp, int* __restrict__ pci,
-                             double* __restrict__ pva, uint8_t* __restrict__ cmask) {
-    THREAD_ELEMS(i, N) {
-        int pos = prp[i];
+// One wave per row.  Lanes write the entries in parallel; the row sum of the isnsp
+// normalisation is accumulated by lane 0 alone, sequentially in ascending column order
+// (recomputing the quotients it sums, so it does not depend on the other lanes' stores).
+__global__ __launch_bounds__(256) void k_bigph_fill(int N, int nf, int isnsp,
+                                                    const int* __restrict__ rp,
+                                                    const int* __restrict__ ci,
+                                                    const double* __restrict__ va,
+                                                    const int* __restrict__ prp,
+                                                    int* __restrict__ pci, double* __restrict__ pva,
+                                                    uint8_t* __restrict__ cmask) {
+    WAVE_ROWS(i, N) {
+        const int pos0 = prp[i];
         if (i >= nf) {
-            pci[pos] = i - nf;
-            pva[pos] = 1.0;
-            cmask[i] = 1;
+            if (lane == 0) {
+                pci[pos0] = i - nf;
+                pva[pos0] = 1.0;
+                cmask[i] = 1;
+            }
             continue;
         }
-        cmask[i] = 0;
+        const int b = rp[i], e = rp[i + 1];
+        // the diagonal, and the first entry of the C block (columns ascend: a suffix)
         double dii = 0.0;
-        for (int t = rp[i]; t < rp[i + 1]; ++t)
-            if (ci[t] == i) dii = va[t];
-        const double nd = -dii;
-        const int start = pos;
-        for (int t = rp[i]; t < rp[i + 1]; ++t) {
+        int first = e;
+        for (int t = b + lane; t < e; t += 64) {
             const int j = ci[t];
-            if (j >= nf) {
-                pci[pos] = j - nf;
-                pva[pos] = va[t] / nd;
-                ++pos;
-            }
+            if (j == i) dii = va[t];
+            if (j >= nf) first = min(first, t);
         }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            dii += __shfl_xor(dii, d);  // one lane holds it
+            first = min(first, __shfl_xor(first, d));
+        }
+        const double nd = -dii;
+        double s = 1.0;
         if (isnsp == 1) {
-            double s = 0.0;
-            for (int e = start; e < pos; ++e) s = s + pva[e];
-            for (int e = start; e < pos; ++e) pva[e] = pva[e] / s;
+            double acc = 0.0;
+            if (lane == 0)
+                for (int t = first; t < e; ++t) acc = acc + va[t] / nd;
+            s = __shfl(acc, 0);
         }
+        for (int t = first + lane; t < e; t += 64) {
+            const double w = va[t] / nd;
+            pci[pos0 + (t - first)] = ci[t] - nf;
+            pva[pos0 + (t - first)] = isnsp == 1 ? w / s : w;
+        }
+        if (lane == 0) cmask[i] = 0;
     }
 }
 
@@ -429,7 +449,7 @@ __global__ void k_bigph_fill(int N, int nf, int isnsp, const int* __restrict__ r
 // dense coarse rows in LDS: acc1 = W1(i,:) = Afc(i,:)/(-a_ii), acc2 = W2(i,:) =
 // sum_k X(i,k) W1(k,:) with X = ((-Dff)\(Aff.*(I+As_FF))), k ascending; the row of
 // W is W1 + 0.5*W2 (the always-true test at transfer.m:54).
-__global__ __launch_bounds__(64) void k_build_W(int N, int Nc, const int* __restrict__ rp,
+__global__ __launch_bounds__(256) void k_build_W(int N, int Nc, const int* __restrict__ rp,
                                                 const int* __restrict__ ci,
                                                 const double* __restrict__ va,
                                                 const double* __restrict__ diag,
@@ -442,23 +462,24 @@ __global__ __launch_bounds__(64) void k_build_W(int N, int Nc, const int* __rest
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* acc2 = reinterpret_cast<double*>(smem_raw);
     double* acc1 = acc2 + Nc;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, T = blockDim.x;  // 64 or 256 threads per row
+    __shared__ int wcnt[4];
     for (int i = blockIdx.x; i < N; i += gridDim.x) {
         double* drow = dense + (size_t)i * Nc;
         if (isC[i]) {  // identity row of P = [W; I]
             const int me = cidx[i];
-            for (int c = lane; c < Nc; c += 64) drow[c] = (c == me) ? 1.0 : 0.0;
+            for (int c = lane; c < Nc; c += T) drow[c] = (c == me) ? 1.0 : 0.0;
             if (lane == 0) rowcnt[i] = 1;
             continue;
         }
-        for (int c = lane; c < Nc; c += 64) {
+        for (int c = lane; c < Nc; c += T) {
             acc1[c] = 0.0;
             acc2[c] = 0.0;
         }
         __syncthreads();
         const double ndi = -diag[i];
         const int b = rp[i], e = rp[i + 1];
-        for (int t = b + lane; t < e; t += 64) {
+        for (int t = b + lane; t < e; t += T) {
             const int j = ci[t];
             if (isC[j]) acc1[cidx[j]] = va[t] / ndi;
         }
@@ -467,7 +488,7 @@ __global__ __launch_bounds__(64) void k_build_W(int N, int Nc, const int* __rest
             if (isF[k] && (k == i || strong[t])) {
                 const double x = va[t] / ndi;
                 const double ndk = -diag[k];
-                for (int u = rp[k] + lane; u < rp[k + 1]; u += 64) {
+                for (int u = rp[k] + lane; u < rp[k + 1]; u += T) {
                     const int j = ci[u];
                     if (isC[j]) {
                         const double w1 = va[u] / ndk;
@@ -481,7 +502,7 @@ __global__ __launch_bounds__(64) void k_build_W(int N, int Nc, const int* __rest
         }
         __syncthreads();
         int nz = 0;
-        for (int c = lane; c < Nc; c += 64) {
+        for (int c = lane; c < Nc; c += T) {
             const double half = 0.5 * acc2[c];
             const double v = acc1[c] + half;
             drow[c] = v;
@@ -489,18 +510,29 @@ __global__ __launch_bounds__(64) void k_build_W(int N, int Nc, const int* __rest
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d);
-        if (lane == 0) rowcnt[i] = nz;
+        if ((lane & 63) == 0) wcnt[lane >> 6] = nz;
+        __syncthreads();
+        if (lane == 0) {
+            int tot = 0;
+            for (int w = 0; w < (T >> 6); ++w) tot += wcnt[w];
+            rowcnt[i] = tot;
+        }
         __syncthreads();
     }
 }
 
 // D = diag(W*1); W = D\W on the F rows (transfer.m:60-62)
-__global__ void k_row_normalize(int N, const uint8_t* __restrict__ isF,
-                                const int* __restrict__ prp, double* __restrict__ pva) {
-    THREAD_ELEMS(i, N) if (isF[i]) {
-        double s = 0.0;
-        for (int e = prp[i]; e < prp[i + 1]; ++e) s = s + pva[e];
-        for (int e = prp[i]; e < prp[i + 1]; ++e) pva[e] = pva[e] / s;
+__global__ __launch_bounds__(256) void k_row_normalize(int N, const uint8_t* __restrict__ isF,
+                                                       const int* __restrict__ prp,
+                                                       double* __restrict__ pva) {
+    WAVE_ROWS(i, N) {
+        if (!isF[i]) continue;
+        const int b = prp[i], e = prp[i + 1];
+        double acc = 0.0;
+        if (lane == 0)
+            for (int t = b; t < e; ++t) acc = acc + pva[t];  // ascending columns, sequential
+        const double s = __shfl(acc, 0);
+        for (int t = b + lane; t < e; t += 64) pva[t] = pva[t] / s;
     }
 }
 
@@ -552,7 +584,7 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         int* rowlen = tmp.alloc<int>((size_t)N + 1);
         int* bad = tmp.alloc<int>(1);
         IPD_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(k_bigph_count, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N, nf,
+        hipLaunchKernelGGL(k_bigph_count, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, nf,
                            A.rp, A.ci, rowlen, bad);
         IPD_KERNEL_CHECK();
         P.rp = dst.alloc<int>((size_t)N + 1);
@@ -562,7 +594,7 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
                     "transfer: bigph level 1 needs a diagonal Aff block (transfer.m:20-21)");
         P.ci = dst.alloc<int>((size_t)P.nnz);
         P.va = dst.alloc<double>((size_t)P.nnz);
-        hipLaunchKernelGGL(k_bigph_fill, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N, nf,
+        hipLaunchKernelGGL(k_bigph_fill, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, nf,
                            o.isnsp, A.rp, A.ci, A.va, P.rp, P.ci, P.va, cmask);
         IPD_KERNEL_CHECK();
     } else {                                                                 // transfer.m:41-63
@@ -606,7 +638,8 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_build_W, dim3(std::min(N, 16384)), dim3(64), (size_t)Nc * 16,
+        const int bw_threads = (double)A.nnz / std::max(N, 1) >= 96.0 ? 256 : 64;
+        hipLaunchKernelGGL(k_build_W, dim3(std::min(N, 16384)), dim3(bw_threads), (size_t)Nc * 16,
                            ctx->stream, N, Nc, A.rp, A.ci, A.va, diag, strong, isC, isF, cidx, dense,
                            rowcnt);
         IPD_KERNEL_CHECK();
@@ -619,7 +652,7 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
                            dense, P.rp, P.ci, P.va);
         IPD_KERNEL_CHECK();
         if (o.isnsp == 1) {                                                  // :60-62
-            hipLaunchKernelGGL(k_row_normalize, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N,
+            hipLaunchKernelGGL(k_row_normalize, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N,
                                isF, P.rp, P.va);
             IPD_KERNEL_CHECK();
         }

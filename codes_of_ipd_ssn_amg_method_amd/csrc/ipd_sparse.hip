@@ -305,26 +305,28 @@ void csr_spmv(ipd_ctx* ctx, const Csr& A, const double* x, double* y) {
 // bit-identical to a sequential Gustavson product.  The dense row goes to a
 // scratch matrix; a second kernel compacts rows (exact zeros dropped, as
 // MATLAB's sparse mtimes does).
-__global__ __launch_bounds__(64) void k_spgemm_rows(int nr, int nc, const int* __restrict__ xrp,
-                                                    const int* __restrict__ xci,
-                                                    const double* __restrict__ xva,
-                                                    const int* __restrict__ yrp,
-                                                    const int* __restrict__ yci,
-                                                    const double* __restrict__ yva,
-                                                    double* __restrict__ dense,
-                                                    int* __restrict__ rowcnt) {
+__global__ __launch_bounds__(256) void k_spgemm_rows(int nr, int nc, const int* __restrict__ xrp,
+                                                     const int* __restrict__ xci,
+                                                     const double* __restrict__ xva,
+                                                     const int* __restrict__ yrp,
+                                                     const int* __restrict__ yci,
+                                                     const double* __restrict__ yva,
+                                                     double* __restrict__ dense,
+                                                     int* __restrict__ rowcnt) {
+    // blockDim.x = 64 (short rows of Y) or 256 (long rows): more lanes per inner step
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int wcnt[4];
     double* acc = reinterpret_cast<double*>(smem_raw);
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, T = blockDim.x;
     for (int i = blockIdx.x; i < nr; i += gridDim.x) {
-        for (int j = lane; j < nc; j += 64) acc[j] = 0.0;
+        for (int j = tid; j < nc; j += T) acc[j] = 0.0;
         __syncthreads();
         const int xb = xrp[i], xe = xrp[i + 1];
         for (int e = xb; e < xe; ++e) {
             const int k = xci[e];
             const double a = xva[e];
             const int yb = yrp[k], ye = yrp[k + 1];
-            for (int t = yb + lane; t < ye; t += 64) {
+            for (int t = yb + tid; t < ye; t += T) {
                 const int j = yci[t];
                 const double prod = a * yva[t];
                 acc[j] = acc[j] + prod;
@@ -333,14 +335,20 @@ __global__ __launch_bounds__(64) void k_spgemm_rows(int nr, int nc, const int* _
         }
         int nz = 0;
         double* drow = dense + (size_t)i * nc;
-        for (int j = lane; j < nc; j += 64) {
+        for (int j = tid; j < nc; j += T) {
             const double v = acc[j];
             drow[j] = v;
             nz += (v != 0.0);
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d);
-        if (lane == 0) rowcnt[i] = nz;
+        if ((tid & 63) == 0) wcnt[tid >> 6] = nz;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < (T >> 6); ++w) tot += wcnt[w];
+            rowcnt[i] = tot;
+        }
         __syncthreads();
     }
 }
@@ -395,8 +403,9 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_spgemm_rows, dim3(std::min(nr, 16384)), dim3(64), lds, ctx->stream, nr,
-                           nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense, rowcnt);
+        const int threads = (Y.nr > 0 && (double)Y.nnz / Y.nr >= 96.0) ? 256 : 64;
+        hipLaunchKernelGGL(k_spgemm_rows, dim3(std::min(nr, 16384)), dim3(threads), lds, ctx->stream,
+                           nr, nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense, rowcnt);
         IPD_KERNEL_CHECK();
     }
     exclusive_scan_i32(ctx, rowcnt, out.rp, nr);
