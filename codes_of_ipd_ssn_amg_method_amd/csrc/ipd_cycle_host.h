@@ -161,6 +161,10 @@ void amg_prepare_levels(ipd_amg* h) {
         rn.dev.r = lv.r;
         rn.dev.rr = lv.rr;
         rn.staged = N <= STAGE_MAX ? 1 : 0;
+        {
+            const char* ns = std::getenv("IPD_NO_STAGE");
+            if (ns && ns[0] == '1') rn.staged = 0;
+        }
         build_padded(ctx, ar, lv.A, rows_per_launch, cu, &rn.dev);
     }
     for (int k = 1; k < h->J; ++k) {
