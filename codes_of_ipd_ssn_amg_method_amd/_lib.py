@@ -56,6 +56,32 @@ class ipd_prob(Structure):
                 ("phi", POINTER(c_double))]
 
 
+class ipd_apd_data(Structure):
+    _fields_ = [("cls", c_int32), ("m", c_int64), ("n", c_int64), ("c", POINTER(c_double)),
+                ("r", POINTER(c_double)), ("l", POINTER(c_double)), ("p", POINTER(c_double)),
+                ("q", POINTER(c_double)), ("gama", POINTER(c_double)), ("gama_scalar", c_double),
+                ("mu", c_double), ("phi", POINTER(c_double))]
+
+
+class ipd_apd_opts(Structure):
+    _fields_ = [("maxit", c_int32), ("kkt_tol", c_double), ("ssn_it", c_int32),
+                ("ssn_tol1", c_double), ("nu", c_double), ("delta", c_double),
+                ("ll_max", c_int32), ("prob", c_int32)]
+
+
+class ipd_ssn_rec(Structure):
+    _fields_ = [("k", c_int32), ("ssn_it", c_int32), ("ll", c_int32), ("itamg", c_int32),
+                ("E", c_int64), ("info0", c_int64), ("info1", c_int64), ("Fk_norm", c_double),
+                ("resamg", c_double), ("bk1", c_double), ("tk", c_double)]
+
+
+class ipd_apd_result(Structure):
+    _fields_ = [("converged", c_int32), ("k", c_int32), ("fval", c_double),
+                ("kkt", c_double * 4), ("rr", c_double), ("sum_amg", c_int64),
+                ("total_amg", c_int64), ("fail_amg", c_int64), ("max_amg", c_int64),
+                ("restarts", c_int32), ("nrec", c_int64)]
+
+
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -76,6 +102,8 @@ lib.ipd_amg_destroy.restype = None
 lib.ipd_dmat_destroy.restype = None
 lib.ipd_amg_opts_init.restype = None
 lib.ipd_pcg_opts_init.restype = None
+lib.ipd_apd_opts_init.restype = None
+lib.ipd_apd_destroy.restype = None
 
 # every symbol the header declares (tests check that they all resolve)
 EXPORTS = [
@@ -91,6 +119,9 @@ EXPORTS = [
     "ipd_ax_dev", "ipd_aty_dev", "ipd_asat_dev", "ipd_amg_setup_dev", "ipd_amg_solve_dev",
     "ipd_hybrid_amg_dev", "ipd_amg_bench_cycles", "ipd_amg_bench_sweeps", "ipd_amg_cycle_bytes", "ipd_comm_get_unique_id",
     "ipd_comm_init", "ipd_comm_finalize", "ipd_amg_bench_cycles_sharded",
+    "ipd_apd_opts_init", "ipd_apd_create", "ipd_apd_destroy", "ipd_apd_warmup",
+    "ipd_apd_set_state", "ipd_apd_get_state", "ipd_apd_run", "ipd_apd_history",
+    "ipd_apd_records", "ipd_apd_begin", "ipd_apd_eval", "ipd_apd_bench_eval",
 ]
 
 

@@ -27,7 +27,8 @@ from ._lib import CscIn, IpdError, MatlabRand, bptr, check, csc_out_to_scipy, dp
 __all__ = [
     "Ax", "Aty", "ASAt", "invAAt", "invHHt", "strength", "cf_split", "mis_set", "transfer",
     "Class_AMG", "AMGHierarchy", "MG_Vcycle", "MG_Wcycle", "PCG", "components", "Hybrid_AMG",
-    "AMG4POT", "MatlabRand", "IpdError", "amg_options",
+    "AMG4POT", "MatlabRand", "IpdError", "amg_options", "APDWorkspace", "warmup_class1",
+    "warmup_class2", "APD_SsN_Class1", "APD_SsN_Class2",
 ]
 
 
@@ -376,3 +377,217 @@ def AMG4POT(prob_data: dict, amg_options: dict, str_: str = "amg", rng: MatlabRa
     check(lib.ipd_amg4pot(_h(), byref(s), byref(o), rng.handle, dptr(zeta), byref(it), byref(res),
                           iptr(info)))
     return zeta, int(it.value), float(res.value), info
+
+
+# ---------------------------------------------------------------------------
+# L5: drivers and warm starts
+# ---------------------------------------------------------------------------
+class APDWorkspace:
+    """The workspace of ``Class1/APD_SsN_Class1.m`` / ``Class2/APD_SsN_Class2.m`` in HBM.
+
+    ``cls=1``: ``c, r, l, p, q, gama`` as loaded from ``InputData/data1-*.mat`` (``gama`` scalar,
+    ``inf`` allowed, or an mn-vector); ``cls=2``: ``c (= C(:)), r, l, p, q, mu, phi`` of
+    ``data4-*.mat``.  The scripts' variables are reachable as attributes/methods: ``state()``
+    -> ``(uk, vk, lk, bk)``, ``history()`` -> ``fxk, KKT_xk, KKT_lk[, KKT_yk, KKT_zk],
+    SsN_itnum``, ``records()`` -> what the scripts print per Newton step.
+    """
+
+    def __init__(self, cls, c, r, l, p, q, gama=np.inf, mu=0.0, phi=None):
+        self.cls = int(cls)
+        self._keep = [f64(c), f64(r), f64(l), f64(p), f64(q)]
+        c_, r_, l_, p_, q_ = self._keep
+        m, n = p_.size, q_.size
+        if l_.size != m or r_.size != n or c_.size != m * n:
+            raise ValueError("APDWorkspace: need length(l)=length(p)=m, length(r)=length(q)=n, "
+                             "length(c)=m*n")
+        d = L.ipd_apd_data()
+        d.cls, d.m, d.n = self.cls, m, n
+        d.c, d.r, d.l, d.p, d.q = dptr(c_), dptr(r_), dptr(l_), dptr(p_), dptr(q_)
+        d.mu = float(mu)
+        d.gama_scalar = np.inf
+        if self.cls == 1:
+            if np.ndim(gama) == 0 or np.size(gama) == 1:
+                d.gama_scalar = float(np.asarray(gama).reshape(-1)[0])
+            else:
+                g = f64(gama)
+                if g.size != m * n:
+                    raise ValueError("gama must be a scalar or an m*n vector")
+                self._keep.append(g)
+                d.gama = dptr(g)
+        else:
+            if phi is None:
+                raise ValueError("class 2 needs phi")
+            ph = f64(phi)
+            if ph.size != m * n:
+                raise ValueError("phi must have m*n entries")
+            self._keep.append(ph)
+            d.phi = dptr(ph)
+        self.m, self.n = m, n
+        self.M = m + n
+        self.L = self.M + (1 if self.cls == 2 else 0)
+        self.U = m * n + (self.M if self.cls == 2 else 0)
+        self.handle = c_void_p()
+        check(lib.ipd_apd_create(_h(), byref(d), byref(self.handle)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib.ipd_apd_destroy(self.handle)
+            self.handle = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- warm start -----------------------------------------------------------
+    def warmup(self, res=None, maxit=None):
+        """``warmup_class1.m:3-20`` nargin rules: no res -> (1e-1, inf); no maxit -> inf."""
+        if res is None:
+            res, maxit = 1e-1, np.inf
+        elif maxit is None:
+            maxit = np.inf
+        mi = -1 if np.isinf(maxit) else int(maxit)
+        check(lib.ipd_apd_warmup(self.handle, c_double(float(res)), c_int64(mi)))
+        u, _, lam, _ = self.state()
+        return u, lam
+
+    # -- workspace ------------------------------------------------------------
+    def set_state(self, u=None, v=None, lam=None, bk=1.0):
+        u_ = f64(u) if u is not None else None
+        v_ = f64(v) if v is not None else None
+        l_ = f64(lam) if lam is not None else None
+        for a, size, name in ((u_, self.U, "u"), (v_, self.U, "v"), (l_, self.L, "lam")):
+            if a is not None and a.size != size:
+                raise ValueError(f"{name} must have {size} entries")
+        check(lib.ipd_apd_set_state(self.handle, dptr(u_) if u_ is not None else None,
+                                    dptr(v_) if v_ is not None else None,
+                                    dptr(l_) if l_ is not None else None, c_double(float(bk))))
+
+    def state(self):
+        u, v, lam = np.empty(self.U), np.empty(self.U), np.empty(self.L)
+        bk = c_double()
+        check(lib.ipd_apd_get_state(self.handle, dptr(u), dptr(v), dptr(lam), byref(bk)))
+        return u, v, lam, bk.value
+
+    # -- the loop -------------------------------------------------------------
+    def options(self, **kw) -> L.ipd_apd_opts:
+        o = L.ipd_apd_opts()
+        lib.ipd_apd_opts_init(c_int32(self.cls), byref(o))
+        for key, val in kw.items():
+            setattr(o, key, val)
+        return o
+
+    def run(self, amg_options: dict, rng: MatlabRand | None = None, iters: int | None = None,
+            **opts) -> dict:
+        o = self.options(**opts)
+        ao = _opts_struct(amg_options)
+        rng = rng or MatlabRand()
+        res = L.ipd_apd_result()
+        check(lib.ipd_apd_run(self.handle, byref(o), byref(ao), rng.handle,
+                              c_int32(o.maxit if iters is None else int(iters)), byref(res)))
+        return dict(converged=bool(res.converged), k=res.k, fval=res.fval, kkt=list(res.kkt),
+                    rr=res.rr, SumAMG=res.sum_amg, TotalAMG=res.total_amg, FailAMG=res.fail_amg,
+                    MaxAMG=res.max_amg, restarts=res.restarts, nrec=res.nrec)
+
+    def history(self) -> dict:
+        names = ["fxk", "KKT_xk", "KKT_lk", "KKT_yk", "KKT_zk", "SsN_itnum"]
+        out = {}
+        for which, name in enumerate(names):
+            if self.cls == 1 and name in ("KKT_yk", "KKT_zk"):
+                continue
+            cnt = c_int64()
+            check(lib.ipd_apd_history(self.handle, c_int32(which), None, c_int64(0), byref(cnt)))
+            buf = np.empty(max(cnt.value, 1))
+            check(lib.ipd_apd_history(self.handle, c_int32(which), dptr(buf), c_int64(cnt.value),
+                                      byref(cnt)))
+            out[name] = buf[:cnt.value].copy()
+        return out
+
+    def records(self) -> list:
+        cnt = c_int64()
+        check(lib.ipd_apd_records(self.handle, None, c_int64(0), byref(cnt)))
+        arr = (L.ipd_ssn_rec * max(cnt.value, 1))()
+        check(lib.ipd_apd_records(self.handle, arr, c_int64(cnt.value), byref(cnt)))
+        keys = [f[0] for f in L.ipd_ssn_rec._fields_]
+        return [{k: getattr(arr[i], k) for k in keys} for i in range(cnt.value)]
+
+    # -- building blocks ------------------------------------------------------
+    def begin(self, k: int):
+        vals = (c_double * 3)()
+        check(lib.ipd_apd_begin(self.handle, c_int32(int(k)), vals))
+        return dict(bk1=vals[0], tk=vals[1], ak=vals[2])
+
+    def eval(self, lam):
+        lam = f64(lam)
+        if lam.size != self.L:
+            raise ValueError(f"lam must have {self.L} entries")
+        s = np.empty(self.m * self.n, np.uint8)
+        t = np.empty(self.M)
+        F = np.empty(self.L)
+        vals = (c_double * 6)()
+        check(lib.ipd_apd_eval(self.handle, dptr(lam), bptr(s), dptr(t) if self.cls == 2 else None,
+                               dptr(F), vals))
+        return dict(s=s.astype(bool), t=(t != 0) if self.cls == 2 else None, Fk=F, bk1=vals[0],
+                    tk=vals[1], ak=vals[2], Fk_norm=vals[3], cFk=vals[4], E=int(vals[5]))
+
+    def bench_eval(self, reps: int = 100):
+        ms, by = c_double(), c_double()
+        check(lib.ipd_apd_bench_eval(self.handle, c_int32(int(reps)), byref(ms), byref(by)))
+        return ms.value, by.value
+
+
+def warmup_class1(c, r, l, p, q, gama, res=None, maxit=None):
+    """``[xk,lk] = warmup_class1(c,r,l,p,q,gama,res,maxit)`` (``Class1/warmup_class1.m:2``)."""
+    if res is not None and maxit is not None and res == 0 and np.isinf(maxit):
+        raise ValueError("res = 0 and maxit = inf")
+    ws = APDWorkspace(1, c, r, l, p, q, gama=gama)
+    try:
+        return ws.warmup(res, maxit)
+    finally:
+        ws.close()
+
+
+def warmup_class2(c, r, l, p, q, mu, phi, res=None, maxit=None):
+    """``[uk,lk] = warmup_class2(c,r,l,p,q,mu,phi,res,maxit)`` (``Class2/warmup_class2.m:1``)."""
+    if res is not None and maxit is not None and res == 0 and np.isinf(maxit):
+        raise ValueError("res = 0 and maxit = inf")
+    ws = APDWorkspace(2, c, r, l, p, q, mu=mu, phi=phi)
+    try:
+        return ws.warmup(res, maxit)
+    finally:
+        ws.close()
+
+
+def _run_script(ws: APDWorkspace, amg_opts: dict, rng, warm, opts) -> dict:
+    try:
+        if warm is not None:
+            ws.warmup(*warm)
+        out = ws.run(amg_opts, rng, **opts)
+        u, v, lam, bk = ws.state()
+        out.update(ws.history())
+        out.update(uk=u, vk=v, lk=lam, bk=bk, records=ws.records())
+        out["xk"] = u[:ws.m * ws.n]
+        return out
+    finally:
+        ws.close()
+
+
+def APD_SsN_Class1(c, r, l, p, q, gama=np.inf, prob=2, rng: MatlabRand | None = None,
+                   amg_opts: dict | None = None, **opts) -> dict:
+    """The script ``Class1/APD_SsN_Class1.m`` with ``inner_solver = 4`` on the workspace it
+    loads (``:27``); returns the variables it leaves behind.  Warm start as ``:53-59``."""
+    amg_opts = amg_opts or dict(retol=1e-11, bigph=1, maxit=30, theta=1 / 4, smoth=5, cycle="w",
+                                isnsp=1, inter=1, guess=None)                          # :87-88
+    warm = (0.0, 100) if prob > 0 else (5e-2, np.inf)                                  # :53-58
+    ws = APDWorkspace(1, c, r, l, p, q, gama=gama)
+    return _run_script(ws, amg_opts, rng, warm, dict(prob=int(prob), **opts))
+
+
+def APD_SsN_Class2(c, r, l, p, q, mu, phi, rng: MatlabRand | None = None,
+                   amg_opts: dict | None = None, **opts) -> dict:
+    """The script ``Class2/APD_SsN_Class2.m`` with ``inner_solver = 4`` (AMG4POT 'amg')."""
+    amg_opts = amg_opts or dict(retol=1e-11, bigph=1, maxit=40, theta=1 / 4, smoth=10, cycle="w",
+                                isnsp=1, inter=1, guess=None)
+    ws = APDWorkspace(2, c, r, l, p, q, mu=mu, phi=phi)
+    return _run_script(ws, amg_opts, rng, (0.0, 100), opts)

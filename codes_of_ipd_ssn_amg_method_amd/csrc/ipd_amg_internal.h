@@ -75,3 +75,17 @@ void amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev, dou
                    int32_t* it, double* rel_res, double* rel_resk, double* rhok);
 void pcg_dev(ipd_ctx* ctx, const Csr& H, const double* e, const double* guess, double tol,
              long long maxit, int precd, double* d, long long* it, double* res, double* resk_host);
+
+// ipd_hybrid.hip: problem-level solvers on device-resident data
+struct HybridOut {
+    int itamg = 0;
+    double resamg = 0.0;
+    long long num_comp = 0, it_num = 0;
+};
+void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
+                    const double* q, int m, int n, double bk1, double tk, const double* z,
+                    const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out);
+void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
+                 const double* q, int m, int n, double bk1, double tk, const double* z,
+                 const uint8_t* s, const double* phi, const AmgOpts& opts, ipd_rng* rng,
+                 double* zeta, HybridOut* out);

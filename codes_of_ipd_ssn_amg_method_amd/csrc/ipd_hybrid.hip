@@ -340,12 +340,6 @@ __global__ __launch_bounds__(256) void k_small_blocks(const int* __restrict__ bo
 // ---------------------------------------------------------------------------
 // Hybrid_AMG
 // ---------------------------------------------------------------------------
-struct HybridOut {
-    int itamg = 0;
-    double resamg = 0.0;
-    long long num_comp = 0, it_num = 0;
-};
-
 static double host_sum(ipd_ctx* ctx, const double* d, int n) {
     std::vector<double> h((size_t)n);
     ctx->fetch(d, h.data(), (size_t)n);
@@ -374,7 +368,7 @@ static void class_amg_on(ipd_ctx* ctx, const Csr& A, const double* f, AmgOpts o,
     *rel_res = rr;
 }
 
-static void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
+void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
                            const double* q, int m, int n, double bk1, double tk, const double* z,
                            const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out) {
     IPD_REQUIRE(rng, IPD_E_ARG, "Hybrid_AMG needs a rand stream");
@@ -543,7 +537,7 @@ __global__ void k_axpby(int n, double a, const double* __restrict__ x, double b,
         out[i] = a * x[i] + b * y[i];
 }
 
-static void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
+void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
                         const double* q, int m, int n, double bk1, double tk, const double* z,
                         const uint8_t* s, const double* phi, const AmgOpts& opts, ipd_rng* rng,
                         double* zeta, HybridOut* out) {

@@ -212,3 +212,7 @@ void kkt_inv_aat(ipd_ctx* ctx, const double* x, const double* p, const double* q
                  double sg1, double sg2, double* y);
 void kkt_inv_hht(ipd_ctx* ctx, const double* v, const double* p, const double* q, int m, int n,
                  double sg, const double* phi, double* y);
+void kkt_inv_hht_pre(ipd_ctx* ctx, const double* v, const double* p, const double* q, int m, int n,
+                     double sg, const double* l, const double* part, int npart, double* y);
+int kkt_phi_consts(ipd_ctx* ctx, const double* phi, const double* p, const double* q, int m, int n,
+                   double* l, double* part);

@@ -501,6 +501,31 @@ __global__ __launch_bounds__(1024) void k_inv_hht_combine(const double* __restri
     if (tid == 0) y[M] = (v2 - lVv) / s;
 }
 
+// invHHt with l = Ax(phi) and the partial sums of ||phi||^2 hoisted out: both depend on the
+// problem only, while the warm start calls invHHt once per iteration (warmup_class2.m:72)
+void kkt_inv_hht_pre(ipd_ctx* ctx, const double* v, const double* p, const double* q, int m, int n,
+                     double sg, const double* l, const double* part, int npart, double* y) {
+    Arena& tmp = *ctx->scratch;
+    const int M = m + n;
+    double* Vl = tmp.alloc<double>((size_t)M);
+    double* Vv1 = tmp.alloc<double>((size_t)M);
+    kkt_inv_aat(ctx, l, p, q, m, n, sg + 1, sg + 1, Vl);
+    kkt_inv_aat(ctx, v, p, q, m, n, sg + 1, sg + 1, Vv1);
+    hipLaunchKernelGGL(k_inv_hht_combine, dim3(1), dim3(1024), 0, ctx->stream, v, l, Vl, Vv1, part,
+                       npart, M, sg, y);
+    IPD_KERNEL_CHECK();
+}
+
+int kkt_phi_consts(ipd_ctx* ctx, const double* phi, const double* p, const double* q, int m, int n,
+                   double* l, double* part /* 1024 doubles */) {
+    const size_t mn = (size_t)m * n;
+    const int npart = (int)std::max<size_t>(1, std::min<size_t>((mn + 255) / 256, 1024));
+    hipLaunchKernelGGL(k_sumsq_partial, dim3(npart), dim3(256), 0, ctx->stream, phi, mn, part);
+    IPD_KERNEL_CHECK();
+    kkt_ax(ctx, phi, p, q, m, n, l);
+    return npart;
+}
+
 void kkt_inv_hht(ipd_ctx* ctx, const double* v, const double* p, const double* q, int m, int n,
                  double sg, const double* phi, double* y) {
     Arena& tmp = *ctx->scratch;

@@ -225,6 +225,91 @@ int ipd_hybrid_amg_dev(ipd_ctx*, const ipd_dmat* H0, const double* t_dev, const 
                        const double* z_dev, const ipd_amg_opts* o, ipd_rng* rng,
                        double* zeta_dev, int32_t* itamg, double* resamg, int64_t info[2]);
 
+/* ---- L5: APD / semismooth-Newton drivers and A-ADMM warm starts ----------- */
+/* SURVEY.md section 8 rows f1/f2.  The reference's drivers are MATLAB *scripts*
+ * (Class1/APD_SsN_Class1.m, Class2/APD_SsN_Class2.m): their boundary is the
+ * workspace they load (`c,r,l,p,q,gama` resp. `C,r,l,p,q,mu,phi`) and the
+ * variables they leave behind (`xk, lk, fxk, KKT_xk, KKT_lk, SsN_itnum,
+ * PCG_itnum, SumAMG, ...`).  `ipd_apd` holds that workspace in HBM; every mn-
+ * sized vector stays on the device for the whole run.                        */
+typedef struct ipd_apd ipd_apd;
+
+typedef struct ipd_apd_data {
+    int32_t cls;          /* 1 = transport-like (Class 1), 2 = partial OT (Class 2)   */
+    int64_t m, n;
+    const double* c;      /* mn, column-major cost                                     */
+    const double* r;      /* n                                                         */
+    const double* l;      /* m                                                         */
+    const double* p;      /* m                                                         */
+    const double* q;      /* n                                                         */
+    const double* gama;   /* class 1: mn upper bounds, or NULL -> gama_scalar          */
+    double gama_scalar;   /* class 1: scalar bound, +Inf allowed (data1-*.mat)         */
+    double mu;            /* class 2: transported mass                                 */
+    const double* phi;    /* class 2: mn                                               */
+} ipd_apd_data;
+
+/* Script constants (APD_SsN_Class1.m:35-36, APD_SsN_Class2.m:35-36).          */
+typedef struct ipd_apd_opts {
+    int32_t maxit;        /* 100                                                       */
+    double kkt_tol;       /* 1e-6                                                      */
+    int32_t ssn_it;       /* 50                                                        */
+    double ssn_tol1;      /* class 1: 1e-11, class 2: 1e-10                            */
+    double nu, delta;     /* 0.2, 0.9                                                  */
+    int32_t ll_max;       /* 500                                                       */
+    int32_t prob;         /* class 1 only: `prob` of :19-23; 3 selects the merit of :186 */
+} ipd_apd_opts;
+void ipd_apd_opts_init(int32_t cls, ipd_apd_opts* o);
+
+/* One record per Newton step: what the reference prints with format `cc`/`bb`
+ * (APD_SsN_Class1.m:91-92,215-236) plus the size of the active set.            */
+typedef struct ipd_ssn_rec {
+    int32_t k, ssn_it, ll, itamg;
+    int64_t E, info0, info1;
+    double Fk_norm, resamg, bk1, tk;
+} ipd_ssn_rec;
+
+typedef struct ipd_apd_result {
+    int32_t converged;    /* `CONV at it = k`                                          */
+    int32_t k;            /* APD iterations done so far                                */
+    double fval;          /* fxk(k+1) = c'*xk                                          */
+    double kkt[4];        /* KKT_xk, KKT_lk, KKT_yk, KKT_zk of the last iterate        */
+    double rr;            /* max relative KKT residual (:265)                          */
+    int64_t sum_amg, total_amg, fail_amg, max_amg;   /* SumAMG ... MaxAMG (:94-97)     */
+    int32_t restarts;
+    int64_t nrec;         /* Newton-step records available through ipd_apd_records     */
+} ipd_apd_result;
+
+int ipd_apd_create(ipd_ctx*, const ipd_apd_data* d, ipd_apd** out);
+void ipd_apd_destroy(ipd_apd* h);
+/* [xk,lk] = warmup_class1(c,r,l,p,q,gama,res,maxit) (Class1/warmup_class1.m:2) and
+ * [uk,lk] = warmup_class2(c,r,l,p,q,mu,phi,res,maxit) (Class2/warmup_class2.m:1):
+ * the result becomes the driver state (xk = vk = xk0, lk = lk0, bk = 1; Class1 :59-60).
+ * maxit < 0 means `inf`; the nargin/res rules of :3-20 are applied.              */
+int ipd_apd_warmup(ipd_apd* h, double res, int64_t maxit);
+/* Workspace access.  u = xk (mn) for class 1, uk = [xk;yk;zk] (mn+n+m) for class 2;
+ * lam = lk (n+m resp. n+m+1).  NULL pointers are skipped.                        */
+int ipd_apd_set_state(ipd_apd* h, const double* u, const double* v, const double* lam, double bk);
+int ipd_apd_get_state(ipd_apd* h, double* u, double* v, double* lam, double* bk);
+/* Runs up to `iters` further APD iterations (`for k = 1:maxit`, Class1 :101-275,
+ * Class2 :95-285) with inner_solver = 4 (Hybrid_AMG resp. AMG4POT 'amg'); stops
+ * early at `CONV` or at opts->maxit.                                              */
+int ipd_apd_run(ipd_apd* h, const ipd_apd_opts* o, const ipd_amg_opts* amg, ipd_rng* rng,
+                int32_t iters, ipd_apd_result* res);
+/* Histories: which = 0 fxk, 1 KKT_xk, 2 KKT_lk, 3 KKT_yk, 4 KKT_zk (k+1 entries),
+ * 5 SsN_itnum (k entries).  Returns the number of entries written in *count.    */
+int ipd_apd_history(const ipd_apd* h, int32_t which, double* out, int64_t cap, int64_t* count);
+int ipd_apd_records(const ipd_apd* h, ipd_ssn_rec* out, int64_t cap, int64_t* count);
+/* Building blocks of one APD iteration, exposed for parity tests and callers that
+ * keep the outer loop: `begin` fixes k and forms ak, bk1, tk, wk, wlk (:113-126);
+ * `eval` evaluates zk = (wk - H'*lam)/tk, s, Fk = bk1*lam - H*prox(zk) - wlk and the
+ * line-search merit cFk (:139-144,182-196) in ONE pass over wk.
+ * vals = {bk1, tk, ak, |Fk|, cFk, E}.                                            */
+int ipd_apd_begin(ipd_apd* h, int32_t k, double vals[3]);
+int ipd_apd_eval(ipd_apd* h, const double* lam, uint8_t* s_out, double* t_out, double* Fk_out,
+                 double vals[6]);
+/* HIP-event timing of `reps` eval passes on the current workspace (bench.py).   */
+int ipd_apd_bench_eval(ipd_apd* h, int32_t reps, double* total_ms, double* bytes_per_pass);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------- */
 /* Runs `cycles` iterations of the Class_AMG loop body (residual, one V/W
  * cycle, norm) on the fixed hierarchy without convergence exit, timed with HIP
