@@ -96,6 +96,49 @@ void ipd_ctx::upload_bytes(void* ddst, const void* hsrc, size_t bytes) {
 
 extern "C" int ipd_version(void) { return IPD_VERSION; }
 
+// ---------------------------------------------------------------------------
+// profiling scopes
+// ---------------------------------------------------------------------------
+#include <chrono>
+static double g_prof_t[PROF_SLOTS];
+static long long g_prof_n[PROF_SLOTS];
+bool ipd_prof_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("IPD_PROFILE");
+        return e && *e && *e != '0';
+    }();
+    return on;
+}
+void ipd_prof_add(int slot, double seconds) {
+    g_prof_t[slot] += seconds;
+    ++g_prof_n[slot];
+}
+static double prof_now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
+ProfScope::ProfScope(ipd_ctx* c, int s) : ctx(c), slot(s) {
+    if (!ipd_prof_enabled()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    t0 = prof_now();
+}
+ProfScope::~ProfScope() {
+    if (!ipd_prof_enabled()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    ipd_prof_add(slot, prof_now() - t0);
+}
+extern "C" int ipd_prof_read(double* seconds, int64_t* calls, int32_t reset) {
+    for (int i = 0; i < PROF_SLOTS; ++i) {
+        if (seconds) seconds[i] = g_prof_t[i];
+        if (calls) calls[i] = g_prof_n[i];
+        if (reset) {
+            g_prof_t[i] = 0.0;
+            g_prof_n[i] = 0;
+        }
+    }
+    return PROF_SLOTS;
+}
+
 extern "C" const char* ipd_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int ipd_ctx_create(int device, ipd_ctx** out) {

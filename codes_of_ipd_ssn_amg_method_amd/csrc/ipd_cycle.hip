@@ -620,13 +620,14 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
     }
 }
 
-// one V or W cycle on r_1 (in L[1].lv.r); the correction ends up in sol_e(c, 1)
-__device__ __forceinline__ void sol_cycle(SolveCtx& c) {
+// one V or W cycle rooted at level k0 on r_{k0} (in L[k0].lv.r); the correction ends up in
+// sol_e(c, k0).  keep0: start from the current iterate of level k0 (MG_Wcycle.m:30).
+__device__ __forceinline__ void sol_cycle(SolveCtx& c, int k0 = 1, bool keep0 = false) {
     const SolveDesc* D = c.D;
     const int J = D->J, nu = D->nu;
     unsigned visited = 0;  // bit k: level k has completed one visit under its current parent
-    int k = 1;
-    bool entering = true, keep = false;
+    int k = k0;
+    bool entering = true, keep = keep0;
     for (int guard = 0; guard < (1 << 22); ++guard) {
         if (entering && k >= D->k_tiny && k > 1) {
             // the whole sub-cycle below here runs in wave 0; 2*nu sweeps per visit leave the
@@ -637,6 +638,7 @@ __device__ __forceinline__ void sol_cycle(SolveCtx& c) {
             }
             __syncthreads();
             c.zeromask &= ~(1u << k);
+            if (k == k0) return;
             entering = false;
             k = k - 1;
             continue;
@@ -649,7 +651,7 @@ __device__ __forceinline__ void sol_cycle(SolveCtx& c) {
                 pcg_block(a, c.red);
                 __syncthreads();
                 c.zeromask &= ~(1u << J);
-                if (J == 1) return;
+                if (J == k0) return;
                 entering = false;
                 k = J - 1;
                 continue;
@@ -690,7 +692,7 @@ __device__ __forceinline__ void sol_cycle(SolveCtx& c) {
             phase_xfer<true>(pa, 0, 1, c.lds, c.xs);
             __syncthreads();
             for (int s = 0; s < nu; ++s) sol_sweep(c, k, true);           // :33-41
-            if (k == 1) return;
+            if (k == k0) return;
             k = k - 1;
         }
     }
@@ -718,28 +720,11 @@ __device__ __forceinline__ void sol_top(SolveCtx& c, const double* b, const doub
     __syncthreads();
 }
 
-// out[0] = it, out[1] = rel_res, out[2] = res0; rel_resk at out[4 ..], rhok at out[4+maxit+2 ..]
-// fixed_cycles > 0: run exactly that many loop bodies without the stopping rules (bench hook)
-template <bool CACHED>
-__global__ __launch_bounds__(BT) void k_solve_small(const SolveDesc* __restrict__ D_global,
-                                                    const double* __restrict__ b, double* xa,
-                                                    double* xb, double* hist, double* out,
-                                                    int fixed_cycles) {
-    __shared__ PhaseLds lds;
-    __shared__ double red[16];
-    extern __shared__ __attribute__((aligned(16))) char dyn_raw[];
-    // dynamic LDS: [ staging vector | descriptor copy | cached levels ]
-    const SolveDesc* D = D_global;
-    SolveDesc* LD = reinterpret_cast<SolveDesc*>(dyn_raw + D->stage_bytes);
-    if (CACHED) {
-        const int* src = reinterpret_cast<const int*>(D);
-        int* dst = reinterpret_cast<int*>(LD);
-        for (int i = threadIdx.x; i < (int)(sizeof(SolveDesc) / 4); i += BT) dst[i] = src[i];
-    }
-    __syncthreads();
-    if (CACHED) {   // Copy the deepest levels into LDS: they are tiny but a W cycle visits level k
-        // 2^(k-1) times, so their phases must not pay global-memory latency.  Every thread
-        // walks the same carve sequence; pointers in the LDS descriptor are patched by thread 0.
+// Copies levels k_lds..J (matrices, transfers, work vectors) into dynamic LDS and patches the
+// LDS descriptor `LD` to point at the copies.  They are tiny, but a W cycle visits level k
+// 2^(k-1) times, so their phases must not pay global-memory latency.  Every thread walks the
+// same carve sequence; pointers are patched by thread 0.
+__device__ __forceinline__ void sol_cache_levels(const SolveDesc* D, SolveDesc* LD, char* dyn_raw) {
         size_t off = (size_t)D->stage_bytes + ((sizeof(SolveDesc) + 15) / 16) * 16;
         auto carve = [&](size_t bytes) {
             char* p = dyn_raw + off;
@@ -837,7 +822,28 @@ __global__ __launch_bounds__(BT) void k_solve_small(const SolveDesc* __restrict_
             if (t0) LD->pcg.work = work;
         }
         __syncthreads();
+}
+
+// out[0] = it, out[1] = rel_res, out[2] = res0; rel_resk at out[4 ..], rhok at out[4+maxit+2 ..]
+// fixed_cycles > 0: run exactly that many loop bodies without the stopping rules (bench hook)
+template <bool CACHED>
+__global__ __launch_bounds__(BT) void k_solve_small(const SolveDesc* __restrict__ D_global,
+                                                    const double* __restrict__ b, double* xa,
+                                                    double* xb, double* hist, double* out,
+                                                    int fixed_cycles) {
+    __shared__ PhaseLds lds;
+    __shared__ double red[16];
+    extern __shared__ __attribute__((aligned(16))) char dyn_raw[];
+    // dynamic LDS: [ staging vector | descriptor copy | cached levels ]
+    const SolveDesc* D = D_global;
+    SolveDesc* LD = reinterpret_cast<SolveDesc*>(dyn_raw + D->stage_bytes);
+    if (CACHED) {
+        const int* src = reinterpret_cast<const int*>(D);
+        int* dst = reinterpret_cast<int*>(LD);
+        for (int i = threadIdx.x; i < (int)(sizeof(SolveDesc) / 4); i += BT) dst[i] = src[i];
     }
+    __syncthreads();
+    if (CACHED) sol_cache_levels(D, LD, dyn_raw);
     SolveCtx c;
     // without cached levels the descriptor stays in global memory: its (uniform) fields
     // are then fetched with scalar loads and live in SGPRs instead of VGPRs
@@ -919,6 +925,48 @@ __global__ __launch_bounds__(BT) void k_solve_small(const SolveDesc* __restrict_
         out[1] = rel_res;
         out[2] = res0;
     }
+}
+
+// Sub-cycle rooted at level k_lds >= 2 of a hierarchy whose upper levels run as multi-workgroup
+// launches: ONE workgroup, every level from the root down cached in LDS.  r_{root} is read from
+// and the correction written to the global vectors the surrounding launches use.
+__global__ __launch_bounds__(BT) void k_subcycle(const SolveDesc* __restrict__ D_global, int keep) {
+    __shared__ PhaseLds lds;
+    __shared__ double red[16];
+    extern __shared__ __attribute__((aligned(16))) char dyn_raw[];
+    const SolveDesc* D = D_global;
+    SolveDesc* LD = reinterpret_cast<SolveDesc*>(dyn_raw + D->stage_bytes);
+    {
+        const int* src = reinterpret_cast<const int*>(D);
+        int* dst = reinterpret_cast<int*>(LD);
+        for (int i = threadIdx.x; i < (int)(sizeof(SolveDesc) / 4); i += BT) dst[i] = src[i];
+    }
+    __syncthreads();
+    sol_cache_levels(D, LD, dyn_raw);
+    const int k0 = D->k_lds, N0 = D->L[k0].lv.N;
+    {
+        double* r = LD->L[k0].lv.r;
+        double* e = LD->L[k0].e;
+        const double* gr = D->L[k0].lv.r;
+        const double* ge = D->L[k0].e;
+        for (int i = threadIdx.x; i < N0; i += BT) {
+            r[i] = gr[i];
+            if (keep) e[i] = ge[i];
+        }
+    }
+    __syncthreads();
+    SolveCtx c;
+    c.D = LD;
+    c.lds = &lds;
+    c.red = red;
+    c.xs = reinterpret_cast<double*>(dyn_raw);
+    c.swapmask = 0;
+    c.zeromask = 0;
+    sol_cycle(c, k0, keep != 0);
+    __syncthreads();
+    const double* res = sol_e(c, k0);
+    double* ge = D->L[k0].e;
+    for (int i = threadIdx.x; i < N0; i += BT) ge[i] = res[i];
 }
 
 #include "ipd_cycle_host.h"

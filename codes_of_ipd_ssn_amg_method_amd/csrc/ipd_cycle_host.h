@@ -36,6 +36,10 @@ struct CycleState {
     size_t solve_lds = 0;
     bool small_ok = false;
     bool solve_cached = false;
+    // single-workgroup sub-cycle rooted at level k_sub (0 = none), see k_subcycle
+    SolveDesc* d_sub = nullptr;
+    int k_sub = 0;
+    size_t sub_lds = 0;
     double* x2 = nullptr;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};  // captured Class_AMG loop bodies (x->x2, x2->x)
     const double* gb = nullptr;                    // right-hand side the graphs were captured for
@@ -230,86 +234,118 @@ void amg_prepare_levels(ipd_amg* h) {
     st->x2 = ar.alloc<double>((size_t)h->L[1].A.nr);
     h->x = ar.alloc<double>((size_t)h->L[1].A.nr);
     h->b = ar.alloc<double>((size_t)h->L[1].A.nr);
-    // ---- single-workgroup solver: eligible when every level is small and stageable ----
+    // ---- single-workgroup kernels -------------------------------------------------------
+    // (a) whole solve in one workgroup when every level is small; (b) otherwise the sub-cycle
+    // below the first level from which everything fits in LDS runs as one launch per visit.
+    auto small_level = [&](int k) {
+        const Level& lv = h->L[k];
+        // one workgroup is one CU: beyond ~1000 short rows per level the multi-launch
+        // path (many CUs per phase) wins again (measured: M = 1000 W-cycle solve 9.5 ms
+        // here vs 17 ms multi-launch; M = 2048: 8.0 ms here vs 5.6 ms multi-launch)
+        return lv.A.nr <= 1024 && lv.A.nnz <= 40000 && (k < 2 || lv.P.nnz <= 40000);
+    };
+    auto r16 = [](size_t b) { return (b + 15) / 16 * 16; };
+    auto fill_desc = [&](SolveDesc* sd) {
+        std::memset(sd, 0, sizeof(SolveDesc));
+        sd->J = h->J;
+        sd->nu = h->opts.smoth;
+        sd->isnsp = h->opts.isnsp;
+        sd->wcycle = h->opts.cycle == 'w';
+        sd->anycycle = (h->opts.cycle == 'w' || h->opts.cycle == 'v');
+        sd->maxit = h->opts.maxit;
+        sd->retol = h->opts.retol;
+        sd->pcg = st->run[(size_t)h->J].pcg;
+        for (int k = 1; k <= h->J; ++k) {
+            SolveLevel& sl = sd->L[k];
+            sl.lv = st->run[(size_t)k].dev;
+            sl.lv.S = 0;  // the single-workgroup kernels walk the CSR arrays only
+            // in one workgroup a row is walked by few lanes: re-pick without widening
+            const Level& lv = h->L[k];
+            {
+                const double avg = (double)lv.A.nnz / std::max(lv.A.nr, 1);
+                int L = 1;
+                while (L < 64 && (double)L * 6.0 < avg) L <<= 1;
+                sl.lv.L = L;
+            }
+            sl.lv.G = 1;
+            sl.e = lv.e;
+            sl.e2 = lv.e2;
+            sl.w = lv.w;
+            sl.nnzA = lv.A.nnz;
+            sl.nnzP = k < h->J ? h->L[k + 1].P.nnz : 0;
+            if (k < h->J) {
+                sl.rest = st->run[(size_t)k].restrict_args;
+                sl.prol = st->run[(size_t)k].prolong_args;
+                for (XferArgs* xa : {&sl.rest, &sl.prol}) {
+                    const double avg = (double)(xa == &sl.rest ? h->L[k + 1].Pt.nnz : h->L[k + 1].P.nnz) /
+                                       std::max(xa->nrows, 1);
+                    int L = 1;
+                    while (L < 64 && (double)L * 6.0 < avg) L <<= 1;
+                    xa->L = L;
+                    xa->G = 1;
+                    xa->staged = 1;
+                    xa->row0 = 0;
+                    xa->row1 = xa->nrows;
+                }
+            }
+        }
+    };
+    // LDS cache plan: deepest levels first, while they fit; returns the first cached level
+    auto plan_lds = [&](size_t stage, size_t* used_out) {
+        size_t used = stage + r16(sizeof(SolveDesc)) + 256;
+        const size_t budget = 150 * 1024;
+        int k_lds = h->J + 1;
+        for (int k = h->J; k >= 1; --k) {
+            const Level& lv = h->L[k];
+            const size_t N = (size_t)lv.A.nr;
+            size_t bytes = r16(4 * (N + 1)) + r16(4 * (size_t)lv.A.nnz) + r16(8 * (size_t)lv.A.nnz) +
+                           7 * r16(8 * N) + 16;
+            if (k < h->J) {
+                const size_t Nc = (size_t)h->L[k + 1].A.nr, np = (size_t)h->L[k + 1].P.nnz;
+                bytes += r16(4 * (Nc + 1)) + r16(4 * (N + 1)) + 2 * (r16(4 * np) + r16(8 * np));
+            }
+            if (k == h->J) bytes += r16(4 * 8 * N);
+            if (used + bytes > budget) break;
+            used += bytes;
+            k_lds = k;
+        }
+        *used_out = used;
+        return k_lds;
+    };
+    auto tiny_from = [&](int k_lds) {   // tiny levels: <= 64 rows, cached, Jacobi (k >= 2)
+        int kt = h->J + 1;
+        const char* nt = std::getenv("IPD_NO_TINY");
+        if (!(nt && nt[0] == '1'))
+            for (int k = h->J; k >= std::max(2, k_lds); --k) {
+                if (h->L[k].A.nr > 64) break;
+                kt = k;
+            }
+        return kt;
+    };
+    static bool attr_set = false;
+    if (!attr_set) {
+        IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subcycle),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        attr_set = true;
+    }
     {
         const char* ns = std::getenv("IPD_NO_SMALL");
         bool ok = !(ns && ns[0] == '1') && h->J <= SOLVE_ML;
         size_t maxlen = 1;
         for (int k = 1; k <= h->J && ok; ++k) {
-            const Level& lv = h->L[k];
-            // one workgroup is one CU: beyond ~1000 short rows per level the multi-launch
-            // path (many CUs per phase) wins again (measured: M = 1000 W-cycle solve 9.5 ms
-            // here vs 17 ms multi-launch; M = 2048: 8.0 ms here vs 5.6 ms multi-launch)
-            ok = ok && lv.A.nr <= 1024 && lv.A.nnz <= 40000;
-            maxlen = std::max(maxlen, (size_t)lv.A.nr);
-            if (k >= 2) ok = ok && lv.P.nnz <= 40000;
+            ok = ok && small_level(k);
+            maxlen = std::max(maxlen, (size_t)h->L[k].A.nr);
         }
         if (ok) {
             std::unique_ptr<SolveDesc> sd(new SolveDesc());
-            std::memset(sd.get(), 0, sizeof(SolveDesc));
-            sd->J = h->J;
-            sd->nu = h->opts.smoth;
-            sd->isnsp = h->opts.isnsp;
-            sd->wcycle = h->opts.cycle == 'w';
-            sd->anycycle = (h->opts.cycle == 'w' || h->opts.cycle == 'v');
-            sd->maxit = h->opts.maxit;
-            sd->retol = h->opts.retol;
-            sd->pcg = st->run[(size_t)h->J].pcg;
-            for (int k = 1; k <= h->J; ++k) {
-                SolveLevel& sl = sd->L[k];
-                sl.lv = st->run[(size_t)k].dev;
-                sl.lv.S = 0;  // the single-workgroup solver walks the CSR arrays only
-                // in one workgroup a row is walked by few lanes: re-pick without widening
-                const Level& lv = h->L[k];
-                if (sl.lv.S == 0) {
-                    const double avg = (double)lv.A.nnz / std::max(lv.A.nr, 1);
-                    int L = 1;
-                    while (L < 64 && (double)L * 6.0 < avg) L <<= 1;
-                    sl.lv.L = L;
-                }
-                sl.lv.G = 1;
-                sl.e = lv.e;
-                sl.e2 = lv.e2;
-                sl.w = lv.w;
-                if (k < h->J) {
-                    sl.rest = st->run[(size_t)k].restrict_args;
-                    sl.prol = st->run[(size_t)k].prolong_args;
-                    for (XferArgs* xa : {&sl.rest, &sl.prol}) {
-                        const double avg = (double)(xa == &sl.rest ? h->L[k + 1].Pt.nnz : h->L[k + 1].P.nnz) /
-                                           std::max(xa->nrows, 1);
-                        int L = 1;
-                        while (L < 64 && (double)L * 6.0 < avg) L <<= 1;
-                        xa->L = L;
-                        xa->G = 1;
-                        xa->staged = 1;
-                        xa->row0 = 0;
-                        xa->row1 = xa->nrows;
-                    }
-                }
-            }
-            // LDS cache plan: deepest levels first, while they fit
-            auto r16 = [](size_t b) { return (b + 15) / 16 * 16; };
+            fill_desc(sd.get());
             const size_t stage = r16(sizeof(double) * maxlen);
-            size_t used = stage + r16(sizeof(SolveDesc)) + 256;
-            const size_t budget = 150 * 1024;
-            int k_lds = h->J + 1;
-            for (int k = h->J; k >= 1; --k) {
-                const Level& lv = h->L[k];
-                SolveLevel& sl = sd->L[k];
-                sl.nnzA = lv.A.nnz;
-                sl.nnzP = k < h->J ? h->L[k + 1].P.nnz : 0;
-                const size_t N = (size_t)lv.A.nr;
-                size_t bytes = r16(4 * (N + 1)) + r16(4 * (size_t)lv.A.nnz) + r16(8 * (size_t)lv.A.nnz) +
-                               7 * r16(8 * N) + 16;
-                if (k < h->J) {
-                    const size_t Nc = (size_t)h->L[k + 1].A.nr, np = (size_t)sl.nnzP;
-                    bytes += r16(4 * (Nc + 1)) + r16(4 * (N + 1)) + 2 * (r16(4 * np) + r16(8 * np));
-                }
-                if (k == h->J) bytes += r16(4 * 8 * N);
-                if (used + bytes > budget) break;
-                used += bytes;
-                k_lds = k;
-            }
+            size_t used = 0;
+            int k_lds = plan_lds(stage, &used);
             {
                 const char* nc = std::getenv("IPD_NO_LDSCACHE");
                 if (nc && nc[0] == '1') {
@@ -319,31 +355,68 @@ void amg_prepare_levels(ipd_amg* h) {
             }
             sd->k_lds = k_lds;
             st->solve_cached = k_lds <= h->J;
-            {   // tiny levels: <= 64 rows, cached, Jacobi (k >= 2)
-                int kt = h->J + 1;
-                const char* nt = std::getenv("IPD_NO_TINY");
-                if (!(nt && nt[0] == '1'))
-                    for (int k = h->J; k >= std::max(2, k_lds); --k) {
-                        if (h->L[k].A.nr > 64) break;
-                        kt = k;
-                    }
-                sd->k_tiny = kt;
-            }
+            sd->k_tiny = tiny_from(k_lds);
             sd->stage_bytes = (int)stage;
             st->solve_lds = used;
-            static bool attr_set = false;
-            if (!attr_set) {
-                IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-                IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-                attr_set = true;
-            }
             st->d_solve = reinterpret_cast<SolveDesc*>(ar.alloc_bytes(sizeof(SolveDesc)));
             ctx->upload_bytes(st->d_solve, sd.get(), sizeof(SolveDesc));
             st->solve_out = ar.alloc<double>(4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2));
             st->small_ok = true;
         }
+    }
+    {
+        const char* ns = std::getenv("IPD_NO_SUBCYCLE");
+        const bool want = !(ns && ns[0] == '1') && !st->small_ok && h->J <= SOLVE_ML && h->J >= 3 &&
+                          (h->opts.cycle == 'w' || h->opts.cycle == 'v');
+        if (want) {
+            // first level from which every level is small ...
+            int k_small = h->J + 1;
+            for (int k = h->J; k >= 2 && small_level(k); --k) k_small = k;
+            if (k_small < h->J) {
+                // ... and everything below it fits in LDS (the stage area holds N_root doubles)
+                for (int kroot = k_small; kroot < h->J; ++kroot) {
+                    const size_t stage = r16(sizeof(double) * (size_t)h->L[kroot].A.nr);
+                    size_t used = 0;
+                    const int k_lds = plan_lds(stage, &used);
+                    if (k_lds > kroot) continue;
+                    std::unique_ptr<SolveDesc> sd(new SolveDesc());
+                    fill_desc(sd.get());
+                    sd->k_lds = kroot;
+                    sd->k_tiny = tiny_from(kroot);
+                    sd->stage_bytes = (int)stage;
+                    // levels kroot..J only: recompute the bytes actually carved
+                    size_t need = stage + r16(sizeof(SolveDesc)) + 256;
+                    {
+                        size_t full = 0;
+                        (void)plan_lds(stage, &full);
+                        // plan_lds may have admitted shallower levels too; count kroot..J only
+                        need = stage + r16(sizeof(SolveDesc)) + 256;
+                        for (int k = h->J; k >= kroot; --k) {
+                            const Level& lv = h->L[k];
+                            const size_t N = (size_t)lv.A.nr;
+                            size_t bytes = r16(4 * (N + 1)) + r16(4 * (size_t)lv.A.nnz) +
+                                           r16(8 * (size_t)lv.A.nnz) + 7 * r16(8 * N) + 16;
+                            if (k < h->J) {
+                                const size_t Nc = (size_t)h->L[k + 1].A.nr, np = (size_t)h->L[k + 1].P.nnz;
+                                bytes += r16(4 * (Nc + 1)) + r16(4 * (N + 1)) + 2 * (r16(4 * np) + r16(8 * np));
+                            }
+                            if (k == h->J) bytes += r16(4 * 8 * N);
+                            need += bytes;
+                        }
+                    }
+                    st->sub_lds = need;
+                    st->k_sub = kroot;
+                    st->d_sub = reinterpret_cast<SolveDesc*>(ar.alloc_bytes(sizeof(SolveDesc)));
+                    ctx->upload_bytes(st->d_sub, sd.get(), sizeof(SolveDesc));
+                    break;
+                }
+            }
+        }
+    }
+    if (const char* dbg = std::getenv("IPD_DEBUG_LEVELS"); dbg && dbg[0] == '1') {
+        std::fprintf(stderr, "[ipd] J=%d small=%d k_sub=%d levels:", h->J, (int)st->small_ok, st->k_sub);
+        for (int k = 1; k <= h->J; ++k) std::fprintf(stderr, " %d/%d", h->L[k].A.nr, h->L[k].A.nnz);
+        std::fprintf(stderr, "\n");
     }
     h->cyc = std::shared_ptr<CycleState>(st.release());
 }
@@ -518,6 +591,14 @@ void amg_cycle(ipd_amg* h, int k, int isnsp, bool wcycle, bool keep_e) {
     Level& lv = h->L[k];
     LevelRun& rn = st->run[(size_t)k];
     const int cu = st->num_cu;
+    if (st->k_sub == k) {  // everything from here down: one workgroup, LDS-resident (replicated)
+        flush_fused(ctx, st);
+        hipLaunchKernelGGL(k_subcycle, dim3(1), dim3(BT), st->sub_lds, ctx->stream,
+                           (const SolveDesc*)st->d_sub, keep_e ? 1 : 0);
+        IPD_KERNEL_CHECK();
+        rn.e_zero = false;
+        return;
+    }
     if (k == h->J) {                                   // MG_Vcycle.m:43 / MG_Wcycle.m:44
         PcgArgs a = rn.pcg;                            // replicated on every rank
         a.rhs = lv.r;

@@ -749,6 +749,7 @@ ApdScal fetch_scal(ipd_apd* h) {
 
 // wk, wlk of iteration k                                       Class1 :113-126, Class2 :110-120
 void apd_begin(ipd_apd* h, int k) {
+    ProfScope ps(h->ctx, PROF_BEGIN_END);
     const double kk = (double)k;
     h->ak = std::sqrt(kk * kk * h->bk);
     h->bk1 = h->bk / (1.0 + h->ak);
@@ -784,6 +785,7 @@ void apd_begin(ipd_apd* h, int k) {
 // one pass at lam_base (+ step*zeta): F -> F_out, multiplier -> lam_out, mask -> h->s
 EvalRes apd_eval(ipd_apd* h, const double* lam_base, const double* zeta, double step,
                  double* lam_out, double* F_out, const double* F_old) {
+    ProfScope ps(h->ctx, PROF_EVAL);
     OpEval op;
     op.P = h->P;
     op.w = h->w;
@@ -822,6 +824,7 @@ EvalRes apd_eval(ipd_apd* h, const double* lam_base, const double* zeta, double 
 // uk1/vk1 (from_w) and the KKT residuals of the iterate at multiplier `lam`
 void apd_end(ipd_apd* h, bool from_w, const double* src_u, const double* lam, double out_kkt[4],
              double* fx) {
+    ProfScope ps(h->ctx, PROF_BEGIN_END);
     const Lam L{lam, nullptr, 0.0};
     if (from_w) {
         OpEnd<true> op;
@@ -936,7 +939,10 @@ void apd_iterate(ipd_apd* h, const ipd_apd_opts& o, const AmgOpts& amg, ipd_rng*
         HybridOut ho;
         {
             CallScope scope(ctx);
-            kkt_asat(ctx, *ctx->scratch, h->s, h->p, h->q, h->m, h->n, &H0);       // :142
+            {
+                ProfScope ps(ctx, PROF_ASAT);
+                kkt_asat(ctx, *ctx->scratch, h->s, h->p, h->q, h->m, h->n, &H0);   // :142
+            }
             hipLaunchKernelGGL(k_negate, dim3(cdiv(h->L, 256)), dim3(256), 0, ctx->stream, h->L,
                                (const double*)F_old, h->negF);                     // z = -Fk_old
             IPD_KERNEL_CHECK();

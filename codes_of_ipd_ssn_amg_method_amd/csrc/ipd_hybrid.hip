@@ -360,10 +360,17 @@ static void class_amg_on(ipd_ctx* ctx, const Csr& A, const double* f, AmgOpts o,
     for (double& v : g) v = gscale * v;
     double* dg = ctx->scratch->alloc<double>((size_t)N);
     ctx->upload(dg, g.data(), (size_t)N);
-    std::unique_ptr<ipd_amg, void (*)(ipd_amg*)> h(amg_setup(ctx, A, o, rng), ipd_amg_destroy);
+    std::unique_ptr<ipd_amg, void (*)(ipd_amg*)> h(nullptr, ipd_amg_destroy);
+    {
+        ProfScope ps(ctx, PROF_AMG_SETUP);
+        h.reset(amg_setup(ctx, A, o, rng));
+    }
     int32_t its = 0;
     double rr = 0.0;
-    amg_solve_dev(h.get(), f, dg, u_out, &its, &rr, nullptr, nullptr);
+    {
+        ProfScope ps(ctx, PROF_AMG_SOLVE);
+        amg_solve_dev(h.get(), f, dg, u_out, &its, &rr, nullptr, nullptr);
+    }
     *it = its;
     *rel_res = rr;
 }
@@ -377,7 +384,10 @@ void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const doub
     const int N0 = 100;                                                   // Hybrid_AMG.m:51
     Arena& tmp = *ctx->scratch;
     Csr Ae;
-    build_Ae(ctx, tmp, H0, tdiag, p, q, m, n, bk1, tk, &Ae);            // :17-24
+    {
+        ProfScope ps(ctx, PROF_BUILD_AE);
+        build_Ae(ctx, tmp, H0, tdiag, p, q, m, n, bk1, tk, &Ae);        // :17-24
+    }
     double* f = tmp.alloc<double>((size_t)M);
     double* u = tmp.alloc<double>((size_t)M);
     double* dK = tmp.alloc<double>((size_t)M);
@@ -388,7 +398,10 @@ void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const doub
     IPD_HIP(hipMemsetAsync(u, 0, sizeof(double) * (size_t)M, ctx->stream));
     // components of A0 = Q0*H0*Q0: same pattern as H0 (qp has no zeros)     :27
     Components cc;
-    find_components(ctx, H0, &cc);
+    {
+        ProfScope ps(ctx, PROF_COMPONENTS);
+        find_components(ctx, H0, &cc);
+    }
     out->num_comp = cc.ncomp;
     std::vector<double> hdK;
     if (tdiag) {
@@ -473,6 +486,7 @@ void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const doub
             maxnb = std::max(maxnb, cc.sizes[k]);
         }
         if (!nodes.empty()) {
+            ProfScope ps(ctx, PROF_SMALL_BLOCKS);
             const int nblk = (int)boff.size() - 1;
             int* d_boff = tmp.alloc<int>(boff.size());
             int* d_nodes = tmp.alloc<int>(nodes.size());

@@ -181,6 +181,20 @@ int comm_rank(const ipd_ctx* ctx);
 int comm_size(const ipd_ctx* ctx);
 void comm_allgather_inplace(ipd_ctx* ctx, double* const* bases, int nvec, int count);
 
+// Wall-clock attribution for tools/bench_driver.py (IPD_PROFILE=1): a scope synchronises the
+// stream at both ends, so it is off unless asked for.
+enum ProfSlot { PROF_ASAT, PROF_BUILD_AE, PROF_COMPONENTS, PROF_AMG_SETUP, PROF_AMG_SOLVE,
+                PROF_SMALL_BLOCKS, PROF_EVAL, PROF_BEGIN_END, PROF_SLOTS };
+bool ipd_prof_enabled();
+void ipd_prof_add(int slot, double seconds);
+struct ProfScope {
+    ipd_ctx* ctx;
+    int slot;
+    double t0 = 0.0;
+    ProfScope(ipd_ctx* c, int s);
+    ~ProfScope();
+};
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------

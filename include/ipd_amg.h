@@ -325,6 +325,12 @@ int ipd_amg_bench_sweeps(ipd_amg* h, int k, int reps, double* total_ms,
 /* SURVEY 8d byte model of the hierarchy: per-level S(A_k), S(P_k), ...       */
 int ipd_amg_cycle_bytes(const ipd_amg* h, double* bytes_per_cycle);
 
+/* Wall-clock attribution of the driver's phases when IPD_PROFILE=1 (each phase is then
+ * bracketed by stream synchronisations).  Slots: 0 ASAt, 1 build Ae, 2 components,
+ * 3 AMG setup, 4 AMG solve, 5 small-block direct solves, 6 evaluation passes,
+ * 7 begin/end passes.  Returns the number of slots.                             */
+int ipd_prof_read(double* seconds, int64_t* calls, int32_t reset);
+
 /* ---- multi-GPU row-block sharding (RCCL over xGMI) ----------------------- */
 #define IPD_COMM_ID_BYTES 128
 int ipd_comm_get_unique_id(uint8_t id[IPD_COMM_ID_BYTES]);

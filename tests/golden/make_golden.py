@@ -117,6 +117,45 @@ def synthetic():
         print("synth", name, "it", rec["it"], "info", rec["info"])
 
 
+def bundled_driver_runs(ref_root):
+    """The reference's two bundled problems (data files, read with scipy.io.loadmat) as npz
+    inputs, and the histories the restated drivers (oracle/drivers.py, inner_solver = 4)
+    produce on them -- the expected values of tests/test_gpu_driver_golden.py."""
+    d = scipy.io.loadmat(os.path.join(ref_root, "Class1", "InputData", "data1-500.mat"))
+    g = lambda k: np.asarray(d[k], dtype=np.float64).ravel()
+    c, r, l, p, q, gama = g("c"), g("r"), g("l"), g("p"), g("q"), g("gama")
+    assert np.all(p == 1) and np.all(q == 1) and np.all(np.isinf(gama))
+    np.savez_compressed(os.path.join(HERE, "data1_500.npz"), c=c, r=r, l=l)
+    x0, l0 = D.warmup_class1(c, r, l, p, q, gama, 100)
+    run = D.apd_ssn_class1(c, r, l, p, q, gama, inner="amg", start=(x0, l0), rng=O.matlab_rng())
+    assert run["converged"]
+    np.savez_compressed(os.path.join(HERE, "class1_500_driver.npz"), k=run["k"], fval=run["fval"],
+                        fxk=run["fxk"], KKT_xk=run["KKT_xk"], KKT_lk=run["KKT_lk"],
+                        SsN_itnum=run["SsN_itnum"], warm_x_norm=np.linalg.norm(x0),
+                        warm_x_nnz=int((x0 > 0).sum()), warm_l=l0,
+                        E=[e["E"] for e in run["log"]], it=[e["it"] for e in run["log"]])
+    print("class1 driver: k=%d f=%.6f steps=%d" % (run["k"], run["fval"], len(run["log"])))
+    d = scipy.io.loadmat(os.path.join(ref_root, "Class2", "InputData", "data4-500.mat"))
+    c, r, l, p, q, phi = g("c"), g("r"), g("l"), g("p"), g("q"), g("phi")
+    mu = float(np.asarray(d["mu"]).ravel()[0])
+    assert np.all(p == 1) and np.all(q == 1) and np.all(phi == 1)
+    assert np.array_equal(np.asarray(d["C"], float).reshape(-1, order="F"), c)
+    np.savez_compressed(os.path.join(HERE, "data4_500.npz"), c=c, r=r, l=l, mu=mu)
+    u0, l0 = D.warmup_class2(c, r, l, p, q, mu, phi, 100)
+    run = D.apd_ssn_class2(c, r, l, p, q, mu, phi, inner="amg", start=(u0, l0),
+                           rng=O.matlab_rng())
+    assert run["converged"]
+    np.savez_compressed(os.path.join(HERE, "class2_500_driver.npz"), k=run["k"], fval=run["fval"],
+                        fxk=run["fxk"], KKT_xk=run["KKT_xk"], KKT_lk=run["KKT_lk"],
+                        KKT_yk=run["KKT_yk"], KKT_zk=run["KKT_zk"], SsN_itnum=run["SsN_itnum"],
+                        warm_u_norm=np.linalg.norm(u0), warm_l=l0,
+                        E=[e["E"] for e in run["log"]], it=[e["it"] for e in run["log"]])
+    print("class2 driver: k=%d f=%.6f steps=%d" % (run["k"], run["fval"], len(run["log"])))
+
+
 if __name__ == "__main__":
-    synthetic()
-    realistic(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
+    root = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+    if "--drivers-only" not in sys.argv:
+        synthetic()
+        realistic(root)
+    bundled_driver_runs(root)

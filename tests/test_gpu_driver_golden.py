@@ -1,0 +1,71 @@
+"""End-to-end runs of the device drivers on the reference's two bundled problems
+(Class1/InputData/data1-500.mat, Class2/InputData/data4-500.mat, stored as
+tests/golden/data{1,4}_500.npz) against the histories of the restated drivers
+(tests/golden/class{1,2}_500_driver.npz, made by tests/golden/make_golden.py).
+
+SURVEY.md 8c: an independent restatement with direct Newton solves converges at k = 58
+(f = 1.126046) and k = 53; the same counts must come out of the device path with
+inner_solver = 4."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def compare(out, g, keys):
+    assert out["converged"]
+    assert out["k"] == int(g["k"])
+    assert abs(out["fval"] - float(g["fval"])) <= 1e-7
+    ssn = out["SsN_itnum"].astype(int)
+    ref = g["SsN_itnum"]
+    half = len(ref) // 2
+    assert np.array_equal(ssn[:half], ref[:half]) and np.abs(ssn - ref).max() <= 1
+    for key in keys:
+        a, b = out[key], g[key]
+        assert a.shape == b.shape, key
+        # entry 0 is measured at the warm start, whose multiplier is only reproducible to
+        # ~1e-6 (see the tests below); from k = 1 on the Newton solves re-determine it
+        assert abs(a[0] - b[0]) <= 1e-4 * (1 + abs(b[0])), key
+        assert np.all(np.abs(a[1:] - b[1:]) <= 1e-6 * (1 + np.abs(b[1:]))), key
+    early = [r for r in out["records"] if r["k"] <= 20]
+    nE = len(early)
+    assert [r["E"] for r in early] == list(g["E"][:nE])
+    assert [r["itamg"] for r in early] == list(g["it"][:nE])
+
+
+def test_class1_bundled_problem():
+    import codes_of_ipd_ssn_amg_method_amd as ipd
+    d = np.load(os.path.join(GOLD, "data1_500.npz"))
+    g = np.load(os.path.join(GOLD, "class1_500_driver.npz"))
+    m = n = 500
+    x0, l0 = ipd.warmup_class1(d["c"], d["r"], d["l"], np.ones(m), np.ones(n), np.inf, 0, 100)
+    assert abs(np.linalg.norm(x0) - float(g["warm_x_norm"])) <= 1e-9 * float(g["warm_x_norm"])
+    # lk0 is sensitive to rounding along [1;1] (the top eigenvector of A*A'): perturbing the
+    # results of Ax by 1e-16 relative inside the oracle moves it by 6.6e-9 (measured), xk0 by 2e-12
+    assert np.linalg.norm(l0 - g["warm_l"]) <= 1e-6 * (1 + np.linalg.norm(g["warm_l"]))
+    out = ipd.APD_SsN_Class1(d["c"], d["r"], d["l"], np.ones(m), np.ones(n), np.inf,
+                             rng=ipd.MatlabRand(5489))
+    compare(out, g, ("fxk", "KKT_xk", "KKT_lk"))
+    assert out["FailAMG"] == 0 and out["restarts"] == 0
+
+
+def test_class2_bundled_problem():
+    import codes_of_ipd_ssn_amg_method_amd as ipd
+    d = np.load(os.path.join(GOLD, "data4_500.npz"))
+    g = np.load(os.path.join(GOLD, "class2_500_driver.npz"))
+    m = n = 500
+    phi = np.ones(m * n)
+    u0, l0 = ipd.warmup_class2(d["c"], d["r"], d["l"], np.ones(m), np.ones(n), float(d["mu"]), phi,
+                               0, 100)
+    # measured on the oracle itself (Ax results perturbed by 1e-16 relative): |uk0| moves by
+    # 5e-10, lk0 by 2.4e-6, almost all of it in the multiplier of phi'*x = mu -- invHHt.m:10
+    # cancels t - l'*Vl = 250002 - 249252 here
+    assert abs(np.linalg.norm(u0) - float(g["warm_u_norm"])) <= 1e-7 * float(g["warm_u_norm"])
+    assert np.linalg.norm(l0 - g["warm_l"]) <= 1e-4 * (1 + np.linalg.norm(g["warm_l"]))
+    out = ipd.APD_SsN_Class2(d["c"], d["r"], d["l"], np.ones(m), np.ones(n), float(d["mu"]), phi,
+                             rng=ipd.MatlabRand(5489))
+    compare(out, g, ("fxk", "KKT_xk", "KKT_lk", "KKT_yk", "KKT_zk"))
