@@ -121,7 +121,7 @@ EXPORTS = [
     "ipd_comm_init", "ipd_comm_finalize", "ipd_amg_bench_cycles_sharded",
     "ipd_apd_opts_init", "ipd_apd_create", "ipd_apd_destroy", "ipd_apd_warmup",
     "ipd_apd_set_state", "ipd_apd_get_state", "ipd_apd_run", "ipd_apd_history",
-    "ipd_apd_records", "ipd_apd_begin", "ipd_apd_eval", "ipd_apd_bench_eval", "ipd_prof_read",
+    "ipd_apd_records", "ipd_apd_begin", "ipd_apd_eval", "ipd_apd_bench_eval", "ipd_prof_read", "ipd_amg_bench_subcycle",
 ]
 
 

@@ -417,11 +417,26 @@ struct SolveLevel {
     XferArgs rest;  // r_{k+1} = P' rr_k      (valid for k < J)
     XferArgs prol;  // e_k += P e_{k+1}
     int nnzA, nnzP;  // sizes for the LDS cache copy
+    // tiny levels (<= 64 rows) also carry DENSE column-major copies in LDS: M[i + j*rows].
+    // Their operators are 50-90 % full, and a dense row walk has affine, independent LDS
+    // addresses (no index -> value dependency), which is what a single wave needs to pipeline.
+    const double* dA;   // N x N
+    const double* dP;   // N x Nc   (prolongation, k < J)
+    const double* dPt;  // Nc x N   (restriction,  k < J)
 };
 struct SolveDesc {
     int J, nu, isnsp, wcycle, anycycle, maxit;
     int k_lds;        // levels k_lds..J (and the transfers between them) are cached in LDS
     int k_tiny;       // levels k_tiny..J have <= 64 rows: their whole sub-cycle runs in ONE wave
+    int k_blk;        // cached Jacobi levels k_blk..k_tiny-1: one thread per row (blk_cycle)
+    // LDS image: this descriptor, a relocation table and the constant arrays of the cached
+    // levels are laid out in global memory exactly as they will sit in LDS (behind the staging
+    // area); pointers into the image are stored as LDS byte offsets and relocated on arrival
+    int image_bytes;  // multiple of 16; 0 = nothing cached
+    int nreloc;
+    double* root_r;   // k_subcycle: global right-hand side / correction of the root level
+    double* root_e;
+    long long* dbg;   // optional: wall_clock64 stamps (100 MHz) of k_subcycle's stages
     int stage_bytes;  // size of the gather staging area at the start of dynamic LDS
     double retol;
     PcgArgs pcg;
@@ -435,7 +450,16 @@ struct SolveCtx {  // per-thread copies of uniform state
     double* xs;
     unsigned swapmask;  // bit k: the current iterate of level k lives in e2
     unsigned zeromask;  // bit k: the iterate of level k is identically zero (not materialised)
+    double* part;       // 3 x 16 per-wave partial sums (blk_cycle)
+    double* sumr;       // per-level sum of the right-hand side (blk_cycle)
+    long long* dbg;     // optional stage clocks (ipd_amg_bench_subcycle), NULL in production
 };
+// accumulates the 100 MHz clock spent since t0 into dbg[slot] (thread 0 only)
+#define SOL_DBG_T0(c) const long long dbg_t0__ = (c).dbg ? wall_clock64() : 0
+#define SOL_DBG_ADD(c, slot)                                                     \
+    do {                                                                         \
+        if ((c).dbg && threadIdx.x == 0) (c).dbg[slot] += wall_clock64() - dbg_t0__; \
+    } while (0)
 
 __device__ __forceinline__ double* sol_e(const SolveCtx& c, int k) {
     return ((c.swapmask >> k) & 1u) ? c.D->L[k].e2 : c.D->L[k].e;
@@ -485,82 +509,185 @@ __device__ __forceinline__ void sol_sweep(SolveCtx& c, int k, bool post) {
     c.zeromask &= ~(1u << k);
 }
 
-// ---- wave-level sub-cycle: levels with <= 64 rows, everything LDS-resident ------------
-// A W cycle visits level k 2^(k-1) times, so most of its phases run on the deepest,
-// tiniest levels (a dozen rows).  There a 1024-thread phase is all fixed cost (barriers,
-// descriptor reads), so ONE wave runs the whole sub-cycle below level k_tiny: lane i owns
-// row i, vectors live in LDS, a wave is its own barrier (LDS operations of one wave
-// execute in order; the fence only stops the compiler from reordering them).
+// ---- LDS-resident sub-cycles ---------------------------------------------------------------
+// Everything below works on levels whose matrices and vectors sit in LDS.  The descriptor
+// keeps GENERIC pointers (the same struct also describes global levels), and a load through
+// a generic pointer is a FLAT instruction: it takes the vector-memory path and several
+// hundred cycles even when it lands in LDS (measured: 2.3 us for a 6-entries-per-row sweep).
+// So each visit first copies what it needs into registers as address_space(3) pointers;
+// the row walks then compile to ds_read.
+#define AS3 __attribute__((address_space(3)))
+template <class T>
+__device__ __forceinline__ AS3 T* as_lds(T* p) {
+    return (AS3 T*)p;
+}
+
+struct LdsLevel {
+    int N, Nc;
+    AS3 const int* rp;
+    AS3 const int* ci;
+    AS3 const double* va;
+    AS3 const double* dinv;
+    AS3 const double* Axi;
+    AS3 double* r;
+    AS3 double* rr;
+    AS3 double* e;    // current iterate (swap parity applied)
+    AS3 double* e2;
+    AS3 double* rc;   // child's right-hand side
+    AS3 const int* Rrp;   // restriction P' (CSR, Nc rows)
+    AS3 const int* Rci;
+    AS3 const double* Rva;
+    AS3 const int* Prp;   // prolongation P (CSR, N rows)
+    AS3 const int* Pci;
+    AS3 const double* Pva;
+    AS3 const double* dA;   // dense copies (tiny levels only)
+    AS3 const double* dP;
+    AS3 const double* dPt;
+    double xx;
+};
+
+__device__ __forceinline__ LdsLevel lds_level(const SolveCtx& c, int k) {
+    const AS3 SolveDesc* D = (const AS3 SolveDesc*)c.D;
+    const AS3 SolveLevel& G = D->L[k];
+    LdsLevel L;
+    L.N = G.lv.N;
+    L.Nc = G.rest.nrows;
+    L.rp = as_lds(G.lv.rp);
+    L.ci = as_lds(G.lv.ci);
+    L.va = as_lds(G.lv.va);
+    L.dinv = as_lds(G.lv.dinv);
+    L.Axi = as_lds(G.lv.Axi);
+    L.r = as_lds(G.lv.r);
+    L.rr = as_lds(G.lv.rr);
+    const bool sw = (c.swapmask >> k) & 1u;
+    L.e = as_lds(sw ? G.e2 : G.e);
+    L.e2 = as_lds(sw ? G.e : G.e2);
+    L.rc = as_lds(G.rest.y);
+    L.Rrp = as_lds(G.rest.rp);
+    L.Rci = as_lds(G.rest.ci);
+    L.Rva = as_lds(G.rest.va);
+    L.Prp = as_lds(G.prol.rp);
+    L.Pci = as_lds(G.prol.ci);
+    L.Pva = as_lds(G.prol.va);
+    L.dA = as_lds(G.dA);
+    L.dP = as_lds(G.dP);
+    L.dPt = as_lds(G.dPt);
+    L.xx = as_lds(G.lv.xx)[0];
+    return L;
+}
+__device__ __forceinline__ AS3 double* lds_e(const SolveCtx& c, int k) {
+    const AS3 SolveDesc* D = (const AS3 SolveDesc*)c.D;
+    return as_lds(((c.swapmask >> k) & 1u) ? D->L[k].e2 : D->L[k].e);
+}
+
+// A wave is its own barrier: LDS operations of one wave execute in order; the fence only
+// stops the compiler from reordering them.
 __device__ __forceinline__ void tiny_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ double tiny_rowdot(const int* rp, const int* ci, const double* va,
-                                              int row, bool valid, const double* x) {
+// sparse row walk, four entries per step: the index loads, then the gathers, are independent,
+// so the LDS latency is paid once per step instead of once per entry; the sum keeps its order
+__device__ __forceinline__ double lds_rowdot(AS3 const int* rp, AS3 const int* ci,
+                                             AS3 const double* va, int row, bool valid,
+                                             AS3 const double* x) {
     double s = 0.0;
-    if (valid)
-        for (int t = rp[row]; t < rp[row + 1]; ++t) s += va[t] * x[ci[t]];
+    if (valid) {
+        int t = rp[row];
+        const int end = rp[row + 1];
+        for (; t + 4 <= end; t += 4) {
+            const int c0 = ci[t], c1 = ci[t + 1], c2 = ci[t + 2], c3 = ci[t + 3];
+            const double v0 = va[t], v1 = va[t + 1], v2 = va[t + 2], v3 = va[t + 3];
+            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+            s += v0 * x0;
+            s += v1 * x1;
+            s += v2 * x2;
+            s += v3 * x3;
+        }
+        for (; t < end; ++t) s += va[t] * x[ci[t]];
+    }
     return s;
 }
 
-__device__ __forceinline__ void tiny_sweep(SolveCtx& c, int k) {  // Jacobi levels only (k >= 2)
-    const SolveLevel& L = c.D->L[k];
-    const int i = threadIdx.x, N = L.lv.N;
-    const bool valid = i < N, ez = (c.zeromask >> k) & 1u;
-    const double* e = sol_e(c, k);
-    double* en = sol_e2(c, k);
-    const double eo = (valid && !ez) ? e[i] : 0.0;
-    const double rv = valid ? L.lv.r[i] : 0.0;
-    const double ax = valid ? L.lv.Axi[i] : 0.0;
-    double cc = 0.0;
-    if (c.D->isnsp) cc = wave_sum(rv - ax * eo) / L.lv.xx[0];
-    const double sd = ez ? 0.0 : tiny_rowdot(L.lv.rp, L.lv.ci, L.lv.va, i, valid, e);
-    if (valid) en[i] = eo + L.lv.dinv[i] * (rv - sd - ax * cc) + cc;
-    tiny_sync();
-    c.swapmask ^= (1u << k);
-    c.zeromask &= ~(1u << k);
+// y_i = sum_j M[i + j*rows] * x[j]: ascending j like the sorted CSR walk, and the explicit
+// zeros add +0.0, so the result has the same bits
+__device__ __forceinline__ double lds_densedot(AS3 const double* M, int rows, int cols, int i,
+                                               bool valid, AS3 const double* x) {
+    double s = 0.0;
+    AS3 const double* col = M + (valid ? i : 0);
+#pragma unroll 8
+    for (int j = 0; j < cols; ++j) s += col[j * rows] * x[j];
+    return valid ? s : 0.0;
+}
+
+// ---- wave-level sub-cycle: levels with <= 64 rows ----------------------------------------
+// A W cycle visits level k 2^(k-1) times, so most of its phases run on the deepest,
+// tiniest levels (a dozen rows).  There a 1024-thread phase is all fixed cost (barriers,
+// descriptor reads), so ONE wave runs the whole sub-cycle below level k_tiny: lane i owns
+// row i, vectors and dense operators live in LDS.  (Keeping the vectors in registers and
+// broadcasting with v_readlane was measured 15 % slower: one wave issues an instruction
+// every ~5 cycles, and two readlanes per column cost more issue slots than one ds_read.)
+__device__ __forceinline__ void tiny_sweeps(SolveCtx& c, int k, LdsLevel& L, int nu, int isnsp) {
+    const int i = threadIdx.x, N = L.N;
+    const bool valid = i < N;
+    const double rv = valid ? L.r[i] : 0.0;
+    const double ax = valid ? L.Axi[i] : 0.0;
+    const double dv = valid ? L.dinv[i] : 0.0;
+    for (int s = 0; s < nu; ++s) {
+        const bool ez = (c.zeromask >> k) & 1u;
+        const double eo = (valid && !ez) ? L.e[i] : 0.0;
+        double cc = 0.0;
+        if (isnsp) cc = wave_sum(rv - ax * eo) / L.xx;
+        const double sd = ez ? 0.0 : lds_densedot(L.dA, N, N, i, valid, L.e);
+        if (valid) L.e2[i] = eo + dv * (rv - sd - ax * cc) + cc;
+        tiny_sync();
+        AS3 double* t = L.e;
+        L.e = L.e2;
+        L.e2 = t;
+        c.swapmask ^= (1u << k);
+        c.zeromask &= ~(1u << k);
+    }
 }
 
 __device__ __forceinline__ void tiny_pcg(SolveCtx& c, int k) {  // PCG.m:68-87, Jacobi, zero guess
-    const SolveLevel& L = c.D->L[k];
-    const PcgArgs& a = c.D->pcg;
-    const int i = threadIdx.x, N = L.lv.N;
+    const LdsLevel L = lds_level(c, k);
+    const AS3 SolveDesc* D = (const AS3 SolveDesc*)c.D;
+    const double tol = D->pcg.tol;
+    const long long maxit = D->pcg.maxit;
+    const int precd = D->pcg.precd;
+    AS3 double* pv = as_lds(D->pcg.work);  // p shared through LDS
+    const int i = threadIdx.x, N = L.N;
     const bool valid = i < N;
-    double* pv = a.work;  // p shared through LDS
-    double dg = 1.0;
-    if (valid)
-        for (int t = L.lv.rp[i]; t < L.lv.rp[i + 1]; ++t)
-            if (L.lv.ci[t] == i) dg = L.lv.va[t];
-    double r = valid ? L.lv.r[i] : 0.0;
-    double p = a.precd == 2 ? r / dg : r;
+    const double dg = valid ? L.dA[i + i * N] : 1.0;
+    double r = valid ? L.r[i] : 0.0;
+    double p = precd == 2 ? r / dg : r;
     double d = 0.0;
     double delta_new = wave_sum(valid ? r * p : 0.0);
-    const double delta_0 = delta_new, thresh = a.tol * a.tol * delta_0;
+    const double delta_0 = delta_new, thresh = tol * tol * delta_0;
     long long it = 0;
-    while (it < a.maxit && delta_new > thresh) {
+    while (it < maxit && delta_new > thresh) {
         const double delta_old = delta_new;
         if (valid) pv[i] = p;
         tiny_sync();
-        const double q = tiny_rowdot(L.lv.rp, L.lv.ci, L.lv.va, i, valid, pv);
+        const double q = lds_densedot(L.dA, N, N, i, valid, pv);
         tiny_sync();
         const double alpha = delta_old / wave_sum(valid ? q * p : 0.0);
         d += alpha * p;
         r -= alpha * q;
-        const double w = a.precd == 2 ? r / dg : r;
+        const double w = precd == 2 ? r / dg : r;
         delta_new = wave_sum(valid ? r * w : 0.0);
         p = w + (delta_new / delta_old) * p;
         ++it;
     }
-    if (valid) sol_e(c, k)[i] = d;
+    if (valid) L.e[i] = d;
     tiny_sync();
     c.zeromask &= ~(1u << k);
 }
 
 // sub-cycle rooted at level k0 >= k_tiny (r_{k0} is in LDS); executed by wave 0 only
 __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
-    const SolveDesc* D = c.D;
-    const int J = D->J, nu = D->nu, i = threadIdx.x;
+    const int J = c.D->J, nu = c.D->nu, wc = c.D->wcycle, isnsp = c.D->isnsp, i = threadIdx.x;
     unsigned visited = 0;
     int k = k0;
     bool entering = true, keep = keep0;
@@ -573,31 +700,31 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
                 k = J - 1;
                 continue;
             }
-            const SolveLevel& L = D->L[k];
+            LdsLevel L = lds_level(c, k);
             if (!keep) {
                 c.zeromask |= (1u << k);
                 if (nu == 0) {
-                    if (i < L.lv.N) sol_e(c, k)[i] = 0.0;
+                    if (i < L.N) L.e[i] = 0.0;
                     tiny_sync();
                     c.zeromask &= ~(1u << k);
                 }
             }
-            for (int s = 0; s < nu; ++s) tiny_sweep(c, k);
+            tiny_sweeps(c, k, L, nu, isnsp);
             {   // residual, then restriction into the child's right-hand side
-                const bool valid = i < L.lv.N;
-                const double sd = tiny_rowdot(L.lv.rp, L.lv.ci, L.lv.va, i, valid, sol_e(c, k));
-                if (valid) L.lv.rr[i] = L.lv.r[i] - sd;
+                const bool valid = i < L.N;
+                const double sd = lds_densedot(L.dA, L.N, L.N, i, valid, L.e);
+                if (valid) L.rr[i] = L.r[i] - sd;
                 tiny_sync();
-                const bool cv = i < L.rest.nrows;
-                const double rc = tiny_rowdot(L.rest.rp, L.rest.ci, L.rest.va, i, cv, L.lv.rr);
-                if (cv) L.rest.y[i] = rc;
+                const bool cv = i < L.Nc;
+                const double rc = lds_densedot(L.dPt, L.Nc, L.N, i, cv, L.rr);
+                if (cv) L.rc[i] = rc;
                 tiny_sync();
             }
             visited &= ~(1u << (k + 1));
             k = k + 1;
             keep = false;
         } else {
-            const bool again = D->wcycle && (k + 1 < J) && !((visited >> (k + 1)) & 1u);
+            const bool again = wc && (k + 1 < J) && !((visited >> (k + 1)) & 1u);
             if (again) {
                 visited |= (1u << (k + 1));
                 k = k + 1;
@@ -605,15 +732,169 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
                 entering = true;
                 continue;
             }
-            const SolveLevel& L = D->L[k];
+            LdsLevel L = lds_level(c, k);
             {
-                const bool valid = i < L.lv.N;
-                double* e = sol_e(c, k);
-                const double sd = tiny_rowdot(L.prol.rp, L.prol.ci, L.prol.va, i, valid, sol_e(c, k + 1));
-                if (valid) e[i] = e[i] + sd;
+                const bool valid = i < L.N;
+                const double sd = lds_densedot(L.dP, L.N, L.Nc, i, valid, lds_e(c, k + 1));
+                if (valid) L.e[i] = L.e[i] + sd;
                 tiny_sync();
             }
-            for (int s = 0; s < nu; ++s) tiny_sweep(c, k);
+            tiny_sweeps(c, k, L, nu, isnsp);
+            if (k == k0) return;
+            k = k - 1;
+        }
+    }
+}
+
+// ---- block-level sub-cycle: cached levels with <= 1024 rows, one thread per row ---------
+// The generic phases (L lanes per row, staging, batched loads) are built for levels that need
+// many CUs; on a 100..1000-row level that already sits in LDS they are all fixed cost (~3 us
+// a phase, measured).  Here thread i owns row i, a sweep is one row walk and ONE barrier: the
+// per-wave partial sums of (A1)'e that the kernel-space correction of the NEXT sweep needs
+// are published by the same barrier that publishes the new iterate.
+__device__ __forceinline__ double blk_total(AS3 const double* part) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < BT / 64; ++w) s += part[w];
+    return s;
+}
+__device__ __forceinline__ void blk_publish(double v, AS3 double* part) {
+    const double w = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = w;
+}
+
+// cur: index (0/1) of the partial-sum buffer that describes the current iterate
+__device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int nu, int isnsp,
+                                           int& cur) {
+    const int i = threadIdx.x, N = L.N;
+    const bool valid = i < N;
+    AS3 double* part = as_lds(c.part);
+    const double rv = valid ? L.r[i] : 0.0;
+    const double ax = valid ? L.Axi[i] : 0.0;
+    const double dv = valid ? L.dinv[i] : 0.0;
+    const double sumr = isnsp ? as_lds(c.sumr)[k] : 0.0;
+    for (int s = 0; s < nu; ++s) {
+        const bool ez = (c.zeromask >> k) & 1u;
+        const double eo = (valid && !ez) ? L.e[i] : 0.0;
+        double cc = 0.0;
+        if (isnsp) cc = (sumr - (ez ? 0.0 : blk_total(part + 16 * cur))) / L.xx;
+        const double sd = ez ? 0.0 : lds_rowdot(L.rp, L.ci, L.va, i, valid, L.e);
+        const double v = eo + dv * (rv - sd - ax * cc) + cc;
+        if (valid) L.e2[i] = v;
+        if (isnsp) blk_publish(valid ? ax * v : 0.0, part + 16 * (cur ^ 1));
+        __syncthreads();
+        cur ^= 1;
+        AS3 double* t = L.e;
+        L.e = L.e2;
+        L.e2 = t;
+        c.swapmask ^= (1u << k);
+        c.zeromask &= ~(1u << k);
+    }
+}
+
+// sub-cycle rooted at level k0 (k_blk <= k0); r_{k0} is in LDS.  Executed by the whole block.
+__device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
+    const SolveDesc* D = c.D;
+    const int J = D->J, nu = D->nu, isnsp = D->isnsp, wc = D->wcycle, k_tiny = D->k_tiny;
+    const int i = threadIdx.x;
+    AS3 double* part = as_lds(c.part);
+    unsigned visited = 0;
+    int k = k0, cur = 0;
+    bool entering = true, keep = keep0;
+    for (int guard = 0; guard < (1 << 22); ++guard) {
+        if (entering && k >= k_tiny) {   // <= 64 rows from here down: wave 0 alone
+            SOL_DBG_T0(c);
+            if (threadIdx.x < 64) {
+                SolveCtx t = c;
+                tiny_cycle(t, k, keep);
+            }
+            __syncthreads();
+            SOL_DBG_ADD(c, 4);
+            c.zeromask &= ~(1u << k);
+            if (k == k0) return;
+            entering = false;
+            k = k - 1;
+            continue;
+        }
+        if (entering) {
+            if (k == J) {   // coarsest level with more than 64 rows
+                PcgArgs a = D->pcg;
+                a.rhs = D->L[J].lv.r;
+                a.d = sol_e(c, J);
+                pcg_block(a, c.red);
+                __syncthreads();
+                c.zeromask &= ~(1u << J);
+                if (J == k0) return;
+                entering = false;
+                k = J - 1;
+                continue;
+            }
+            LdsLevel L = lds_level(c, k);
+            const bool valid = i < L.N;
+            if (!keep) {
+                c.zeromask |= (1u << k);
+                if (nu == 0) {
+                    if (valid) L.e[i] = 0.0;
+                    c.zeromask &= ~(1u << k);
+                }
+            }
+            if (isnsp) {   // 1'r of this visit, and (A1)'e when the visit starts from an iterate
+                const bool ez = (c.zeromask >> k) & 1u;
+                blk_publish(valid ? L.r[i] : 0.0, part + 32);
+                blk_publish((valid && !ez) ? L.Axi[i] * L.e[i] : 0.0, part + 16 * cur);
+                __syncthreads();
+                if (i == 0) as_lds(c.sumr)[k] = blk_total(part + 32);
+                __syncthreads();
+            } else if (nu == 0) {
+                __syncthreads();
+            }
+            {
+                SOL_DBG_T0(c);
+                blk_sweeps(c, k, L, nu, isnsp, cur);
+                SOL_DBG_ADD(c, 5);
+            }
+            {   // residual, then restriction into the child's right-hand side
+                SOL_DBG_T0(c);
+                const double sd = lds_rowdot(L.rp, L.ci, L.va, i, valid, L.e);
+                if (valid) L.rr[i] = L.r[i] - sd;
+                __syncthreads();
+                const bool cv = i < L.Nc;
+                const double rc = lds_rowdot(L.Rrp, L.Rci, L.Rva, i, cv, L.rr);
+                if (cv) L.rc[i] = rc;
+                __syncthreads();
+                SOL_DBG_ADD(c, 6);
+            }
+            visited &= ~(1u << (k + 1));
+            k = k + 1;
+            keep = false;
+        } else {
+            const bool again = wc && (k + 1 < J) && !((visited >> (k + 1)) & 1u);
+            if (again) {
+                visited |= (1u << (k + 1));
+                k = k + 1;
+                keep = true;
+                entering = true;
+                continue;
+            }
+            LdsLevel L = lds_level(c, k);
+            SOL_DBG_T0(c);
+            {
+                const bool valid = i < L.N;
+                const double sd = lds_rowdot(L.Prp, L.Pci, L.Pva, i, valid, lds_e(c, k + 1));
+                double v = 0.0;
+                if (valid) {
+                    v = L.e[i] + sd;
+                    L.e[i] = v;
+                }
+                if (isnsp) blk_publish(valid ? L.Axi[i] * v : 0.0, part + 16 * cur);
+                __syncthreads();
+            }
+            SOL_DBG_ADD(c, 7);
+            {
+                SOL_DBG_T0(c);
+                blk_sweeps(c, k, L, nu, isnsp, cur);
+                SOL_DBG_ADD(c, 5);
+            }
             if (k == k0) return;
             k = k - 1;
         }
@@ -629,13 +910,11 @@ __device__ __forceinline__ void sol_cycle(SolveCtx& c, int k0 = 1, bool keep0 = 
     int k = k0;
     bool entering = true, keep = keep0;
     for (int guard = 0; guard < (1 << 22); ++guard) {
-        if (entering && k >= D->k_tiny && k > 1) {
-            // the whole sub-cycle below here runs in wave 0; 2*nu sweeps per visit leave the
-            // e/e2 roles of every level unchanged, so the other waves need no state update
-            if (threadIdx.x < 64) {
-                SolveCtx t = c;
-                tiny_cycle(t, k, keep);
-            }
+        if (entering && k >= D->k_blk) {
+            // the whole sub-cycle below here runs thread-per-row out of LDS (wave 0 alone from
+            // k_tiny down); 2*nu sweeps per visit leave the e/e2 roles of every level unchanged
+            SolveCtx t = c;
+            blk_cycle(t, k, keep);
             __syncthreads();
             c.zeromask &= ~(1u << k);
             if (k == k0) return;
@@ -720,108 +999,58 @@ __device__ __forceinline__ void sol_top(SolveCtx& c, const double* b, const doub
     __syncthreads();
 }
 
-// Copies levels k_lds..J (matrices, transfers, work vectors) into dynamic LDS and patches the
-// LDS descriptor `LD` to point at the copies.  They are tiny, but a W cycle visits level k
-// 2^(k-1) times, so their phases must not pay global-memory latency.  Every thread walks the
-// same carve sequence; pointers are patched by thread 0.
-__device__ __forceinline__ void sol_cache_levels(const SolveDesc* D, SolveDesc* LD, char* dyn_raw) {
-        size_t off = (size_t)D->stage_bytes + ((sizeof(SolveDesc) + 15) / 16) * 16;
-        auto carve = [&](size_t bytes) {
-            char* p = dyn_raw + off;
-            off += (bytes + 15) / 16 * 16;
-            return p;
-        };
-        auto copy_i = [&](const int* src, size_t n) {
-            int* d = reinterpret_cast<int*>(carve(n * 4));
-            for (size_t i = threadIdx.x; i < n; i += BT) d[i] = src[i];
-            return d;
-        };
-        auto copy_d = [&](const double* src, size_t n) {
-            double* d = reinterpret_cast<double*>(carve(n * 8));
-            for (size_t i = threadIdx.x; i < n; i += BT) d[i] = src[i];
-            return d;
-        };
-        auto copy_h = [&](const unsigned short* src, size_t n) {
-            unsigned short* d = reinterpret_cast<unsigned short*>(carve(n * 2));
-            for (size_t i = threadIdx.x; i < n; i += BT) d[i] = src[i];
-            return d;
-        };
-        const bool t0 = threadIdx.x == 0;
-        for (int k = D->k_lds; k <= D->J; ++k) {
-            const SolveLevel& G = D->L[k];
-            SolveLevel& T = LD->L[k];
-            const size_t N = (size_t)G.lv.N;
-            const int* rp = copy_i(G.lv.rp, N + 1);
-            const int* ci = copy_i(G.lv.ci, (size_t)G.nnzA);
-            const double* va = copy_d(G.lv.va, (size_t)G.nnzA);
-            const double* dinv = copy_d(G.lv.dinv, N);
-            const double* Axi = copy_d(G.lv.Axi, N);
-            const double* xx = copy_d(G.lv.xx, 1);
-            const unsigned short* pci = nullptr;
-            const double* pva = nullptr;
-            const double* diag = nullptr;
-            if (G.lv.S > 0) {
-                pci = copy_h(G.lv.pci, N * G.lv.S);
-                pva = copy_d(G.lv.pva, N * G.lv.S);
-                diag = copy_d(G.lv.diag, N);
-            }
-            double* r = reinterpret_cast<double*>(carve(N * 8));
-            double* rr = reinterpret_cast<double*>(carve(N * 8));
-            double* e = reinterpret_cast<double*>(carve(N * 8));
-            double* e2 = reinterpret_cast<double*>(carve(N * 8));
-            double* w = reinterpret_cast<double*>(carve(N * 8));
-            if (t0) {
-                T.lv.rp = rp;
-                T.lv.ci = ci;
-                T.lv.va = va;
-                T.lv.dinv = dinv;
-                T.lv.Axi = Axi;
-                T.lv.xx = xx;
-                T.lv.pci = pci;
-                T.lv.pva = pva;
-                T.lv.diag = diag;
-                T.lv.r = r;
-                T.lv.rr = rr;
-                T.e = e;
-                T.e2 = e2;
-                T.w = w;
-            }
-            if (k < D->J) {  // transfers between two cached levels
-                const size_t Nc = (size_t)G.rest.nrows;
-                const int* trp = copy_i(G.rest.rp, Nc + 1);
-                const int* tci = copy_i(G.rest.ci, (size_t)G.nnzP);
-                const double* tva = copy_d(G.rest.va, (size_t)G.nnzP);
-                const int* prp = copy_i(G.prol.rp, N + 1);
-                const int* pci2 = copy_i(G.prol.ci, (size_t)G.nnzP);
-                const double* pva2 = copy_d(G.prol.va, (size_t)G.nnzP);
-                if (t0) {
-                    T.rest.rp = trp;
-                    T.rest.ci = tci;
-                    T.rest.va = tva;
-                    T.prol.rp = prp;
-                    T.prol.ci = pci2;
-                    T.prol.va = pva2;
-                }
-            }
-        }
-        __syncthreads();
-        if (t0) {  // vectors that cross level boundaries, and the coarsest PCG
-            for (int k = 1; k < D->J; ++k) {
-                LD->L[k].rest.x = LD->L[k].lv.rr;
-                LD->L[k].rest.y = LD->L[k + 1].lv.r;
-            }
-            const int J = D->J;
-            if (J >= D->k_lds) {
-                LD->pcg.rp = LD->L[J].lv.rp;
-                LD->pcg.ci = LD->L[J].lv.ci;
-                LD->pcg.va = LD->L[J].lv.va;
-            }
-        }
-        if (D->J >= D->k_lds) {
-            double* work = reinterpret_cast<double*>(carve(4 * (size_t)D->L[D->J].lv.N * 8));
-            if (t0) LD->pcg.work = work;
-        }
-        __syncthreads();
+struct PackEntry {
+    const void* src;
+    unsigned dst_off, bytes;  // multiples of 4
+};
+// gathers the constant arrays of the cached levels into the image (one workgroup per array)
+__global__ __launch_bounds__(256) void k_pack_image(const PackEntry* __restrict__ ents,
+                                                    char* __restrict__ img) {
+    const PackEntry e = ents[blockIdx.x];
+    const int* src = reinterpret_cast<const int*>(e.src);
+    int* dst = reinterpret_cast<int*>(img + e.dst_off);
+    for (unsigned i = threadIdx.x; i < e.bytes / 4; i += 256) dst[i] = src[i];
+}
+
+struct DenseEntry {
+    const int* rp;
+    const int* ci;
+    const double* va;
+    int rows, cols;
+    unsigned dst_off;
+};
+// dense column-major copies of the tiny levels' operators (one workgroup per matrix)
+__global__ __launch_bounds__(256) void k_pack_dense(const DenseEntry* __restrict__ ents,
+                                                    char* __restrict__ img) {
+    const DenseEntry e = ents[blockIdx.x];
+    double* dst = reinterpret_cast<double*>(img + e.dst_off);
+    for (int t = threadIdx.x; t < e.rows * e.cols; t += 256) dst[t] = 0.0;
+    __syncthreads();
+    for (int r = threadIdx.x; r < e.rows; r += 256)
+        for (int t = e.rp[r]; t < e.rp[r + 1]; ++t) dst[r + (size_t)e.ci[t] * e.rows] = e.va[t];
+}
+
+static constexpr int RELOC_MAX = 640;
+__host__ __device__ constexpr size_t sol_r16(size_t b) { return (b + 15) / 16 * 16; }
+static constexpr size_t SOL_HEAD = sol_r16(sizeof(SolveDesc)) + sol_r16(4 * RELOC_MAX);
+
+// One flat copy of the image (many 16-byte loads in flight per lane) instead of one dependent
+// global round trip per array (measured: ~60 arrays x ~1.5 us dominated the sub-cycle kernel).
+__device__ __forceinline__ SolveDesc* sol_load_image(const SolveDesc* Dg, char* dyn_raw) {
+    const int stage = Dg->stage_bytes, n16 = Dg->image_bytes / 16;
+    const uint4* src = reinterpret_cast<const uint4*>(Dg);
+    uint4* dst = reinterpret_cast<uint4*>(dyn_raw + stage);
+    for (int i = threadIdx.x; i < n16; i += BT) dst[i] = src[i];
+    __syncthreads();
+    SolveDesc* LD = reinterpret_cast<SolveDesc*>(dyn_raw + stage);
+    const unsigned* rel =
+        reinterpret_cast<const unsigned*>(dyn_raw + stage + sol_r16(sizeof(SolveDesc)));
+    for (int t = threadIdx.x; t < LD->nreloc; t += BT) {
+        char** f = reinterpret_cast<char**>(reinterpret_cast<char*>(LD) + rel[t]);
+        *f = dyn_raw + reinterpret_cast<size_t>(*f);
+    }
+    __syncthreads();
+    return LD;
 }
 
 // out[0] = it, out[1] = rel_res, out[2] = res0; rel_resk at out[4 ..], rhok at out[4+maxit+2 ..]
@@ -833,17 +1062,12 @@ __global__ __launch_bounds__(BT) void k_solve_small(const SolveDesc* __restrict_
                                                     int fixed_cycles) {
     __shared__ PhaseLds lds;
     __shared__ double red[16];
+    __shared__ double blkpart[48 + SOLVE_ML + 1];
     extern __shared__ __attribute__((aligned(16))) char dyn_raw[];
     // dynamic LDS: [ staging vector | descriptor copy | cached levels ]
     const SolveDesc* D = D_global;
-    SolveDesc* LD = reinterpret_cast<SolveDesc*>(dyn_raw + D->stage_bytes);
-    if (CACHED) {
-        const int* src = reinterpret_cast<const int*>(D);
-        int* dst = reinterpret_cast<int*>(LD);
-        for (int i = threadIdx.x; i < (int)(sizeof(SolveDesc) / 4); i += BT) dst[i] = src[i];
-    }
-    __syncthreads();
-    if (CACHED) sol_cache_levels(D, LD, dyn_raw);
+    SolveDesc* LD = nullptr;
+    if (CACHED) LD = sol_load_image(D_global, dyn_raw);
     SolveCtx c;
     // without cached levels the descriptor stays in global memory: its (uniform) fields
     // are then fetched with scalar loads and live in SGPRs instead of VGPRs
@@ -853,6 +1077,9 @@ __global__ __launch_bounds__(BT) void k_solve_small(const SolveDesc* __restrict_
     c.xs = reinterpret_cast<double*>(dyn_raw);
     c.swapmask = 0;
     c.zeromask = 0;
+    c.part = blkpart;
+    c.sumr = blkpart + 48;
+    c.dbg = nullptr;
     D = c.D;
     const int N = D->L[1].lv.N;
     const int maxit = D->maxit;
@@ -933,22 +1160,19 @@ __global__ __launch_bounds__(BT) void k_solve_small(const SolveDesc* __restrict_
 __global__ __launch_bounds__(BT) void k_subcycle(const SolveDesc* __restrict__ D_global, int keep) {
     __shared__ PhaseLds lds;
     __shared__ double red[16];
+    __shared__ double blkpart[48 + SOLVE_ML + 1];
     extern __shared__ __attribute__((aligned(16))) char dyn_raw[];
     const SolveDesc* D = D_global;
-    SolveDesc* LD = reinterpret_cast<SolveDesc*>(dyn_raw + D->stage_bytes);
-    {
-        const int* src = reinterpret_cast<const int*>(D);
-        int* dst = reinterpret_cast<int*>(LD);
-        for (int i = threadIdx.x; i < (int)(sizeof(SolveDesc) / 4); i += BT) dst[i] = src[i];
-    }
-    __syncthreads();
-    sol_cache_levels(D, LD, dyn_raw);
+    long long* dbg = D->dbg;
+    if (dbg && threadIdx.x == 0) dbg[0] = wall_clock64();
+    SolveDesc* LD = sol_load_image(D_global, dyn_raw);
+    if (dbg && threadIdx.x == 0) dbg[1] = wall_clock64();
     const int k0 = D->k_lds, N0 = D->L[k0].lv.N;
     {
         double* r = LD->L[k0].lv.r;
         double* e = LD->L[k0].e;
-        const double* gr = D->L[k0].lv.r;
-        const double* ge = D->L[k0].e;
+        const double* gr = D->root_r;
+        const double* ge = D->root_e;
         for (int i = threadIdx.x; i < N0; i += BT) {
             r[i] = gr[i];
             if (keep) e[i] = ge[i];
@@ -962,10 +1186,22 @@ __global__ __launch_bounds__(BT) void k_subcycle(const SolveDesc* __restrict__ D
     c.xs = reinterpret_cast<double*>(dyn_raw);
     c.swapmask = 0;
     c.zeromask = 0;
+    c.part = blkpart;
+    c.sumr = blkpart + 48;
+    c.dbg = dbg;
+    if (dbg && threadIdx.x == 0) {
+        dbg[4] = dbg[5] = dbg[6] = dbg[7] = 0;
+        dbg[2] = wall_clock64();
+        dbg[8] = clock64();
+    }
     sol_cycle(c, k0, keep != 0);
     __syncthreads();
+    if (dbg && threadIdx.x == 0) {
+        dbg[3] = wall_clock64();
+        dbg[8] = clock64() - dbg[8];
+    }
     const double* res = sol_e(c, k0);
-    double* ge = D->L[k0].e;
+    double* ge = D->root_e;
     for (int i = threadIdx.x; i < N0; i += BT) ge[i] = res[i];
 }
 

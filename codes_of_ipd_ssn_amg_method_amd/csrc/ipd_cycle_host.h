@@ -290,9 +290,19 @@ void amg_prepare_levels(ipd_amg* h) {
             }
         }
     };
+    // bottom run of levels with <= 64 rows (k >= 2): candidates for the wave-level sub-cycle
+    int tiny_lo = h->J + 1;
+    {
+        const char* nt = std::getenv("IPD_NO_TINY");
+        if (!(nt && nt[0] == '1'))
+            for (int k = h->J; k >= 2; --k) {
+                if (h->L[k].A.nr > 64) break;
+                tiny_lo = k;
+            }
+    }
     // LDS cache plan: deepest levels first, while they fit; returns the first cached level
     auto plan_lds = [&](size_t stage, size_t* used_out) {
-        size_t used = stage + r16(sizeof(SolveDesc)) + 256;
+        size_t used = stage + SOL_HEAD + 256;
         const size_t budget = 150 * 1024;
         int k_lds = h->J + 1;
         for (int k = h->J; k >= 1; --k) {
@@ -305,6 +315,10 @@ void amg_prepare_levels(ipd_amg* h) {
                 bytes += r16(4 * (Nc + 1)) + r16(4 * (N + 1)) + 2 * (r16(4 * np) + r16(8 * np));
             }
             if (k == h->J) bytes += r16(4 * 8 * N);
+            if (k >= tiny_lo) {   // dense copies of the tiny levels
+                bytes += r16(8 * N * N);
+                if (k < h->J) bytes += 2 * r16(8 * N * (size_t)h->L[k + 1].A.nr);
+            }
             if (used + bytes > budget) break;
             used += bytes;
             k_lds = k;
@@ -313,14 +327,122 @@ void amg_prepare_levels(ipd_amg* h) {
         return k_lds;
     };
     auto tiny_from = [&](int k_lds) {   // tiny levels: <= 64 rows, cached, Jacobi (k >= 2)
-        int kt = h->J + 1;
-        const char* nt = std::getenv("IPD_NO_TINY");
-        if (!(nt && nt[0] == '1'))
-            for (int k = h->J; k >= std::max(2, k_lds); --k) {
-                if (h->L[k].A.nr > 64) break;
-                kt = k;
+        return std::max(tiny_lo, std::max(2, k_lds));
+    };
+    auto blk_from = [&](int k_lds) {    // cached Jacobi levels: thread-per-row sub-cycle
+        const char* nb = std::getenv("IPD_NO_BLK");
+        if ((nb && nb[0] == '1') || k_lds > h->J) return h->J + 1;
+        return std::max(2, k_lds);
+    };
+    // Lays levels k_from..J out behind the staging area, packs the image on the device and
+    // returns it (the descriptor the kernels take); *lds_total = dynamic LDS bytes to request.
+    auto build_image = [&](SolveDesc* sd, int k_from, size_t stage, size_t* lds_total) {
+        std::vector<PackEntry> packs;
+        std::vector<unsigned> relocs;
+        size_t off = stage + SOL_HEAD;   // LDS offset (from dyn_raw) of the next carve
+        auto carve = [&](size_t bytes) {
+            const size_t o = off;
+            off += r16(bytes);
+            return o;
+        };
+        auto set_off = [&](auto& field, size_t o) {
+            using T = std::remove_reference_t<decltype(field)>;
+            field = reinterpret_cast<T>(o);
+            relocs.push_back((unsigned)(reinterpret_cast<char*>(&field) - reinterpret_cast<char*>(sd)));
+        };
+        auto put = [&](auto& field, size_t n) {   // constant array: copied into the image
+            using T = std::remove_reference_t<decltype(field)>;
+            using E = std::remove_cv_t<std::remove_pointer_t<T>>;
+            const size_t o = carve(n * sizeof(E));
+            packs.push_back(PackEntry{(const void*)field, (unsigned)(o - stage), (unsigned)(n * sizeof(E))});
+            set_off(field, o);
+        };
+        for (int k = k_from; k <= h->J; ++k) {     // constants first: they form the image
+            SolveLevel& T = sd->L[k];
+            const size_t N = (size_t)T.lv.N;
+            put(T.lv.rp, N + 1);
+            put(T.lv.ci, (size_t)T.nnzA);
+            put(T.lv.va, (size_t)T.nnzA);
+            put(T.lv.dinv, N);
+            put(T.lv.Axi, N);
+            put(T.lv.xx, 1);
+            if (k < h->J) {
+                const size_t Nc = (size_t)T.rest.nrows;
+                put(T.rest.rp, Nc + 1);
+                put(T.rest.ci, (size_t)T.nnzP);
+                put(T.rest.va, (size_t)T.nnzP);
+                put(T.prol.rp, N + 1);
+                put(T.prol.ci, (size_t)T.nnzP);
+                put(T.prol.va, (size_t)T.nnzP);
             }
-        return kt;
+        }
+        std::vector<DenseEntry> dense;
+        for (int k = std::max(k_from, sd->k_tiny); k <= h->J; ++k) {
+            SolveLevel& T = sd->L[k];
+            const Level& lv = h->L[k];
+            const size_t N = (size_t)lv.A.nr;
+            auto add = [&](const double*& field, const Csr& m) {
+                const size_t o = carve(8 * (size_t)m.nr * m.nc);
+                dense.push_back(DenseEntry{m.rp, m.ci, m.va, m.nr, m.nc, (unsigned)(o - stage)});
+                set_off(field, o);
+            };
+            add(T.dA, lv.A);
+            if (k < h->J) {
+                add(T.dP, h->L[k + 1].P);
+                add(T.dPt, h->L[k + 1].Pt);
+            }
+            (void)N;
+        }
+        const size_t image_bytes = off - stage;
+        for (int k = k_from; k <= h->J; ++k) {     // work vectors: carved, not copied
+            SolveLevel& T = sd->L[k];
+            const size_t N = (size_t)T.lv.N;
+            set_off(T.lv.r, carve(N * 8));
+            set_off(T.lv.rr, carve(N * 8));
+            set_off(T.e, carve(N * 8));
+            set_off(T.e2, carve(N * 8));
+            set_off(T.w, carve(N * 8));
+        }
+        for (int k = std::max(1, k_from - 1); k < h->J; ++k) {   // vectors that cross levels
+            SolveLevel& T = sd->L[k];
+            if (k >= k_from) {
+                T.rest.x = T.lv.rr;
+                relocs.push_back((unsigned)(reinterpret_cast<char*>(&T.rest.x) - reinterpret_cast<char*>(sd)));
+            }
+            T.rest.y = sd->L[k + 1].lv.r;
+            relocs.push_back((unsigned)(reinterpret_cast<char*>(&T.rest.y) - reinterpret_cast<char*>(sd)));
+        }
+        {
+            sd->pcg.rp = sd->L[h->J].lv.rp;
+            sd->pcg.ci = sd->L[h->J].lv.ci;
+            sd->pcg.va = sd->L[h->J].lv.va;
+            for (auto* f : {(const void**)&sd->pcg.rp, (const void**)&sd->pcg.ci, (const void**)&sd->pcg.va})
+                relocs.push_back((unsigned)(reinterpret_cast<char*>(f) - reinterpret_cast<char*>(sd)));
+            set_off(sd->pcg.work, carve(4 * (size_t)sd->L[h->J].lv.N * 8));
+        }
+        IPD_REQUIRE(relocs.size() <= (size_t)RELOC_MAX, IPD_E_LIMIT, "LDS image: too many relocations");
+        sd->image_bytes = (int)image_bytes;
+        sd->nreloc = (int)relocs.size();
+        *lds_total = off;
+        char* img = reinterpret_cast<char*>(ar.alloc_bytes(image_bytes));
+        std::vector<char> head(SOL_HEAD, 0);
+        std::memcpy(head.data(), sd, sizeof(SolveDesc));
+        std::memcpy(head.data() + r16(sizeof(SolveDesc)), relocs.data(), relocs.size() * sizeof(unsigned));
+        ctx->upload_bytes(img, head.data(), SOL_HEAD);
+        for (PackEntry& e : packs) e.dst_off += 0;   // offsets are relative to the image start
+        PackEntry* dents = ctx->scratch->alloc<PackEntry>(packs.size());
+        ctx->upload_bytes(dents, packs.data(), packs.size() * sizeof(PackEntry));
+        hipLaunchKernelGGL(k_pack_image, dim3((unsigned)packs.size()), dim3(256), 0, ctx->stream,
+                           (const PackEntry*)dents, img);
+        IPD_KERNEL_CHECK();
+        if (!dense.empty()) {
+            DenseEntry* dd = ctx->scratch->alloc<DenseEntry>(dense.size());
+            ctx->upload_bytes(dd, dense.data(), dense.size() * sizeof(DenseEntry));
+            hipLaunchKernelGGL(k_pack_dense, dim3((unsigned)dense.size()), dim3(256), 0, ctx->stream,
+                               (const DenseEntry*)dd, img);
+            IPD_KERNEL_CHECK();
+        }
+        return reinterpret_cast<SolveDesc*>(img);
     };
     static bool attr_set = false;
     if (!attr_set) {
@@ -356,10 +478,15 @@ void amg_prepare_levels(ipd_amg* h) {
             sd->k_lds = k_lds;
             st->solve_cached = k_lds <= h->J;
             sd->k_tiny = tiny_from(k_lds);
+            sd->k_blk = blk_from(k_lds);
             sd->stage_bytes = (int)stage;
             st->solve_lds = used;
-            st->d_solve = reinterpret_cast<SolveDesc*>(ar.alloc_bytes(sizeof(SolveDesc)));
-            ctx->upload_bytes(st->d_solve, sd.get(), sizeof(SolveDesc));
+            if (st->solve_cached) {
+                st->d_solve = build_image(sd.get(), k_lds, stage, &st->solve_lds);
+            } else {
+                st->d_solve = reinterpret_cast<SolveDesc*>(ar.alloc_bytes(sizeof(SolveDesc)));
+                ctx->upload_bytes(st->d_solve, sd.get(), sizeof(SolveDesc));
+            }
             st->solve_out = ar.alloc<double>(4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2));
             st->small_ok = true;
         }
@@ -383,31 +510,12 @@ void amg_prepare_levels(ipd_amg* h) {
                     fill_desc(sd.get());
                     sd->k_lds = kroot;
                     sd->k_tiny = tiny_from(kroot);
+                    sd->k_blk = blk_from(kroot);
                     sd->stage_bytes = (int)stage;
-                    // levels kroot..J only: recompute the bytes actually carved
-                    size_t need = stage + r16(sizeof(SolveDesc)) + 256;
-                    {
-                        size_t full = 0;
-                        (void)plan_lds(stage, &full);
-                        // plan_lds may have admitted shallower levels too; count kroot..J only
-                        need = stage + r16(sizeof(SolveDesc)) + 256;
-                        for (int k = h->J; k >= kroot; --k) {
-                            const Level& lv = h->L[k];
-                            const size_t N = (size_t)lv.A.nr;
-                            size_t bytes = r16(4 * (N + 1)) + r16(4 * (size_t)lv.A.nnz) +
-                                           r16(8 * (size_t)lv.A.nnz) + 7 * r16(8 * N) + 16;
-                            if (k < h->J) {
-                                const size_t Nc = (size_t)h->L[k + 1].A.nr, np = (size_t)h->L[k + 1].P.nnz;
-                                bytes += r16(4 * (Nc + 1)) + r16(4 * (N + 1)) + 2 * (r16(4 * np) + r16(8 * np));
-                            }
-                            if (k == h->J) bytes += r16(4 * 8 * N);
-                            need += bytes;
-                        }
-                    }
-                    st->sub_lds = need;
+                    sd->root_r = h->L[kroot].r;
+                    sd->root_e = h->L[kroot].e;
                     st->k_sub = kroot;
-                    st->d_sub = reinterpret_cast<SolveDesc*>(ar.alloc_bytes(sizeof(SolveDesc)));
-                    ctx->upload_bytes(st->d_sub, sd.get(), sizeof(SolveDesc));
+                    st->d_sub = build_image(sd.get(), kroot, stage, &st->sub_lds);
                     break;
                 }
             }
@@ -1056,6 +1164,53 @@ extern "C" int ipd_amg_bench_cycles(ipd_amg* h, const double* b_dev, double* x_d
 // the context's stream: the per-launch duration of the dominant kernel (k_smooth).
 // launches_per_sweep = 2 for the bigraph Gauss-Seidel level, 1 for Jacobi levels;
 // bytes_per_sweep = S(A_k) + 6*8*N_k (fused-GS form).
+extern "C" int ipd_amg_bench_subcycle(ipd_amg* h, int reps, double* total_ms, int32_t* k_sub,
+                                      int64_t stamps[8]) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && reps > 0 && total_ms, IPD_E_ARG, "bad argument");
+        ipd_ctx* ctx = h->ctx;
+        ctx->set_device();
+        CycleState* st = state_of(h);
+        IPD_REQUIRE(st, IPD_E_ARG, "hierarchy has no cycle state");
+        if (k_sub) *k_sub = st->k_sub;
+        *total_ms = 0.0;
+        if (!st->k_sub) return;
+        CallScope scope(ctx);
+        long long* dbg = ctx->scratch->alloc<long long>(16);
+        IPD_HIP(hipMemsetAsync(dbg, 0, 128, ctx->stream));
+        // patch the debug pointer into the image header
+        const size_t off = offsetof(SolveDesc, dbg);
+        ctx->upload_bytes(reinterpret_cast<char*>(st->d_sub) + off, &dbg, sizeof(dbg));
+        IPD_HIP(hipMemsetAsync(h->L[st->k_sub].r, 0, sizeof(double) * (size_t)h->L[st->k_sub].N,
+                               ctx->stream));
+        hipEvent_t e0, e1;
+        IPD_HIP(hipEventCreate(&e0));
+        IPD_HIP(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_subcycle, dim3(1), dim3(BT), st->sub_lds, ctx->stream,
+                           (const SolveDesc*)st->d_sub, 0);
+        IPD_HIP(hipEventRecord(e0, ctx->stream));
+        for (int r = 0; r < reps; ++r)
+            hipLaunchKernelGGL(k_subcycle, dim3(1), dim3(BT), st->sub_lds, ctx->stream,
+                               (const SolveDesc*)st->d_sub, 0);
+        IPD_HIP(hipEventRecord(e1, ctx->stream));
+        IPD_HIP(hipEventSynchronize(e1));
+        IPD_KERNEL_CHECK();
+        float ms = 0.f;
+        IPD_HIP(hipEventElapsedTime(&ms, e0, e1));
+        IPD_HIP(hipEventDestroy(e0));
+        IPD_HIP(hipEventDestroy(e1));
+        *total_ms = ms;
+        long long hs[16];
+        ctx->fetch(dbg, hs, 16);
+        if (stamps && hs[3] > hs[2])   // shader clock (MHz) seen by the cycle: s_memtime ticks / 10 ns
+            stamps[0] = hs[8] * 100 / (hs[3] - hs[2]), hs[0] = stamps[0];
+        if (stamps)
+            for (int i = 0; i < 8; ++i) stamps[i] = hs[i];
+        long long* none = nullptr;
+        ctx->upload_bytes(reinterpret_cast<char*>(st->d_sub) + off, &none, sizeof(none));
+    });
+}
+
 extern "C" int ipd_amg_bench_sweeps(ipd_amg* h, int k, int reps, double* total_ms,
                                     int* launches_per_sweep, double* bytes_per_sweep) {
     return ipd_guard([&] {

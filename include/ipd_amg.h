@@ -322,6 +322,12 @@ int ipd_amg_bench_cycles(ipd_amg* h, const double* b_dev, double* x_dev, int cyc
  * bigraph Gauss-Seidel level (F half, C half) and 1 on Jacobi levels.          */
 int ipd_amg_bench_sweeps(ipd_amg* h, int k, int reps, double* total_ms,
                          int* launches_per_sweep, double* bytes_per_sweep);
+/* Times `reps` launches of the single-workgroup sub-cycle kernel (levels k_sub..J out of
+ * LDS) on a zero right-hand side; stamps = 100 MHz clock at start / image loaded / cycle
+ * begins / cycle done inside the last launch, then clocks spent in: wave-level sub-cycles,
+ * block-level sweeps, residual+restriction, prolongation.  *k_sub = 0: no such kernel.  */
+int ipd_amg_bench_subcycle(ipd_amg* h, int reps, double* total_ms, int32_t* k_sub,
+                           int64_t stamps[8]);
 /* SURVEY 8d byte model of the hierarchy: per-level S(A_k), S(P_k), ...       */
 int ipd_amg_cycle_bytes(const ipd_amg* h, double* bytes_per_cycle);
 

@@ -41,6 +41,9 @@ def run(cls, N, pr):
     t2 = time.perf_counter()
     out = ws.run(amg, ipd.MatlabRand(5489))
     t3 = time.perf_counter()
+    lls = np.array([r["ll"] for r in ws.records()] or [0])
+    ll_stats = dict(mean=float(lls.mean()), p50=float(np.median(lls)), max=int(lls.max()),
+                    zero_frac=float((lls == 0).mean()))
     prof = None
     if os.environ.get("IPD_PROFILE"):
         import ctypes
@@ -55,7 +58,7 @@ def run(cls, N, pr):
     rec = dict(cls=cls, N=N, upload_s=t1 - t0, warmup_s=t2 - t1, apd_s=t3 - t2, k=out["k"],
                converged=out["converged"], fval=out["fval"], newton_steps=out["nrec"],
                SumAMG=out["SumAMG"], eval_us=1e3 * ms / 200, eval_GBps=by * 200 / (ms * 1e-3) / 1e9,
-               eval_bytes=by)
+               eval_bytes=by, ll=ll_stats)
     if prof:
         rec["profile_s_calls"] = prof
     ws.close()
