@@ -32,7 +32,8 @@ namespace {
 constexpr int TR = 256;        // tile rows
 constexpr int TC = 16;         // tile columns per sub-tile
 constexpr int TLD = TR + 16;   // LDS column stride
-constexpr int NSC = 5;         // scalar accumulators per workgroup
+constexpr int NSC = 8;         // scalar accumulators per workgroup
+constexpr int MK = 8;          // line-search trial points evaluated by one merit pass
 
 struct Geo {
     int m, n, nib, njg, reps;  // njg column groups of reps*TC columns
@@ -217,6 +218,50 @@ struct OpEval {
     }
 };
 
+// --- :199-207  |prox(zk)|^2 at MK trial multipliers lk_old + step[k]*zeta in one pass over wk.
+// A rejected Armijo test is followed by dozens of further trials (delta = 0.9; measured mean 57
+// when the first one fails): they only need the merit, not Fk or the mask, so MK of them share
+// one read of wk.  Per trial the arithmetic is that of OpEval, operation for operation.
+struct OpMerit {
+    static constexpr int FC = 16;
+    Prob P;
+    const double* w;
+    const double* lam;
+    const double* zeta;
+    double step[MK];
+    double itk;
+    struct Raw {
+        double w, phi, g;
+    };
+    struct RowC {
+        double pi, l2, z2;
+    };
+    __device__ void row_const(RowC& rc, int i) const {
+        rc.pi = P.p[i];
+        rc.l2 = lam[P.n + i];
+        rc.z2 = zeta[P.n + i];
+    }
+    __device__ void fetch(Raw& r, size_t idx) const {
+        r.w = w[idx];
+        r.phi = P.cls2 ? P.phi[idx] : 0.0;
+        r.g = P.gama ? P.gama[idx] : P.gs;
+    }
+    __device__ double compute(const Raw& r, const RowC& rc, int j, size_t, double* sc) const {
+        const double l1 = lam[j], z1 = zeta[j], qj = P.q[j];
+        const int M = P.m + P.n;
+        const double lL = P.cls2 ? lam[M] : 0.0, zL = P.cls2 ? zeta[M] : 0.0;
+#pragma unroll
+        for (int k = 0; k < MK; ++k) {
+            double aty = rc.pi * (l1 + step[k] * z1) + (rc.l2 + step[k] * rc.z2) * qj;
+            if (P.cls2) aty = aty + (lL + step[k] * zL) * r.phi;
+            const double z = itk * (r.w - aty);
+            const double px = prox_of(P, z, r.g);
+            sc[k] += px * px;
+        }
+        return 0.0;
+    }
+};
+
 // --- :239-242,253-254  uk1 = prox(zk), vk1, and the KKT residuals of (uk1, lk1)
 template <bool FROM_W>
 struct OpEnd {
@@ -274,18 +319,25 @@ struct Parts {
     int nblk;
 };
 
-// sum of the partials of one entry of A*x, in a fixed order; loads go out 16 at a time (a
+// sum of the partials of one entry of A*x, in a fixed order; loads go out 32 at a time (a
 // plain loop pays one L2/HBM round trip per partial: 64 of them made this epilogue 47 us)
 __device__ __forceinline__ double sum_strided(const double* __restrict__ base, int count,
                                               size_t stride) {
     double s = 0.0;
     int k = 0;
-    for (; k + 16 <= count; k += 16) {
-        double v[16];
+    for (; k + 32 <= count; k += 32) {
+        double v[32];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = base[(size_t)(k + u) * stride];
+        for (int u = 0; u < 32; ++u) v[u] = base[(size_t)(k + u) * stride];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s += v[u];
+        for (int u = 0; u < 32; ++u) s += v[u];
+    }
+    for (; k + 8 <= count; k += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(k + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
     }
     for (; k < count; ++k) s += base[(size_t)k * stride];
     return s;
@@ -349,20 +401,42 @@ struct EvalFin {
     double* tmask;       // class 2: t = zk(mn+1:end) >= 0 as 0/1 doubles (diag of T)
     double bk1, itk;
     ApdScal* out;
+    double* fpart;   // per-block partial sums of the epilogue
+    int* counter;    // ticket of the epilogue blocks (0 between launches)
 };
 
-__global__ __launch_bounds__(BT) void k_eval_fin(const EvalFin a) {
-    __shared__ double red[16];
+// The epilogue of the evaluation pass runs once per line-search trial, so it is spread over
+// cdiv(L, 128) small workgroups (one entry of Fk per thread: its 64+ partial sums arrive in two
+// round trips instead of one workgroup walking 0.5 MB -- measured 36 us -> see DESIGN.md);
+// the last workgroup to finish (ticket) adds the per-block scalars in block order.
+constexpr int EB = 128;
+constexpr int NFS = 6;   // f2, l2, wl, fz, tp2, tz2
+
+__device__ __forceinline__ double sum128(double v, double* red) {   // result in every thread
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1];
+}
+__device__ __forceinline__ double scal_total128(const Parts& pt, int slot, double* red) {
+    double a = 0.0;
+    for (int b = threadIdx.x; b < pt.nblk; b += EB) a += pt.spart[(size_t)b * NSC + slot];
+    return sum128(a, red);
+}
+
+__global__ __launch_bounds__(EB) void k_eval_fin(const EvalFin a) {
+    __shared__ double red[2];
+    __shared__ int is_last;
     const int M = a.P.m + a.P.n;
     const size_t mn = (size_t)a.P.m * a.P.n;
-    double prox2 = scal_total(a.pt, 0, red);
-    const double z2s = scal_total(a.pt, 1, red);
-    const double zmp2 = scal_total(a.pt, 2, red);
-    const double phix = scal_total(a.pt, 3, red);
-    const double cnt = scal_total(a.pt, 4, red);
-    double f2 = 0.0, l2 = 0.0, wl = 0.0, fz = 0.0, tp2 = 0.0, tz2 = 0.0;
     const int L = M + (a.P.cls2 ? 1 : 0);
-    for (int t = threadIdx.x; t < L; t += BT) {
+    const int t = blockIdx.x * EB + threadIdx.x;
+    // phi'*prox(zk) is needed by the one thread that owns the last entry of Fk (class 2)
+    double phix = 0.0;
+    if (a.P.cls2 && blockIdx.x == M / EB) phix = scal_total128(a.pt, 3, red);
+    double f2 = 0.0, l2 = 0.0, wl = 0.0, fz = 0.0, tp2 = 0.0, tz2 = 0.0;
+    if (t < L) {
         const double lt = a.lam.at(t);
         double Hp;
         if (t < M) {
@@ -372,8 +446,8 @@ __global__ __launch_bounds__(BT) void k_eval_fin(const EvalFin a) {
                 const double pz = z > 0.0 ? z : 0.0;
                 if (a.tmask) a.tmask[t] = z >= 0.0 ? 1.0 : 0.0;
                 Hp = Hp + pz;                                              // Class2 :141
-                tp2 += pz * pz;
-                tz2 += z * z;
+                tp2 = pz * pz;
+                tz2 = z * z;
             }
         } else {
             Hp = phix;
@@ -381,26 +455,40 @@ __global__ __launch_bounds__(BT) void k_eval_fin(const EvalFin a) {
         const double f = a.bk1 * lt - Hp - a.wlk[t];                       // :144
         a.F[t] = f;
         if (a.lam_out) a.lam_out[t] = lt;
-        f2 += f * f;
-        l2 += lt * lt;
-        wl += a.wlk[t] * lt;
-        if (a.lam.zeta && a.Fold) fz += a.Fold[t] * a.lam.zeta[t];
+        f2 = f * f;
+        l2 = lt * lt;
+        wl = a.wlk[t] * lt;
+        if (a.lam.zeta && a.Fold) fz = a.Fold[t] * a.lam.zeta[t];
     }
-    f2 = block_sum(f2, red);
-    l2 = block_sum(l2, red);
-    wl = block_sum(wl, red);
-    fz = block_sum(fz, red);
-    tp2 = block_sum(tp2, red);
-    tz2 = block_sum(tz2, red);
+    double vals[NFS] = {f2, l2, wl, fz, tp2, tz2};
+#pragma unroll
+    for (int k = 0; k < NFS; ++k) {
+        const double sk = sum128(vals[k], red);
+        if (threadIdx.x == 0) a.fpart[(size_t)blockIdx.x * NFS + k] = sk;
+    }
+    __threadfence();
+    if (threadIdx.x == 0) is_last = (atomicAdd(a.counter, 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const double prox2 = scal_total128(a.pt, 0, red);
+    const double z2s = scal_total128(a.pt, 1, red);
+    const double zmp2 = scal_total128(a.pt, 2, red);
+    const double cnt = scal_total128(a.pt, 4, red);
     if (threadIdx.x == 0) {
-        a.out->normF2 = f2;
-        a.out->lam2 = l2;
-        a.out->wlk_lam = wl;
-        a.out->prox2 = prox2 + tp2;
-        a.out->z2 = z2s + tz2;
+        double tot[NFS];
+        for (int k = 0; k < NFS; ++k) tot[k] = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b)
+            for (int k = 0; k < NFS; ++k) tot[k] += a.fpart[(size_t)b * NFS + k];
+        a.out->normF2 = tot[0];
+        a.out->lam2 = tot[1];
+        a.out->wlk_lam = tot[2];
+        a.out->fold_zeta = tot[3];
+        a.out->prox2 = prox2 + tot[4];
+        a.out->z2 = z2s + tot[5];
         a.out->zmp2 = zmp2;  // tails: z - prox(z) = min(z,0); only class 1 (prob 3) uses it
         a.out->count = cnt;
-        a.out->fold_zeta = fz;
+        *a.counter = 0;
     }
 }
 
@@ -462,6 +550,43 @@ __global__ __launch_bounds__(BT) void k_end_fin(const EndFin a) {
         a.out->kz2 = kz2;
         a.out->kl2 = kl2;
         a.out->fx = fx;
+    }
+}
+
+struct MeritFin {
+    Parts pt;
+    Prob P;
+    const double* w;
+    const double* lam;
+    const double* zeta;
+    const double* wlk;
+    double step[MK];
+    double bk1, tk, itk;
+    double* out;   // MK merit values cFk_new
+};
+
+__global__ __launch_bounds__(BT) void k_merit_fin(const MeritFin a) {
+    __shared__ double red[16];
+    const int M = a.P.m + a.P.n;
+    const size_t mn = (size_t)a.P.m * a.P.n;
+    const int L = M + (a.P.cls2 ? 1 : 0);
+    for (int k = 0; k < MK; ++k) {
+        double l2 = 0.0, wl = 0.0, tp2 = 0.0;
+        for (int t = threadIdx.x; t < L; t += BT) {
+            const double lt = a.lam[t] + a.step[k] * a.zeta[t];
+            l2 += lt * lt;
+            wl += a.wlk[t] * lt;
+            if (a.P.cls2 && t < M) {
+                const double z = a.itk * (a.w[mn + t] - lt);
+                const double pz = z > 0.0 ? z : 0.0;
+                tp2 += pz * pz;
+            }
+        }
+        l2 = block_sum(l2, red);
+        wl = block_sum(wl, red);
+        tp2 = block_sum(tp2, red);
+        const double prox2 = scal_total(a.pt, k, red) + tp2;
+        if (threadIdx.x == 0) a.out[k] = a.bk1 / 2.0 * l2 - wl + 0.5 * a.tk * prox2;   // :201-204
     }
 }
 
@@ -714,6 +839,9 @@ struct ipd_apd {
     uint8_t* s = nullptr;
     double *lpart = nullptr, *rpart = nullptr, *spart = nullptr;
     ApdScal* dscal = nullptr;
+    double* fpart = nullptr;
+    int* counter = nullptr;
+    double* merit = nullptr;
     double *phi_l = nullptr, *phi_part = nullptr;  // Ax(phi), partial sums of |phi|^2
     int phi_npart = 0;
     // script variables
@@ -817,7 +945,9 @@ EvalRes apd_eval(ipd_apd* h, const double* lam_base, const double* zeta, double 
     f.bk1 = h->bk1;
     f.itk = op.itk;
     f.out = h->dscal;
-    hipLaunchKernelGGL(k_eval_fin, dim3(1), dim3(BT), 0, h->ctx->stream, f);
+    f.fpart = h->fpart;
+    f.counter = h->counter;
+    hipLaunchKernelGGL(k_eval_fin, dim3(cdiv(h->L, EB)), dim3(EB), 0, h->ctx->stream, f);
     IPD_KERNEL_CHECK();
     const ApdScal s = fetch_scal(h);
     EvalRes r;
@@ -830,6 +960,34 @@ EvalRes apd_eval(ipd_apd* h, const double* lam_base, const double* zeta, double 
     r.fold_zeta = s.fold_zeta;
     r.E = (long long)(s.count + 0.5);
     return r;
+}
+
+// merit cFk at lam_base + step[k]*zeta for MK steps (class 1 prob < 3 and class 2)
+void apd_merit(ipd_apd* h, const double* lam_base, const double* zeta, const double step[MK],
+               double merit[MK]) {
+    ProfScope ps(h->ctx, PROF_EVAL);
+    OpMerit op;
+    op.P = h->P;
+    op.w = h->w;
+    op.lam = lam_base;
+    op.zeta = zeta;
+    op.itk = 1.0 / h->tk;
+    MeritFin f;
+    f.pt = parts_of(h);
+    f.P = h->P;
+    f.w = h->w;
+    f.lam = lam_base;
+    f.zeta = zeta;
+    f.wlk = h->wlk;
+    f.bk1 = h->bk1;
+    f.tk = h->tk;
+    f.itk = op.itk;
+    f.out = h->merit;
+    for (int k = 0; k < MK; ++k) op.step[k] = f.step[k] = step[k];
+    launch_tiles(h, op);
+    hipLaunchKernelGGL(k_merit_fin, dim3(1), dim3(BT), 0, h->ctx->stream, f);
+    IPD_KERNEL_CHECK();
+    h->ctx->fetch(h->merit, merit, MK);
 }
 
 // uk1/vk1 (from_w) and the KKT residuals of the iterate at multiplier `lam`
@@ -979,11 +1137,34 @@ void apd_iterate(ipd_apd* h, const ipd_apd_opts& o, const AmgOpts& amg, ipd_rng*
         double step = 1.0;
         e_new = apd_eval(h, lam_old, h->zeta, step, lam_new, F_new, F_old);
         const double ress = std::fabs(e_new.fold_zeta);                            // :198
-        while (merit(e_new) > cF_old - o.nu * step * ress) {                       // :199
-            ++ll;
+        if (merit(e_new) > cF_old - o.nu * step * ress && !merit3 && o.ll_max > 0) {      // :199
+            // the trials that follow only decide on the merit: MK of them per pass over wk,
+            // then one full evaluation at the accepted (or last) step
+            bool found = false;
+            while (!found && ll < o.ll_max) {
+                double st[MK], mv[MK];
+                for (int k = 0; k < MK; ++k) st[k] = std::pow(o.delta, (double)(ll + 1 + k));
+                apd_merit(h, lam_old, h->zeta, st, mv);
+                for (int k = 0; k < MK && !found; ++k) {
+                    const int cand = ll + 1 + k;
+                    if (cand > o.ll_max) break;
+                    if (!(mv[k] > cF_old - o.nu * st[k] * ress) || cand == o.ll_max) {
+                        ll = cand;
+                        found = true;
+                    }
+                }
+                if (!found) ll += MK;
+            }
+            ll = std::min(ll, (int)o.ll_max);
             step = std::pow(o.delta, (double)ll);
             e_new = apd_eval(h, lam_old, h->zeta, step, lam_new, F_new, F_old);
-            if (ll == o.ll_max) break;
+        } else {
+            while (merit(e_new) > cF_old - o.nu * step * ress) {                   // :199
+                ++ll;
+                step = std::pow(o.delta, (double)ll);
+                e_new = apd_eval(h, lam_old, h->zeta, step, lam_new, F_new, F_old);
+                if (ll == o.ll_max) break;
+            }
         }
         ipd_ssn_rec rec;
         rec.k = k;
@@ -1248,6 +1429,10 @@ extern "C" int ipd_apd_create(ipd_ctx* ctx, const ipd_apd_data* d, ipd_apd** out
         h->rpart = A.alloc<double>((size_t)g.nib * n);
         h->spart = A.alloc<double>((size_t)g.nib * g.njg * NSC);
         h->dscal = reinterpret_cast<ApdScal*>(A.alloc<double>(sizeof(ApdScal) / sizeof(double) + 1));
+        h->fpart = A.alloc<double>((size_t)cdiv(L, EB) * NFS);
+        h->merit = A.alloc<double>(MK);
+        h->counter = A.alloc<int>(4);
+        IPD_HIP(hipMemsetAsync(h->counter, 0, 16, ctx->stream));
         Prob& P = h->P;
         P.cls2 = d->cls == 2 ? 1 : 0;
         P.m = m;
