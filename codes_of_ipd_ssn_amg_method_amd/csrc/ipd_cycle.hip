@@ -610,6 +610,37 @@ __device__ __forceinline__ double lds_rowdot(AS3 const int* rp, AS3 const int* c
     return s;
 }
 
+// The coarse levels have a few long rows (hubs: 60+ entries against a mean of 6), and with one
+// thread per row the whole block waits for them at every barrier (measured: 70 % of a sweep).
+// So a row is walked by Lr consecutive lanes (Lr = largest power of two with rows*Lr <= 1024,
+// at most 16), entries strided over the lanes, partial sums combined with DPP row operations.
+__device__ __forceinline__ int lanes_per_row(int rows) {
+    int L = 1;
+    while (L < 16 && rows * (L * 2) <= BT) L <<= 1;
+    return L;
+}
+// every lane of the group returns the full sum
+__device__ __forceinline__ double lds_rowdot_split(AS3 const int* rp, AS3 const int* ci,
+                                                   AS3 const double* va, int row, int sub, int Lr,
+                                                   bool valid, AS3 const double* x) {
+    double s = 0.0;
+    if (valid) {
+        int t = rp[row] + sub;
+        const int end = rp[row + 1];
+        for (; t + 3 * Lr < end; t += 4 * Lr) {
+            const int c0 = ci[t], c1 = ci[t + Lr], c2 = ci[t + 2 * Lr], c3 = ci[t + 3 * Lr];
+            const double v0 = va[t], v1 = va[t + Lr], v2 = va[t + 2 * Lr], v3 = va[t + 3 * Lr];
+            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+            s += v0 * x0;
+            s += v1 * x1;
+            s += v2 * x2;
+            s += v3 * x3;
+        }
+        for (; t < end; t += Lr) s += va[t] * x[ci[t]];
+    }
+    return subwave_sum(s, Lr);
+}
+
 // y_i = sum_j M[i + j*rows] * x[j]: ascending j like the sorted CSR walk, and the explicit
 // zeros add +0.0, so the result has the same bits
 __device__ __forceinline__ double lds_densedot(AS3 const double* M, int rows, int cols, int i,
@@ -766,8 +797,9 @@ __device__ __forceinline__ void blk_publish(double v, AS3 double* part) {
 // cur: index (0/1) of the partial-sum buffer that describes the current iterate
 __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int nu, int isnsp,
                                            int& cur) {
-    const int i = threadIdx.x, N = L.N;
-    const bool valid = i < N;
+    const int N = L.N, Lr = lanes_per_row(N);
+    const int i = threadIdx.x / Lr, sub = threadIdx.x % Lr;
+    const bool valid = i < N, owner = valid && sub == 0;
     AS3 double* part = as_lds(c.part);
     const double rv = valid ? L.r[i] : 0.0;
     const double ax = valid ? L.Axi[i] : 0.0;
@@ -778,10 +810,10 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
         const double eo = (valid && !ez) ? L.e[i] : 0.0;
         double cc = 0.0;
         if (isnsp) cc = (sumr - (ez ? 0.0 : blk_total(part + 16 * cur))) / L.xx;
-        const double sd = ez ? 0.0 : lds_rowdot(L.rp, L.ci, L.va, i, valid, L.e);
+        const double sd = ez ? 0.0 : lds_rowdot_split(L.rp, L.ci, L.va, i, sub, Lr, valid, L.e);
         const double v = eo + dv * (rv - sd - ax * cc) + cc;
-        if (valid) L.e2[i] = v;
-        if (isnsp) blk_publish(valid ? ax * v : 0.0, part + 16 * (cur ^ 1));
+        if (owner) L.e2[i] = v;
+        if (isnsp) blk_publish(owner ? ax * v : 0.0, part + 16 * (cur ^ 1));
         __syncthreads();
         cur ^= 1;
         AS3 double* t = L.e;
@@ -855,12 +887,19 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
             }
             {   // residual, then restriction into the child's right-hand side
                 SOL_DBG_T0(c);
-                const double sd = lds_rowdot(L.rp, L.ci, L.va, i, valid, L.e);
-                if (valid) L.rr[i] = L.r[i] - sd;
+                {
+                    const int Lr = lanes_per_row(L.N), row = i / Lr, sub = i % Lr;
+                    const bool rvld = row < L.N;
+                    const double sd = lds_rowdot_split(L.rp, L.ci, L.va, row, sub, Lr, rvld, L.e);
+                    if (rvld && sub == 0) L.rr[row] = L.r[row] - sd;
+                }
                 __syncthreads();
-                const bool cv = i < L.Nc;
-                const double rc = lds_rowdot(L.Rrp, L.Rci, L.Rva, i, cv, L.rr);
-                if (cv) L.rc[i] = rc;
+                {
+                    const int Lr = lanes_per_row(L.Nc), row = i / Lr, sub = i % Lr;
+                    const bool cv = row < L.Nc;
+                    const double rc = lds_rowdot_split(L.Rrp, L.Rci, L.Rva, row, sub, Lr, cv, L.rr);
+                    if (cv && sub == 0) L.rc[row] = rc;
+                }
                 __syncthreads();
                 SOL_DBG_ADD(c, 6);
             }
@@ -879,14 +918,16 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
             LdsLevel L = lds_level(c, k);
             SOL_DBG_T0(c);
             {
-                const bool valid = i < L.N;
-                const double sd = lds_rowdot(L.Prp, L.Pci, L.Pva, i, valid, lds_e(c, k + 1));
+                const int Lr = lanes_per_row(L.N), row = i / Lr, sub = i % Lr;
+                const bool own = row < L.N && sub == 0;
+                const double sd = lds_rowdot_split(L.Prp, L.Pci, L.Pva, row, sub, Lr, row < L.N,
+                                                   lds_e(c, k + 1));
                 double v = 0.0;
-                if (valid) {
-                    v = L.e[i] + sd;
-                    L.e[i] = v;
+                if (own) {
+                    v = L.e[row] + sd;
+                    L.e[row] = v;
                 }
-                if (isnsp) blk_publish(valid ? L.Axi[i] * v : 0.0, part + 16 * cur);
+                if (isnsp) blk_publish(own ? L.Axi[row] * v : 0.0, part + 16 * cur);
                 __syncthreads();
             }
             SOL_DBG_ADD(c, 7);
@@ -1191,6 +1232,7 @@ __global__ __launch_bounds__(BT) void k_subcycle(const SolveDesc* __restrict__ D
     c.dbg = dbg;
     if (dbg && threadIdx.x == 0) {
         dbg[4] = dbg[5] = dbg[6] = dbg[7] = 0;
+        dbg[9] = dbg[10] = dbg[11] = dbg[12] = 0;
         dbg[2] = wall_clock64();
         dbg[8] = clock64();
     }

@@ -150,28 +150,40 @@ static void build_Ae(ipd_ctx* ctx, Arena& dst, const Csr& H0, const double* tdia
 // member of i's component, whatever the interleaving (deterministic).
 __global__ __launch_bounds__(1024) void k_components(int N, const int* __restrict__ rp,
                                                      const int* __restrict__ ci,
-                                                     int* __restrict__ parent) {
+                                                     int* __restrict__ parent_out) {
+    // the parent array lives in LDS (M <= 16384 nodes): hooks and pointer jumping then cost LDS
+    // latency instead of a global round trip each (measured 430 us -> see DESIGN.md)
+    extern __shared__ int parent[];
     __shared__ int changed;
     for (int i = threadIdx.x; i < N; i += 1024) parent[i] = i;
-    if (threadIdx.x == 0) parent[N] = 1;  // "not converged" until a round makes no hook
+    int converged = 0;
     __syncthreads();
+    auto hook = [&](int pi, int j, bool& any) {
+        const int pj = parent[j];
+        if (pj < pi) {
+            atomicMin(&parent[pi], pj);
+            any = true;
+        } else if (pi < pj) {
+            atomicMin(&parent[pj], pi);
+            any = true;
+        }
+    };
     for (int round = 0; round < 64; ++round) {
         if (threadIdx.x == 0) changed = 0;
         __syncthreads();
-        // hook: one wave per row (hub rows have ~1000 entries), lanes over its entries
         bool any = false;
-        for (int i = threadIdx.x >> 6; i < N; i += 16) {
+        // short rows: one thread each; long rows (hubs have ~1000 entries): one wave each
+        for (int i = threadIdx.x; i < N; i += 1024) {
+            const int b = rp[i], e = rp[i + 1];
+            if (e - b > 32) continue;
             const int pi = parent[i];
-            for (int t = rp[i] + (threadIdx.x & 63); t < rp[i + 1]; t += 64) {
-                const int pj = parent[ci[t]];
-                if (pj < pi) {
-                    atomicMin(&parent[pi], pj);
-                    any = true;
-                } else if (pi < pj) {
-                    atomicMin(&parent[pj], pi);
-                    any = true;
-                }
-            }
+            for (int t = b; t < e; ++t) hook(pi, ci[t], any);
+        }
+        for (int i = threadIdx.x >> 6; i < N; i += 16) {
+            const int b = rp[i], e = rp[i + 1];
+            if (e - b <= 32) continue;
+            const int pi = parent[i];
+            for (int t = b + (threadIdx.x & 63); t < e; t += 64) hook(pi, ci[t], any);
         }
         if (any) changed = 1;
         __syncthreads();
@@ -185,10 +197,12 @@ __global__ __launch_bounds__(1024) void k_components(int N, const int* __restric
         const int c = changed;
         __syncthreads();
         if (!c) {
-            if (threadIdx.x == 0) parent[N] = 0;
+            converged = 1;
             break;
         }
     }
+    for (int i = threadIdx.x; i < N; i += 1024) parent_out[i] = parent[i];
+    if (threadIdx.x == 0) parent_out[N] = converged ? 0 : 1;
 }
 
 struct Components {
@@ -203,7 +217,15 @@ static void find_components(ipd_ctx* ctx, const Csr& A, Components* out) {
     IPD_REQUIRE(A.nr == A.nc, IPD_E_ARG, "Adjacency matrix must be square");  // components.m:33
     const int N = A.nr;
     int* parent = ctx->scratch->alloc<int>((size_t)N + 1);
-    hipLaunchKernelGGL(k_components, dim3(1), dim3(1024), 0, ctx->stream, N, A.rp, A.ci, parent);
+    IPD_REQUIRE(N <= 16384, IPD_E_LIMIT, "components: more than 16384 nodes");
+    static bool attr_set = false;
+    if (!attr_set) {
+        IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_components),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 66 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_components, dim3(1), dim3(1024), sizeof(int) * ((size_t)N + 1), ctx->stream,
+                       N, A.rp, A.ci, parent);
     IPD_KERNEL_CHECK();
     std::vector<int> par((size_t)N + 1);
     ctx->fetch(parent, par.data(), (size_t)N + 1);
