@@ -417,7 +417,7 @@ struct SolveLevel {
     XferArgs rest;  // r_{k+1} = P' rr_k      (valid for k < J)
     XferArgs prol;  // e_k += P e_{k+1}
     int nnzA, nnzP;  // sizes for the LDS cache copy
-    // tiny levels (<= 64 rows) also carry DENSE column-major copies in LDS: M[i + j*rows].
+    // tiny levels (<= 32 rows) also carry DENSE column-major copies in LDS: M[i + j*rows].
     // Their operators are 50-90 % full, and a dense row walk has affine, independent LDS
     // addresses (no index -> value dependency), which is what a single wave needs to pipeline.
     const double* dA;   // N x N
@@ -427,7 +427,7 @@ struct SolveLevel {
 struct SolveDesc {
     int J, nu, isnsp, wcycle, anycycle, maxit;
     int k_lds;        // levels k_lds..J (and the transfers between them) are cached in LDS
-    int k_tiny;       // levels k_tiny..J have <= 64 rows: their whole sub-cycle runs in ONE wave
+    int k_tiny;       // levels k_tiny..J have <= 32 rows: their whole sub-cycle runs in ONE wave
     int k_blk;        // cached Jacobi levels k_blk..k_tiny-1: one thread per row (blk_cycle)
     // LDS image: this descriptor, a relocation table and the constant arrays of the cached
     // levels are laid out in global memory exactly as they will sit in LDS (behind the staging
@@ -652,16 +652,44 @@ __device__ __forceinline__ double lds_densedot(AS3 const double* M, int rows, in
     return valid ? s : 0.0;
 }
 
-// ---- wave-level sub-cycle: levels with <= 64 rows ----------------------------------------
+// ---- wave-level sub-cycle: levels with <= 32 rows ----------------------------------------
 // A W cycle visits level k 2^(k-1) times, so most of its phases run on the deepest,
 // tiniest levels (a dozen rows).  There a 1024-thread phase is all fixed cost (barriers,
 // descriptor reads), so ONE wave runs the whole sub-cycle below level k_tiny: lane i owns
 // row i, vectors and dense operators live in LDS.  (Keeping the vectors in registers and
 // broadcasting with v_readlane was measured 15 % slower: one wave issues an instruction
 // every ~5 cycles, and two readlanes per column cost more issue slots than one ds_read.)
+// rows are walked by Lt = 2..8 lanes each when the level leaves lanes idle (N <= 32)
+__device__ __forceinline__ int tiny_lanes(int rows) {
+    int L = 1;
+    while (L < 8 && rows * (L * 2) <= 64) L <<= 1;
+    return L;
+}
+// every lane of the row's group returns the full sum (columns strided over the group)
+__device__ __forceinline__ double lds_densedot_split(AS3 const double* M, int rows, int cols,
+                                                     int row, int sub, int Lt, bool valid,
+                                                     AS3 const double* x) {
+    double s = 0.0;
+    AS3 const double* base = M + (valid ? row : 0);
+    int j = sub;
+    for (; j + 3 * Lt < cols; j += 4 * Lt) {
+        const double a0 = base[j * rows], a1 = base[(j + Lt) * rows], a2 = base[(j + 2 * Lt) * rows],
+                     a3 = base[(j + 3 * Lt) * rows];
+        const double x0 = x[j], x1 = x[j + Lt], x2 = x[j + 2 * Lt], x3 = x[j + 3 * Lt];
+        s += a0 * x0;
+        s += a1 * x1;
+        s += a2 * x2;
+        s += a3 * x3;
+    }
+    for (; j < cols; j += Lt) s += base[j * rows] * x[j];
+    s = subwave_sum(s, Lt);
+    return valid ? s : 0.0;
+}
+
 __device__ __forceinline__ void tiny_sweeps(SolveCtx& c, int k, LdsLevel& L, int nu, int isnsp) {
-    const int i = threadIdx.x, N = L.N;
-    const bool valid = i < N;
+    const int N = L.N, Lt = tiny_lanes(N);
+    const int i = threadIdx.x / Lt, sub = threadIdx.x % Lt;
+    const bool valid = i < N, owner = valid && sub == 0;
     const double rv = valid ? L.r[i] : 0.0;
     const double ax = valid ? L.Axi[i] : 0.0;
     const double dv = valid ? L.dinv[i] : 0.0;
@@ -669,9 +697,9 @@ __device__ __forceinline__ void tiny_sweeps(SolveCtx& c, int k, LdsLevel& L, int
         const bool ez = (c.zeromask >> k) & 1u;
         const double eo = (valid && !ez) ? L.e[i] : 0.0;
         double cc = 0.0;
-        if (isnsp) cc = wave_sum(rv - ax * eo) / L.xx;
-        const double sd = ez ? 0.0 : lds_densedot(L.dA, N, N, i, valid, L.e);
-        if (valid) L.e2[i] = eo + dv * (rv - sd - ax * cc) + cc;
+        if (isnsp) cc = wave_sum(owner ? rv - ax * eo : 0.0) / L.xx;
+        const double sd = ez ? 0.0 : lds_densedot_split(L.dA, N, N, i, sub, Lt, valid, L.e);
+        if (owner) L.e2[i] = eo + dv * (rv - sd - ax * cc) + cc;
         tiny_sync();
         AS3 double* t = L.e;
         L.e = L.e2;
@@ -688,37 +716,38 @@ __device__ __forceinline__ void tiny_pcg(SolveCtx& c, int k) {  // PCG.m:68-87, 
     const long long maxit = D->pcg.maxit;
     const int precd = D->pcg.precd;
     AS3 double* pv = as_lds(D->pcg.work);  // p shared through LDS
-    const int i = threadIdx.x, N = L.N;
-    const bool valid = i < N;
+    const int N = L.N, Lt = tiny_lanes(N);
+    const int i = threadIdx.x / Lt, sub = threadIdx.x % Lt;
+    const bool valid = i < N, owner = valid && sub == 0;
     const double dg = valid ? L.dA[i + i * N] : 1.0;
     double r = valid ? L.r[i] : 0.0;
     double p = precd == 2 ? r / dg : r;
     double d = 0.0;
-    double delta_new = wave_sum(valid ? r * p : 0.0);
+    double delta_new = wave_sum(owner ? r * p : 0.0);
     const double delta_0 = delta_new, thresh = tol * tol * delta_0;
     long long it = 0;
     while (it < maxit && delta_new > thresh) {
         const double delta_old = delta_new;
-        if (valid) pv[i] = p;
+        if (owner) pv[i] = p;
         tiny_sync();
-        const double q = lds_densedot(L.dA, N, N, i, valid, pv);
+        const double q = lds_densedot_split(L.dA, N, N, i, sub, Lt, valid, pv);
         tiny_sync();
-        const double alpha = delta_old / wave_sum(valid ? q * p : 0.0);
+        const double alpha = delta_old / wave_sum(owner ? q * p : 0.0);
         d += alpha * p;
         r -= alpha * q;
         const double w = precd == 2 ? r / dg : r;
-        delta_new = wave_sum(valid ? r * w : 0.0);
+        delta_new = wave_sum(owner ? r * w : 0.0);
         p = w + (delta_new / delta_old) * p;
         ++it;
     }
-    if (valid) L.e[i] = d;
+    if (owner) L.e[i] = d;
     tiny_sync();
     c.zeromask &= ~(1u << k);
 }
 
 // sub-cycle rooted at level k0 >= k_tiny (r_{k0} is in LDS); executed by wave 0 only
 __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
-    const int J = c.D->J, nu = c.D->nu, wc = c.D->wcycle, isnsp = c.D->isnsp, i = threadIdx.x;
+    const int J = c.D->J, nu = c.D->nu, wc = c.D->wcycle, isnsp = c.D->isnsp, t = threadIdx.x;
     unsigned visited = 0;
     int k = k0;
     bool entering = true, keep = keep0;
@@ -735,20 +764,26 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
             if (!keep) {
                 c.zeromask |= (1u << k);
                 if (nu == 0) {
-                    if (i < L.N) L.e[i] = 0.0;
+                    if (t < L.N) L.e[t] = 0.0;
                     tiny_sync();
                     c.zeromask &= ~(1u << k);
                 }
             }
             tiny_sweeps(c, k, L, nu, isnsp);
             {   // residual, then restriction into the child's right-hand side
-                const bool valid = i < L.N;
-                const double sd = lds_densedot(L.dA, L.N, L.N, i, valid, L.e);
-                if (valid) L.rr[i] = L.r[i] - sd;
+                {
+                    const int Lt = tiny_lanes(L.N), i = t / Lt, sub = t % Lt;
+                    const bool valid = i < L.N;
+                    const double sd = lds_densedot_split(L.dA, L.N, L.N, i, sub, Lt, valid, L.e);
+                    if (valid && sub == 0) L.rr[i] = L.r[i] - sd;
+                }
                 tiny_sync();
-                const bool cv = i < L.Nc;
-                const double rc = lds_densedot(L.dPt, L.Nc, L.N, i, cv, L.rr);
-                if (cv) L.rc[i] = rc;
+                {
+                    const int Lt = tiny_lanes(L.Nc), i = t / Lt, sub = t % Lt;
+                    const bool cv = i < L.Nc;
+                    const double rc = lds_densedot_split(L.dPt, L.Nc, L.N, i, sub, Lt, cv, L.rr);
+                    if (cv && sub == 0) L.rc[i] = rc;
+                }
                 tiny_sync();
             }
             visited &= ~(1u << (k + 1));
@@ -765,9 +800,10 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
             }
             LdsLevel L = lds_level(c, k);
             {
+                const int Lt = tiny_lanes(L.N), i = t / Lt, sub = t % Lt;
                 const bool valid = i < L.N;
-                const double sd = lds_densedot(L.dP, L.N, L.Nc, i, valid, lds_e(c, k + 1));
-                if (valid) L.e[i] = L.e[i] + sd;
+                const double sd = lds_densedot_split(L.dP, L.N, L.Nc, i, sub, Lt, valid, lds_e(c, k + 1));
+                if (valid && sub == 0) L.e[i] = L.e[i] + sd;
                 tiny_sync();
             }
             tiny_sweeps(c, k, L, nu, isnsp);
@@ -834,7 +870,7 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
     int k = k0, cur = 0;
     bool entering = true, keep = keep0;
     for (int guard = 0; guard < (1 << 22); ++guard) {
-        if (entering && k >= k_tiny) {   // <= 64 rows from here down: wave 0 alone
+        if (entering && k >= k_tiny) {   // <= 32 rows from here down: wave 0 alone
             SOL_DBG_T0(c);
             if (threadIdx.x < 64) {
                 SolveCtx t = c;

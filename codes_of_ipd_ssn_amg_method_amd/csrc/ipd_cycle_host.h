@@ -294,13 +294,14 @@ void amg_prepare_levels(ipd_amg* h) {
             }
         }
     };
-    // bottom run of levels with <= 64 rows (k >= 2): candidates for the wave-level sub-cycle
+    // bottom run of levels with <= 32 rows (k >= 2): candidates for the wave-level sub-cycle
+    // (33..64 rows run faster block-wide with 16 lanes per row than in one wave)
     int tiny_lo = h->J + 1;
     {
         const char* nt = std::getenv("IPD_NO_TINY");
         if (!(nt && nt[0] == '1'))
             for (int k = h->J; k >= 2; --k) {
-                if (h->L[k].A.nr > 64) break;
+                if (h->L[k].A.nr > 32) break;
                 tiny_lo = k;
             }
     }
@@ -330,7 +331,7 @@ void amg_prepare_levels(ipd_amg* h) {
         *used_out = used;
         return k_lds;
     };
-    auto tiny_from = [&](int k_lds) {   // tiny levels: <= 64 rows, cached, Jacobi (k >= 2)
+    auto tiny_from = [&](int k_lds) {   // tiny levels: <= 32 rows, cached, Jacobi (k >= 2)
         return std::max(tiny_lo, std::max(2, k_lds));
     };
     auto blk_from = [&](int k_lds) {    // cached Jacobi levels: thread-per-row sub-cycle
