@@ -31,7 +31,6 @@ namespace {
 
 constexpr int TR = 256;        // tile rows
 constexpr int TC = 16;         // tile columns per sub-tile
-constexpr int TLD = TR + 16;   // LDS column stride
 constexpr int NSC = 8;         // scalar accumulators per workgroup
 constexpr int MK = 8;          // line-search trial points evaluated by one merit pass
 
@@ -46,7 +45,7 @@ static Geo make_geo(int m, int n) {
     g.nib = cdiv(m, TR);
     const int njb = cdiv(n, TC);
     int reps = 1;
-    while (reps < 8 && (long long)g.nib * cdiv(njb, reps * 2) >= 1024) reps *= 2;
+    while (reps < 8 && (long long)g.nib * cdiv(njb, reps * 2) >= 4096) reps *= 2;
     g.reps = reps;
     g.njg = cdiv(njb, reps);
     return g;
@@ -83,67 +82,103 @@ struct Lam {
 // ---------------------------------------------------------------------------
 // tile walker
 // ---------------------------------------------------------------------------
+// 16 values per lane (one per column of a chunk) -> the 16 column sums over the wave's 64 rows.
+// A butterfly reduce-scatter over lane bits 0..3 halves the live values at every step (8+4+2+1
+// exchanges) and two more exchanges add the four 16-lane rows: 17 exchanges instead of 16 full
+// wave reductions (tools/ubench_eval.hip: 5.8 -> 6.1 TB/s at m=n=4096, 2.2 -> 2.6 at 1024).
+// On return lane l < 16 holds the sum of column colsum_index(l).
+__device__ __forceinline__ double colsum16(const double (&xv)[TC], int lane) {
+    double a8[8], a4[4], a2[2], a1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool hi = lane & 1;
+        a8[k] = (hi ? xv[k + 8] : xv[k]) + __shfl_xor(hi ? xv[k] : xv[k + 8], 1);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool hi = lane & 2;
+        a4[k] = (hi ? a8[k + 4] : a8[k]) + __shfl_xor(hi ? a8[k] : a8[k + 4], 2);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const bool hi = lane & 4;
+        a2[k] = (hi ? a4[k + 2] : a4[k]) + __shfl_xor(hi ? a4[k] : a4[k + 2], 4);
+    }
+    {
+        const bool hi = lane & 8;
+        a1 = (hi ? a2[1] : a2[0]) + __shfl_xor(hi ? a2[0] : a2[1], 8);
+    }
+    a1 += __shfl_xor(a1, 16);
+    a1 += __shfl_xor(a1, 32);
+    return a1;
+}
+__device__ __forceinline__ int colsum_index(int lane) {
+    return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+}
+
 template <class Op>
 __global__ __launch_bounds__(256) void k_tiles(const Op op, const Geo g,
                                                double* __restrict__ lpart,
                                                double* __restrict__ rpart,
                                                double* __restrict__ spart) {
-    __shared__ double tile[TC * TLD];
+    // Every wave owns 64 consecutive rows and walks its columns alone: row sums stay in a
+    // register, the column sums over the wave's rows come out of a register butterfly -- no
+    // LDS tile, no barrier inside the loop (the first version transposed 256x16 tiles through
+    // LDS and stalled three times per tile: 2.0 TB/s at m=n=4096).
     __shared__ double red[4 * NSC];
-    const int tid = threadIdx.x, ib = blockIdx.x, jg = blockIdx.y;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int ib = blockIdx.x, jg = blockIdx.y;
     const int i = ib * TR + tid;
     const bool in_i = i < g.m;
     const int ic = in_i ? i : g.m - 1;
+    const double pi = in_i ? op.P.p[i] : 0.0;
     typename Op::RowC rc;
     op.row_const(rc, ic);
     double sc[NSC];
 #pragma unroll
     for (int k = 0; k < NSC; ++k) sc[k] = 0.0;
     double lacc = 0.0;
+    double* const rrow = rpart + ((size_t)ib * 4 + wv) * g.n;
     for (int rep = 0; rep < g.reps; ++rep) {
         const int j0 = (jg * g.reps + rep) * TC;
         if (j0 >= g.n) break;  // uniform
-        if (rep) __syncthreads();
+        double xv[TC];
         // loads are issued Op::FC columns at a time: enough bytes in flight per lane without
         // spilling the ops that stream six or seven arrays
 #pragma unroll
         for (int c0 = 0; c0 < TC; c0 += Op::FC) {
             typename Op::Raw raw[Op::FC];
+            typename Op::ColC cc[Op::FC];
 #pragma unroll
             for (int jj = 0; jj < Op::FC; ++jj) {
                 const int j = min(j0 + c0 + jj, g.n - 1);
                 op.fetch(raw[jj], (size_t)j * g.m + ic);
+                // per-column uniforms (scalar loads) up front, with a clamped index: inside the
+                // bounds check below they could not be hoisted and serialised every column
+                op.col_const(cc[jj], j);
             }
 #pragma unroll
             for (int jj = 0; jj < Op::FC; ++jj) {
                 const int j = j0 + c0 + jj;
-                double xv = 0.0;
+                double x = 0.0;
                 if (in_i && j < g.n) {
-                    xv = op.compute(raw[jj], rc, j, (size_t)j * g.m + i, sc);
-                    lacc += xv * op.P.q[j];
+                    x = op.compute(raw[jj], rc, cc[jj], (size_t)j * g.m + i, sc);
+                    lacc += x * cc[jj].q;
                 }
-                tile[(c0 + jj) * TLD + tid] = xv;
+                xv[c0 + jj] = x * pi;
             }
         }
-        __syncthreads();
-        // column sums: 16 lanes per column, 16 rows per lane, then a 16-lane DPP sum
-        const int jj = tid >> 4, sub = tid & 15;
-        double cacc = 0.0;
-#pragma unroll
-        for (int k = 0; k < TR / 16; ++k) {
-            const int r = sub + 16 * k;
-            const int gi = ib * TR + r;
-            const double pi = gi < g.m ? op.P.p[gi] : 0.0;
-            cacc += tile[jj * TLD + r] * pi;
+        if (Op::NEED_AX) {
+            const double cs = colsum16(xv, lane);
+            const int col = j0 + colsum_index(lane);
+            if (lane < 16 && col < g.n) rrow[col] = cs;
         }
-        cacc = row16_sum(cacc);
-        if (sub == 0 && j0 + jj < g.n) rpart[(size_t)ib * g.n + j0 + jj] = cacc;
     }
-    if (in_i) lpart[(size_t)jg * g.m + i] = lacc;
+    if (Op::NEED_AX && in_i) lpart[(size_t)jg * g.m + i] = lacc;
 #pragma unroll
     for (int k = 0; k < NSC; ++k) {
         const double w = wave_sum(sc[k]);
-        if ((tid & 63) == 0) red[(tid >> 6) * NSC + k] = w;
+        if (lane == 0) red[wv * NSC + k] = w;
     }
     __syncthreads();
     if (tid < NSC) {
@@ -155,6 +190,7 @@ __global__ __launch_bounds__(256) void k_tiles(const Op op, const Geo g,
 
 // --- APD_SsN_Class1.m:125 / Class2 :119  wk = -wc + bk*(uk+ak*vk)/ak^2 ; partials of H*uk
 struct OpBegin {
+    static constexpr bool NEED_AX = true;
     static constexpr int FC = 16;
     Prob P;
     const double* u;
@@ -165,54 +201,76 @@ struct OpBegin {
         double c, u, v, phi;
     };
     struct RowC {};
+    struct ColC {
+        double q;
+    };
     __device__ void row_const(RowC&, int) const {}
+    __device__ void col_const(ColC& c, int j) const { c.q = P.q[j]; }
     __device__ void fetch(Raw& r, size_t idx) const {
         r.c = P.c[idx];
         r.u = u[idx];
         r.v = v[idx];
         r.phi = P.cls2 ? P.phi[idx] : 0.0;
     }
-    __device__ double compute(const Raw& r, const RowC&, int, size_t idx, double* sc) const {
+    __device__ double compute(const Raw& r, const RowC&, const ColC&, size_t idx, double* sc) const {
         w[idx] = -r.c + bk * (r.u + ak * r.v) / ak2;
         sc[3] += r.phi * r.u;
         return r.u;
     }
 };
 
-// --- :139-144,182-196  zk, s, prox(zk) and its reductions at one multiplier
-struct OpEval {
+// --- :139-144,182-196  zk, s, prox(zk) and its reductions at one multiplier.
+// Compile-time variants (class 2 / vector gama / the prob-3 merit): the pass is HBM-bound only
+// if the per-entry state stays small -- a runtime-flagged version kept 48 loads and three extra
+// accumulators alive per lane and ran at a third of the bandwidth.
+template <bool CLS2, bool GVEC, bool M3>
+struct OpEvalT {
+    static constexpr bool NEED_AX = true;
     static constexpr int FC = 16;
     Prob P;
     const double* w;
-    uint8_t* s;  // may be NULL
+    uint8_t* s;
     Lam lam;
     double itk;  // 1/tk
     struct Raw {
         double w, phi, g;
     };
     struct RowC {
-        double pi, y2;
+        double pi, y2, lamL;
+    };
+    struct ColC {
+        double y1, q;
     };
     __device__ void row_const(RowC& rc, int i) const {
         rc.pi = P.p[i];
         rc.y2 = lam.at(P.n + i);
+        rc.lamL = CLS2 ? lam.at(P.m + P.n) : 0.0;
+    }
+    __device__ void col_const(ColC& c, int j) const {
+        c.y1 = lam.at(j);
+        c.q = P.q[j];
     }
     __device__ void fetch(Raw& r, size_t idx) const {
         r.w = w[idx];
-        r.phi = P.cls2 ? P.phi[idx] : 0.0;
-        r.g = P.gama ? P.gama[idx] : P.gs;
+        if (CLS2) r.phi = P.phi[idx];
+        if (GVEC) r.g = P.gama[idx];
     }
-    __device__ double compute(const Raw& r, const RowC& rc, int j, size_t idx, double* sc) const {
-        double aty = rc.pi * lam.at(j) + rc.y2 * P.q[j];           // Aty.m:12-13
-        if (P.cls2) aty = aty + lam.at(P.m + P.n) * r.phi;          // Class2 :139
+    __device__ double compute(const Raw& r, const RowC& rc, const ColC& cc, size_t idx,
+                              double* sc) const {
+        double aty = rc.pi * cc.y1 + rc.y2 * cc.q;                  // Aty.m:12-13
+        if (CLS2) aty = aty + rc.lamL * r.phi;                      // Class2 :139
         const double z = itk * (r.w - aty);
-        const double px = prox_of(P, z, r.g);
-        const bool act = P.cls2 ? (z >= 0.0) : (z >= 0.0 && z <= r.g);
-        if (s) s[idx] = act ? 1 : 0;
+        const double g = GVEC ? r.g : P.gs;
+        const double t = z > 0.0 ? z : 0.0;
+        const double px = CLS2 ? t : (t < g ? t : g);               // prox (Class1 :32, Class2 :29)
+        const bool act = CLS2 ? (z >= 0.0) : (z >= 0.0 && z <= g);
+        s[idx] = act ? 1 : 0;
         sc[0] += px * px;
-        sc[1] += z * z;
-        sc[2] += (z - px) * (z - px);
-        sc[3] += r.phi * px;
+        if (M3) {
+            sc[1] += z * z;
+            sc[2] += (z - px) * (z - px);
+        }
+        if (CLS2) sc[3] += r.phi * px;
         sc[4] += act ? 1.0 : 0.0;
         return px;
     }
@@ -223,6 +281,7 @@ struct OpEval {
 // when the first one fails): they only need the merit, not Fk or the mask, so MK of them share
 // one read of wk.  Per trial the arithmetic is that of OpEval, operation for operation.
 struct OpMerit {
+    static constexpr bool NEED_AX = false;
     static constexpr int FC = 16;
     Prob P;
     const double* w;
@@ -236,18 +295,26 @@ struct OpMerit {
     struct RowC {
         double pi, l2, z2;
     };
+    struct ColC {
+        double l1, z1, q;
+    };
     __device__ void row_const(RowC& rc, int i) const {
         rc.pi = P.p[i];
         rc.l2 = lam[P.n + i];
         rc.z2 = zeta[P.n + i];
+    }
+    __device__ void col_const(ColC& c, int j) const {
+        c.l1 = lam[j];
+        c.z1 = zeta[j];
+        c.q = P.q[j];
     }
     __device__ void fetch(Raw& r, size_t idx) const {
         r.w = w[idx];
         r.phi = P.cls2 ? P.phi[idx] : 0.0;
         r.g = P.gama ? P.gama[idx] : P.gs;
     }
-    __device__ double compute(const Raw& r, const RowC& rc, int j, size_t, double* sc) const {
-        const double l1 = lam[j], z1 = zeta[j], qj = P.q[j];
+    __device__ double compute(const Raw& r, const RowC& rc, const ColC& cc, size_t, double* sc) const {
+        const double l1 = cc.l1, z1 = cc.z1, qj = cc.q;
         const int M = P.m + P.n;
         const double lL = P.cls2 ? lam[M] : 0.0, zL = P.cls2 ? zeta[M] : 0.0;
 #pragma unroll
@@ -265,6 +332,7 @@ struct OpMerit {
 // --- :239-242,253-254  uk1 = prox(zk), vk1, and the KKT residuals of (uk1, lk1)
 template <bool FROM_W>
 struct OpEnd {
+    static constexpr bool NEED_AX = true;
     static constexpr int FC = 8;
     Prob P;
     const double* w;      // FROM_W
@@ -279,9 +347,16 @@ struct OpEnd {
     struct RowC {
         double pi, y2;
     };
+    struct ColC {
+        double y1, q;
+    };
     __device__ void row_const(RowC& rc, int i) const {
         rc.pi = P.p[i];
         rc.y2 = lam.at(P.n + i);
+    }
+    __device__ void col_const(ColC& c, int j) const {
+        c.y1 = lam.at(j);
+        c.q = P.q[j];
     }
     __device__ void fetch(Raw& r, size_t idx) const {
         r.w = FROM_W ? w[idx] : 0.0;
@@ -290,8 +365,9 @@ struct OpEnd {
         r.phi = P.cls2 ? P.phi[idx] : 0.0;
         r.g = P.gama ? P.gama[idx] : P.gs;
     }
-    __device__ double compute(const Raw& r, const RowC& rc, int j, size_t idx, double* sc) const {
-        double aty = rc.pi * lam.at(j) + rc.y2 * P.q[j];
+    __device__ double compute(const Raw& r, const RowC& rc, const ColC& cc, size_t idx,
+                              double* sc) const {
+        double aty = rc.pi * cc.y1 + rc.y2 * cc.q;
         if (P.cls2) aty = aty + lam.at(P.m + P.n) * r.phi;
         double u1 = r.u;
         if (FROM_W) {
@@ -344,7 +420,7 @@ __device__ __forceinline__ double sum_strided(const double* __restrict__ base, i
 }
 
 __device__ __forceinline__ double ax_entry(const Parts& pt, int t) {
-    if (t < pt.g.n) return sum_strided(pt.rpart + t, pt.g.nib, (size_t)pt.g.n);
+    if (t < pt.g.n) return sum_strided(pt.rpart + t, 4 * pt.g.nib, (size_t)pt.g.n);
     return sum_strided(pt.lpart + (t - pt.g.n), pt.g.njg, (size_t)pt.g.m);
 }
 
@@ -606,6 +682,7 @@ struct WarmScal {
 
 // pass A: dd = etafk*wuk - ak^2*(wc + cAlk + sgk*cAw); partials of H*dd
 struct OpWarmA {
+    static constexpr bool NEED_AX = true;
     static constexpr int FC = 4;
     Prob P;
     const double* x;
@@ -623,10 +700,18 @@ struct OpWarmA {
     struct RowC {
         double pi, h2, b2;
     };
+    struct ColC {
+        double bj, hj, q;
+    };
     __device__ void row_const(RowC& rc, int i) const {
         rc.pi = P.p[i];
         rc.h2 = hl1[P.n + i];
         rc.b2 = b[P.n + i];
+    }
+    __device__ void col_const(ColC& c, int j) const {
+        c.bj = b[j];
+        c.hj = hl1[j];
+        c.q = P.q[j];
     }
     __device__ void fetch(Raw& r, size_t idx) const {
         r.x = x[idx];
@@ -637,11 +722,12 @@ struct OpWarmA {
         r.c = P.c[idx];
         r.phi = P.cls2 ? P.phi[idx] : 0.0;
     }
-    __device__ double compute(const Raw& r, const RowC& rc, int j, size_t idx, double* sc) const {
+    __device__ double compute(const Raw& r, const RowC& rc, const ColC& cc, size_t idx,
+                              double* sc) const {
         const double wux = (s.ak * s.gk * r.v + s.gkmu * r.x) / s.etafk;              // :63
         const double hl2 = r.l2 - s.ibk * (r.x - r.w) + s.akbk * (-(r.pi - r.w));     // :65
-        double atb = rc.pi * b[j] + rc.b2 * P.q[j];                                    // Atb
-        double aty = rc.pi * hl1[j] + rc.h2 * P.q[j];
+        double atb = rc.pi * cc.bj + rc.b2 * cc.q;                                     // Atb
+        double aty = rc.pi * cc.hj + rc.h2 * cc.q;
         const int M = P.m + P.n;
         double cAlk;
         if (P.cls2) {
@@ -661,6 +747,7 @@ struct OpWarmA {
 // pass B: xk1, vk1, wk1, pik1 and the splitting multiplier; partials of H*xk1.  H*vk1 follows in
 // the epilogue from linearity, H*vk1 = H*xk1 + (H*xk1 - H*xk)/ak, without another pass.
 struct OpWarmB {
+    static constexpr bool NEED_AX = true;
     static constexpr int FC = 4;
     Prob P;
     const double* dd;
@@ -677,9 +764,16 @@ struct OpWarmB {
     struct RowC {
         double pi, f2;
     };
+    struct ColC {
+        double fj, q;
+    };
     __device__ void row_const(RowC& rc, int i) const {
         rc.pi = P.p[i];
         rc.f2 = ff[P.n + i];
+    }
+    __device__ void col_const(ColC& c, int j) const {
+        c.fj = ff[j];
+        c.q = P.q[j];
     }
     __device__ void fetch(Raw& r, size_t idx) const {
         r.d = dd[idx];
@@ -690,8 +784,9 @@ struct OpWarmB {
         r.phi = P.cls2 ? P.phi[idx] : 0.0;
         r.g = P.gama ? P.gama[idx] : P.gs;
     }
-    __device__ double compute(const Raw& r, const RowC& rc, int j, size_t idx, double* sc) const {
-        double aty = rc.pi * ff[j] + rc.f2 * P.q[j];
+    __device__ double compute(const Raw& r, const RowC& rc, const ColC& cc, size_t idx,
+                              double* sc) const {
+        double aty = rc.pi * cc.fj + rc.f2 * cc.q;
         if (P.cls2) aty = aty + ff[P.m + P.n] * r.phi;
         const double x1 = (r.d - aty) / s.tt_etafk;                                    // :70
         const double v1 = x1 + (x1 - r.x) / s.ak;                                      // :71
@@ -842,6 +937,7 @@ struct ipd_apd {
     double* fpart = nullptr;
     int* counter = nullptr;
     double* merit = nullptr;
+    bool merit3 = false;   // class 1, prob 3: the merit needs |zk|^2 and |zk - prox(zk)|^2 (:186)
     double *phi_l = nullptr, *phi_part = nullptr;  // Ax(phi), partial sums of |phi|^2
     int phi_npart = 0;
     // script variables
@@ -921,29 +1017,44 @@ void apd_begin(ipd_apd* h, int k) {
     IPD_KERNEL_CHECK();
 }
 
+template <bool CLS2, bool GVEC, bool M3>
+void launch_eval_t(ipd_apd* h, const Lam& lam, double itk) {
+    OpEvalT<CLS2, GVEC, M3> op;
+    op.P = h->P;
+    op.w = h->w;
+    op.s = h->s;
+    op.lam = lam;
+    op.itk = itk;
+    launch_tiles(h, op);
+}
+void launch_eval(ipd_apd* h, const Lam& lam, double itk) {
+    if (h->cls == 2) return launch_eval_t<true, false, false>(h, lam, itk);
+    const bool gv = h->gama != nullptr, m3 = h->merit3;
+    if (gv)
+        m3 ? launch_eval_t<false, true, true>(h, lam, itk) : launch_eval_t<false, true, false>(h, lam, itk);
+    else
+        m3 ? launch_eval_t<false, false, true>(h, lam, itk) : launch_eval_t<false, false, false>(h, lam, itk);
+}
+
 // one pass at lam_base (+ step*zeta): F -> F_out, multiplier -> lam_out, mask -> h->s
 EvalRes apd_eval(ipd_apd* h, const double* lam_base, const double* zeta, double step,
                  double* lam_out, double* F_out, const double* F_old) {
     ProfScope ps(h->ctx, PROF_EVAL);
-    OpEval op;
-    op.P = h->P;
-    op.w = h->w;
-    op.s = h->s;
-    op.lam = Lam{lam_base, zeta, step};
-    op.itk = 1.0 / h->tk;
-    launch_tiles(h, op);
+    const Lam lamv{lam_base, zeta, step};
+    const double itk = 1.0 / h->tk;
+    launch_eval(h, lamv, itk);
     EvalFin f;
     f.pt = parts_of(h);
     f.P = h->P;
     f.w = h->w;
-    f.lam = op.lam;
+    f.lam = lamv;
     f.wlk = h->wlk;
     f.Fold = F_old;
     f.lam_out = lam_out;
     f.F = F_out;
     f.tmask = h->tmask;
     f.bk1 = h->bk1;
-    f.itk = op.itk;
+    f.itk = itk;
     f.out = h->dscal;
     f.fpart = h->fpart;
     f.counter = h->counter;
@@ -1087,6 +1198,7 @@ void apd_iterate(ipd_apd* h, const ipd_apd_opts& o, const AmgOpts& amg, ipd_rng*
     const double bk1 = h->bk1, tk = h->tk;
     const double ssn_tol = std::max(bk1 / ((double)k * (double)k), o.ssn_tol1);   // :123
     const bool merit3 = !c2 && o.prob >= 3;
+    h->merit3 = merit3;
     auto merit = [&](const EvalRes& e) {
         const double f0 = bk1 / 2.0 * e.lam2 - e.wlk_lam;                         // :182
         return merit3 ? f0 + 0.5 * tk * (e.z2 - e.zmp2) : f0 + 0.5 * tk * e.prox2;
@@ -1426,7 +1538,8 @@ extern "C" int ipd_apd_create(ipd_ctx* ctx, const ipd_apd_data* d, ipd_apd** out
         h->s = A.alloc<uint8_t>(mn);
         const Geo& g = h->geo;
         h->lpart = A.alloc<double>((size_t)g.njg * m);
-        h->rpart = A.alloc<double>((size_t)g.nib * n);
+        h->rpart = A.alloc<double>((size_t)g.nib * 4 * n);
+        IPD_HIP(hipMemsetAsync(h->rpart, 0, sizeof(double) * (size_t)g.nib * 4 * n, ctx->stream));
         h->spart = A.alloc<double>((size_t)g.nib * g.njg * NSC);
         h->dscal = reinterpret_cast<ApdScal*>(A.alloc<double>(sizeof(ApdScal) / sizeof(double) + 1));
         h->fpart = A.alloc<double>((size_t)cdiv(L, EB) * NFS);
@@ -1599,18 +1712,14 @@ extern "C" int ipd_apd_bench_eval(ipd_apd* h, int32_t reps, double* total_ms,
         IPD_REQUIRE(h->tk > 0.0, IPD_E_ARG, "ipd_apd_begin must run first");
         ipd_ctx* ctx = h->ctx;
         ctx->set_device();
-        OpEval op;
-        op.P = h->P;
-        op.w = h->w;
-        op.s = h->s;
-        op.lam = Lam{h->lam, nullptr, 0.0};
-        op.itk = 1.0 / h->tk;
+        const Lam lamv{h->lam, nullptr, 0.0};
+        const double itk = 1.0 / h->tk;
         hipEvent_t e0, e1;
         IPD_HIP(hipEventCreate(&e0));
         IPD_HIP(hipEventCreate(&e1));
-        launch_tiles(h, op);
+        launch_eval(h, lamv, itk);
         IPD_HIP(hipEventRecord(e0, ctx->stream));
-        for (int r = 0; r < reps; ++r) launch_tiles(h, op);
+        for (int r = 0; r < reps; ++r) launch_eval(h, lamv, itk);
         IPD_HIP(hipEventRecord(e1, ctx->stream));
         IPD_HIP(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -1625,7 +1734,7 @@ extern "C" int ipd_apd_bench_eval(ipd_apd* h, int32_t reps, double* total_ms,
             double by = 8.0 * mn + mn + 16.0 * h->M;
             if (h->phi) by += 8.0 * mn;
             if (h->gama) by += 8.0 * mn;
-            by += 8.0 * ((double)h->geo.njg * h->m + (double)h->geo.nib * h->n);
+            by += 8.0 * ((double)h->geo.njg * h->m + 4.0 * h->geo.nib * h->n);
             *bytes_per_pass = by;
         }
     });
