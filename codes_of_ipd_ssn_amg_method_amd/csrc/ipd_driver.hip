@@ -6,18 +6,18 @@
 // Every mn-sized vector (c, xk, vk, wk, phi, gama, the mask s) lives in HBM for the whole
 // run; the host keeps only the scalars of the scripts (ak, bk, tk, norms, counters).
 //
-// The mn-sized work of one Newton step is ONE streaming pass (`OpEval`): from wk and the
+// The mn-sized work of one Newton step is ONE streaming pass (`OpEvalT`): from wk and the
 // multiplier it forms zk = (wk - H'lk)/tk on the fly (never stored), writes the byte mask
 // s = (0 <= zk <= gama), and reduces Ax(prox(zk)), |prox(zk)|^2, phi'prox(zk) -- i.e. Fk,
 // the active set and the Armijo merit of one trial point come out of 8 bytes read + 1 byte
 // written per entry, where the scripts make ~10 passes (Aty, zk, prox, Ax, norms, s).
 // These passes are HBM-bound: 9 B/entry (class 1), 17 B/entry with phi (class 2).
 //
-// Layout: x(i,j) = x[i + j*m] (MATLAB's reshape(x,m,n)); a workgroup owns a 256-row x
-// (16*reps)-column tile, lanes run along i (coalesced), 16 independent loads in flight per
-// lane and array.  Row sums accumulate in registers, column sums go through an LDS copy of
-// the 256x16 sub-tile; partial sums are combined by a single-workgroup epilogue kernel in a
-// fixed order (deterministic, no float atomics), which also does all O(m+n) vector work.
+// Layout: x(i,j) = x[i + j*m] (MATLAB's reshape(x,m,n)); a wave owns 64 rows x (16*reps)
+// columns, lanes run along i (coalesced), 16 independent loads in flight per lane and array.
+// Row sums accumulate in registers, the 16 column sums of a chunk come out of a register
+// butterfly (k_tiles); partial sums are combined by small epilogue kernels in a fixed order
+// (deterministic, no float atomics), which also do all O(m+n) vector work.
 #pragma clang fp contract(off)
 
 #include <algorithm>

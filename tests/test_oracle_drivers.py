@@ -1,0 +1,71 @@
+"""CPU checks of the restated drivers (oracle/drivers.py), the checker of rows f1/f2.
+
+They pin the restatement against (a) the histories stored in tests/golden/ for the reference's
+bundled inputs (regression of the oracle itself), (b) the convergence facts SURVEY.md 8c
+records for an independent restatement (Class 1: k = 58, f = 1.126046; Class 2: k = 53), and
+(c) self-consistency: inner_solver 1 (direct) and 4 (AMG) must walk the same path."""
+import os
+
+import numpy as np
+
+from oracle import drivers as D
+from oracle import ipd_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def small(cls, m, n, seed=1):
+    rs = np.random.RandomState(seed)
+    c, r, l = rs.random_sample(m * n), rs.random_sample(n), rs.random_sample(m)
+    if cls == 1:
+        return c, r, l * r.sum() / l.sum()
+    return c, r, l, 0.65 * min(r.sum(), l.sum())
+
+
+def test_golden_histories_record_the_surveyed_convergence():
+    g1 = np.load(os.path.join(GOLD, "class1_500_driver.npz"))
+    g2 = np.load(os.path.join(GOLD, "class2_500_driver.npz"))
+    assert int(g1["k"]) == 58 and abs(float(g1["fval"]) - 1.126046) < 5e-7
+    assert int(g2["k"]) == 53
+    for g in (g1, g2):
+        assert len(g["fxk"]) == int(g["k"]) + 1 == len(g["KKT_xk"])
+        assert len(g["SsN_itnum"]) == int(g["k"])
+        rr = max(g["KKT_xk"][-1] / (1 + g["KKT_xk"][0]), g["KKT_lk"][-1] / (1 + g["KKT_lk"][0]))
+        assert rr <= 1e-6                                     # APD_SsN_Class1.m:265-266
+
+
+def test_warmup_class1_reproduces_the_stored_warm_start():
+    d = np.load(os.path.join(GOLD, "data1_500.npz"))
+    g = np.load(os.path.join(GOLD, "class1_500_driver.npz"))
+    one = np.ones(500)
+    x0, l0 = D.warmup_class1(d["c"], d["r"], d["l"], one, one, np.inf, 100)
+    assert abs(np.linalg.norm(x0) - float(g["warm_x_norm"])) <= 1e-9 * float(g["warm_x_norm"])
+    assert int((x0 > 0).sum()) == int(g["warm_x_nnz"])
+    # lk0 moves by 7e-9 under 1e-16 perturbations of Ax (a different BLAS is enough)
+    assert np.linalg.norm(l0 - g["warm_l"]) <= 1e-6 * (1 + np.linalg.norm(g["warm_l"]))
+
+
+def test_class1_direct_and_amg_inner_solvers_agree():
+    c, r, l = small(1, 28, 28)
+    one = np.ones(28)
+    a = D.apd_ssn_class1(c, r, l, one, one, np.inf, inner="direct")
+    b = D.apd_ssn_class1(c, r, l, one, one, np.inf, inner="amg", rng=O.matlab_rng())
+    assert a["converged"] and b["converged"] and a["k"] == b["k"]
+    assert abs(a["fval"] - b["fval"]) <= 1e-8
+    x = b["xk"]
+    assert x.min() >= 0 and np.linalg.norm(O.Ax(x, one, one) - np.concatenate([r, l])) <= 1e-5
+
+
+def test_class2_direct_and_amg_inner_solvers_agree():
+    c, r, l, mu = small(2, 26, 30)
+    p, q, phi = np.ones(26), np.ones(30), np.ones(26 * 30)
+    a = D.apd_ssn_class2(c, r, l, p, q, mu, phi, inner="direct")
+    b = D.apd_ssn_class2(c, r, l, p, q, mu, phi, inner="amg", rng=O.matlab_rng())
+    assert a["converged"] and b["converged"] and a["k"] == b["k"]
+    assert abs(a["fval"] - b["fval"]) <= 1e-8
+    u = b["uk"]
+    mn = 26 * 30
+    x, y, z = u[:mn], u[mn:mn + 30], u[mn + 30:]
+    assert min(x.min(), y.min(), z.min()) >= 0
+    assert abs(phi @ x - mu) <= 1e-5 * (1 + mu)              # transported mass
+    assert np.linalg.norm(O.Ax(x, p, q) + np.concatenate([y, z]) - np.concatenate([r, l])) <= 1e-5
