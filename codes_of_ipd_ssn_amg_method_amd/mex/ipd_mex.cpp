@@ -20,8 +20,11 @@
 static ipd_ctx* g_ctx = nullptr;
 static ipd_rng* g_rng = nullptr;   // MATLAB-compatible stream; reseed with ipd_mex('rng', seed)
 static ipd_amg* g_h = nullptr;     // the "global" hierarchy of Class_AMG / MG_Vcycle / MG_Wcycle
+static ipd_apd* g_apd = nullptr;   // the driver workspace of apd_create / apd_warmup / apd_run
 
 static void at_exit() {
+    if (g_apd) ipd_apd_destroy(g_apd);
+    g_apd = nullptr;
     if (g_h) ipd_amg_destroy(g_h);
     if (g_rng) ipd_rng_destroy(g_rng);
     if (g_ctx) ipd_ctx_destroy(g_ctx);
@@ -189,6 +192,49 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(it);
         if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(res);
         if (nlhs > 3) { plhs[3] = mxCreateDoubleMatrix(1, 2, mxREAL); mxGetDoubles(plhs[3])[0] = (double)info[0]; mxGetDoubles(plhs[3])[1] = (double)info[1]; }
+    } else if (fn == "apd_create") {   // ipd_mex('apd_create', cls, c,r,l,p,q, gama | mu,phi): the loaded workspace
+        ipd_apd_data d; std::memset(&d, 0, sizeof(d));
+        d.cls = (int32_t)mxGetScalar(a[0]);
+        d.c = mxGetDoubles(a[1]); d.r = mxGetDoubles(a[2]); d.l = mxGetDoubles(a[3]);
+        d.p = mxGetDoubles(a[4]); d.q = mxGetDoubles(a[5]);
+        d.m = (int64_t)mxGetNumberOfElements(a[4]); d.n = (int64_t)mxGetNumberOfElements(a[5]);
+        if (d.cls == 1) {
+            if (mxGetNumberOfElements(a[6]) == 1) d.gama_scalar = mxGetScalar(a[6]);
+            else d.gama = mxGetDoubles(a[6]);
+        } else {
+            d.mu = mxGetScalar(a[6]); d.phi = mxGetDoubles(a[7]);
+        }
+        if (g_apd) { ipd_apd_destroy(g_apd); g_apd = nullptr; }
+        chk(ipd_apd_create(g_ctx, &d, &g_apd));
+    } else if (fn == "apd_warmup" || fn == "apd_state") {   // [uk,lk] = ... (warmup_class1.m:2 / warmup_class2.m:1)
+        if (!g_apd) mexErrMsgIdAndTxt("ipdamg:state", "no workspace: call apd_create first");
+        if (fn == "apd_warmup") {
+            const double res = mxGetScalar(a[0]), mi = mxGetScalar(a[1]);
+            chk(ipd_apd_warmup(g_apd, res, mxIsInf(mi) ? -1 : (int64_t)mi));
+        }
+        // sizes follow from the workspace: query them through a state read into oversized buffers
+        const mxArray* sz = nrhs > 3 ? a[2] : nullptr; (void)sz;
+        const size_t U = (size_t)mxGetScalar(mexGetVariablePtr("caller", "ipd_U")), L = (size_t)mxGetScalar(mexGetVariablePtr("caller", "ipd_L"));
+        plhs[0] = col(U); mxArray* lk = col(L); double bk = 0;
+        chk(ipd_apd_get_state(g_apd, mxGetDoubles(plhs[0]), nullptr, mxGetDoubles(lk), &bk));
+        if (nlhs > 1) plhs[1] = lk; else mxDestroyArray(lk);
+        if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(bk);
+    } else if (fn == "apd_run") {      // out = ipd_mex('apd_run', amg_options[, iters]): the main loop, inner_solver = 4
+        if (!g_apd) mexErrMsgIdAndTxt("ipdamg:state", "no workspace: call apd_create first");
+        ipd_amg_opts o = opts_of(a[0]); ipd_apd_result r;
+        chk(ipd_apd_run(g_apd, nullptr, &o, g_rng, nrhs > 2 ? (int32_t)mxGetScalar(a[1]) : 1000000, &r));
+        const char* names[] = {"converged", "k", "fval", "rr", "SumAMG", "TotalAMG", "FailAMG", "MaxAMG",
+                               "fxk", "KKT_xk", "KKT_lk", "KKT_yk", "KKT_zk", "SsN_itnum"};
+        plhs[0] = mxCreateStructMatrix(1, 1, 14, names);
+        const double sc[8] = {(double)r.converged, (double)r.k, r.fval, r.rr, (double)r.sum_amg,
+                              (double)r.total_amg, (double)r.fail_amg, (double)r.max_amg};
+        for (int i = 0; i < 8; ++i) mxSetFieldByNumber(plhs[0], 0, i, mxCreateDoubleScalar(sc[i]));
+        for (int w = 0; w < 6; ++w) {   // histories as column vectors, like the script's variables
+            int64_t cnt = 0; chk(ipd_apd_history(g_apd, w, nullptr, 0, &cnt));
+            mxArray* v = col((size_t)cnt);
+            chk(ipd_apd_history(g_apd, w, mxGetDoubles(v), cnt, &cnt));
+            mxSetFieldByNumber(plhs[0], 0, 8 + w, v);
+        }
     } else {
         mexErrMsgIdAndTxt("ipdamg:arg", "unknown function '%s'", fn.c_str());
     }
