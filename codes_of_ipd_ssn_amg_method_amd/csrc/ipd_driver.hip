@@ -1575,6 +1575,14 @@ extern "C" void ipd_apd_destroy(ipd_apd* h) {
     delete h;
 }
 
+extern "C" int ipd_apd_dims(const ipd_apd* h, int64_t* len_u, int64_t* len_lam) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h, IPD_E_ARG, "NULL handle");
+        if (len_u) *len_u = (int64_t)h->U;
+        if (len_lam) *len_lam = (int64_t)h->L;
+    });
+}
+
 extern "C" int ipd_apd_warmup(ipd_apd* h, double res, int64_t maxit) {
     return ipd_guard([&] {
         IPD_REQUIRE(h, IPD_E_ARG, "NULL handle");

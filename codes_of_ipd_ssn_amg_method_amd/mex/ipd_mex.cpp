@@ -212,10 +212,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             const double res = mxGetScalar(a[0]), mi = mxGetScalar(a[1]);
             chk(ipd_apd_warmup(g_apd, res, mxIsInf(mi) ? -1 : (int64_t)mi));
         }
-        // sizes follow from the workspace: query them through a state read into oversized buffers
-        const mxArray* sz = nrhs > 3 ? a[2] : nullptr; (void)sz;
-        const size_t U = (size_t)mxGetScalar(mexGetVariablePtr("caller", "ipd_U")), L = (size_t)mxGetScalar(mexGetVariablePtr("caller", "ipd_L"));
-        plhs[0] = col(U); mxArray* lk = col(L); double bk = 0;
+        int64_t U = 0, L = 0; chk(ipd_apd_dims(g_apd, &U, &L));
+        plhs[0] = col((size_t)U); mxArray* lk = col((size_t)L); double bk = 0;
         chk(ipd_apd_get_state(g_apd, mxGetDoubles(plhs[0]), nullptr, mxGetDoubles(lk), &bk));
         if (nlhs > 1) plhs[1] = lk; else mxDestroyArray(lk);
         if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(bk);

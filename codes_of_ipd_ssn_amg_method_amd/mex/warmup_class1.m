@@ -4,6 +4,5 @@ if nargin == 6, res = 1e-1; maxit = inf; end
 if nargin == 7, maxit = inf; end
 if res == 0 && maxit == inf, error('res = 0 and maxit = inf'); end
 ipd_mex('apd_create', 1, c, r, l, double(p), double(q), gama);
-ipd_U = numel(c); ipd_L = numel(r) + numel(l); %#ok<NASGU> sizes read by the gateway
 [xk,lk] = ipd_mex('apd_warmup', res, maxit);
 end

@@ -4,6 +4,5 @@ if nargin == 7, res = 1e-1; maxit = inf; end
 if nargin == 8, maxit = inf; end
 if res == 0 && maxit == inf, error('res = 0 and maxit = inf'); end
 ipd_mex('apd_create', 2, c, r, l, double(p), double(q), mu, double(phi));
-ipd_U = numel(c) + numel(r) + numel(l); ipd_L = numel(r) + numel(l) + 1; %#ok<NASGU>
 [uk,lk] = ipd_mex('apd_warmup', res, maxit);
 end

@@ -281,6 +281,8 @@ typedef struct ipd_apd_result {
 
 int ipd_apd_create(ipd_ctx*, const ipd_apd_data* d, ipd_apd** out);
 void ipd_apd_destroy(ipd_apd* h);
+/* lengths of uk (mn, or mn+n+m for class 2) and lk (n+m, or n+m+1)                 */
+int ipd_apd_dims(const ipd_apd* h, int64_t* len_u, int64_t* len_lam);
 /* [xk,lk] = warmup_class1(c,r,l,p,q,gama,res,maxit) (Class1/warmup_class1.m:2) and
  * [uk,lk] = warmup_class2(c,r,l,p,q,mu,phi,res,maxit) (Class2/warmup_class2.m:1):
  * the result becomes the driver state (xk = vk = xk0, lk = lk0, bk = 1; Class1 :59-60).
