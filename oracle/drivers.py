@@ -53,7 +53,7 @@ def warmup_class1(c, r, l, p, q, gama, maxit=100):
 
 
 def apd_ssn_class1(c, r, l, p, q, gama, capture=(), inner="direct", maxit=100, rng=None,
-                   amg_cycle="w", verbose=False, start=None):
+                   amg_cycle="w", verbose=False, start=None, prob=2):
     """`APD_SsN_Class1.m:30-275`.  `capture` = iterable of (k, ssn_it) pairs (1-based) whose
     Newton systems are recorded as dicts(s, bk1, tk, z, k, ssn).  inner = "direct"
     (inner_solver 1, `:146-148`) or "amg" (inner_solver 4, `:160-161`, oracle Hybrid_AMG)."""
@@ -105,15 +105,20 @@ def apd_ssn_class1(c, r, l, p, q, gama, capture=(), inner="direct", maxit=100, r
             else:
                 pd = dict(bk1=bk1, tk=tk, q=q, p=p, T=Tz, H0=H0, z=-Fk_old)
                 zeta, it_in, _, _ = O.Hybrid_AMG(pd, opts, rng)
+            def merit(f0, zk):                                   # :183-187 / :192-196
+                if prob < 3:
+                    return f0 + 0.5 * tk * np.linalg.norm(prox(zk)) ** 2
+                return f0 + 0.5 * tk * (np.linalg.norm(zk) ** 2 - np.linalg.norm(zk - prox(zk)) ** 2)
+
             f0 = bk1 / 2 * np.linalg.norm(lk_old) ** 2 - wlk @ lk_old
-            cF_old = f0 + 0.5 * tk * np.linalg.norm(prox(zk)) ** 2
+            cF_old = merit(f0, zk)
             ll = 0
             ress = abs(Fk_old @ zeta)
             while True:
                 lk_new = lk_old + delta ** ll * zeta
                 f0 = bk1 / 2 * np.linalg.norm(lk_new) ** 2 - wlk @ lk_new
                 zk = 1 / tk * (wk - O.Aty(lk_new, p, q))
-                cF_new = f0 + 0.5 * tk * np.linalg.norm(prox(zk)) ** 2
+                cF_new = merit(f0, zk)
                 if not (cF_new > cF_old - nu * delta ** ll * ress) or ll == ll_max:
                     break
                 ll += 1

@@ -148,7 +148,7 @@ def test_warmup_argument_rules():
 # ---------------------------------------------------------------------------
 # whole runs
 # ---------------------------------------------------------------------------
-def check_run(out, ref, keys):
+def check_run(out, ref, keys, late_counts=True, rtol=1e-7):
     assert out["converged"] and ref["converged"]
     assert out["k"] == ref["k"]
     assert abs(out["fval"] - ref["fval"]) <= 1e-8 * max(1.0, abs(ref["fval"]))
@@ -156,11 +156,12 @@ def check_run(out, ref, keys):
     # from the rounding floor; later the test compares numbers of size 1e-11 and may flip by one
     a, b = out["SsN_itnum"].astype(int), np.asarray(ref["SsN_itnum"])
     assert a.shape == b.shape and np.array_equal(a[:15], b[:15])
-    assert np.abs(a - b).max() <= 1 and np.array_equal(a[:len(a) // 2], b[:len(a) // 2])
+    if late_counts:
+        assert np.abs(a - b).max() <= 1 and np.array_equal(a[:len(a) // 2], b[:len(a) // 2])
     for key in keys:
         a, b = np.asarray(out[key]), np.asarray(ref[key])
         assert a.shape == b.shape
-        assert np.all(np.abs(a - b) <= 1e-7 * (1 + np.abs(b))), key
+        assert np.all(np.abs(a - b) <= rtol * (1 + np.abs(b))), key
 
 
 @pytest.mark.parametrize("m,n", [(24, 24), (40, 28)])
@@ -179,6 +180,30 @@ def test_apd_class1_run_matches_oracle(m, n):
     early = [r for r in recs if r["k"] <= 15]
     assert [(r["k"], r["ssn_it"], r["E"]) for r in early] == \
         [(e["k"], e["ssn"], e["E"]) for e in ref["log"] if e["k"] <= 15]
+    ws.close()
+
+
+def test_apd_class1_capacity_constrained_run_matches_oracle():
+    """prob = 3 (`APD_SsN_Class1.m:23,183-187`): finite vector gama, the |zk|^2 - |zk-prox|^2 merit."""
+    m, n = 30, 26
+    pr = problem(1, m, n, seed=4)
+    rs = np.random.RandomState(11)
+    # capacities that keep the problem feasible: l <= Gama*1n, r <= Gama'*1m with room to spare
+    gama = (2.5 * max(pr["l"].max() / n, pr["r"].max() / m)) * (0.6 + 0.8 * rs.random_sample(m * n))
+    start = D.warmup_class1(pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], gama, 100)
+    ref = D.apd_ssn_class1(pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], gama, inner="amg",
+                           start=start, rng=O.matlab_rng(), prob=3)
+    ws = ws_of(1, pr, gama)
+    ws.set_state(start[0], start[0], start[1], 1.0)
+    out = ws.run(dict(retol=1e-11, bigph=1, maxit=30, theta=1 / 4, smoth=5, cycle="w", isnsp=1,
+                      inter=1), ipd().MatlabRand(5489), prob=3)
+    out.update(ws.history())
+    # the prob-3 merit |zk|^2 - |zk - prox(zk)|^2 cancels, so late Armijo decisions (|Fk| ~ 1e-10)
+    # are rounding-dependent: Newton-step counts are compared over the first 15 iterations only
+    check_run(out, ref, ("fxk", "KKT_xk", "KKT_lk"), late_counts=False, rtol=1e-5)
+    x = ws.state()[0]
+    assert x.min() >= 0 and np.all(x <= gama + 1e-12)
+    assert (x >= gama - 1e-9).sum() > 0, "no capacity is active: the test would not exercise gama"
     ws.close()
 
 
