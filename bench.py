@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--cycle", default="v", choices=["v", "w"])
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-maskop", action="store_true",
+                    help="keep the CSR sweeps on level 1 (no 1-bit-per-entry operator)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,7 +114,7 @@ def main():
     # one in the process (torch bundles its own libamdhip64 with the same SONAME).
     import codes_of_ipd_ssn_amg_method_amd as ipd
     from codes_of_ipd_ssn_amg_method_amd import _lib
-    from ctypes import byref, c_double, c_int
+    from ctypes import byref, c_double, c_int, c_int64
 
     dist = None
     if world > 1:
@@ -130,6 +132,17 @@ def main():
     h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
     setup_s = time.perf_counter() - t0
     ctx = _lib.get_ctx()
+    # Hybrid_AMG attaches the matrix-free level-1 operator itself (csrc/ipd_hybrid.hip); the
+    # bench builds the hierarchy through Class_AMG's interface, so it asks for it explicitly
+    maskop = False
+    if not args.no_maskop:
+        from ctypes import c_int32 as _ci32
+        dp = _lib.DeviceBuffer.from_array(np.ones(m))
+        dq = _lib.DeviceBuffer.from_array(np.ones(n))
+        got = _ci32(0)
+        _lib.check(_lib.lib.ipd_amg_attach_mask_operator(h.handle, dp.ptr, dq.ptr, c_int64(m),
+                                                         c_int64(n), c_double(TK), byref(got)))
+        maskop = bool(got.value)
     db = _lib.DeviceBuffer.from_array(f)
     dx = _lib.DeviceBuffer.from_array(guess)
 
@@ -207,6 +220,7 @@ def main():
                                    m, args.mask, args.rho, args.cycle.upper()),
                    "M": M, "E": int(s.sum()), "levels": h.level_sizes(),
                    "level_nnz": [h.level_dims(k)[1] for k in range(1, h.J + 1)],
+                   "level1_operator": "bit mask + scale vectors" if maskop else "CSR",
                    "parallelism": ("row-block sharded x%d, RCCL all-gather" % world) if sharded
                    else ("replicas x%d" % world if world > 1 else "single GPU")},
         "cycle_bytes_algorithmic": bytes_per_cycle,
@@ -229,11 +243,23 @@ def main():
             reps = 200
             _lib.check(_lib.lib.ipd_amg_bench_sweeps(h.handle, _ci(k), _ci(reps), byref(ms),
                                                      byref(lps), byref(bps)))
-            per_level.append({"level": k, "us_per_launch": 1e3 * ms.value / (reps * lps.value),
+            per_level.append({"level": k,
+                              "kernel": "k_smooth_mask" if (k == 1 and maskop) else "k_smooth",
+                              "us_per_launch": 1e3 * ms.value / (reps * lps.value),
                               "bytes_per_launch": bps.value / lps.value,
                               "GBps": bps.value * reps / ms.value / 1e6})
             # weight = launches per cycle of this level (2 nu sweeps)
             w = 2 * opts["smoth"] * (2 ** (k - 1) if args.cycle == "w" and k + 1 < h.J else 1)
+            if per_level[-1]["kernel"] != "k_smooth":
+                # level 1 through the bit-mask operator: it does not stream the matrix, so it
+                # is reported beside the roofline of k_smooth, not inside it
+                nwords = n * ((m + 63) // 64) + m * ((n + 63) // 64)
+                result["level1_mask_operator"] = {
+                    "kernel": "k_smooth_mask", "us_per_launch": per_level[-1]["us_per_launch"],
+                    "csr_equivalent_bytes_per_launch": per_level[-1]["bytes_per_launch"],
+                    "actual_bytes_per_launch": (8 * nwords) / 2 + 8 * (4 * M + M // 2),
+                    "launches_per_cycle": w * lps.value}
+                continue
             tot_bytes += w * bps.value
             tot_ms += w * ms.value / reps
             launches += w * lps.value

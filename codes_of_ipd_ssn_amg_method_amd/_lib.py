@@ -122,6 +122,7 @@ EXPORTS = [
     "ipd_apd_opts_init", "ipd_apd_create", "ipd_apd_destroy", "ipd_apd_dims", "ipd_apd_warmup",
     "ipd_apd_set_state", "ipd_apd_get_state", "ipd_apd_run", "ipd_apd_history",
     "ipd_apd_records", "ipd_apd_begin", "ipd_apd_eval", "ipd_apd_bench_eval", "ipd_prof_read", "ipd_amg_bench_subcycle",
+    "ipd_amg_attach_mask_operator",
 ]
 
 

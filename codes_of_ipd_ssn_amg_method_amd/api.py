@@ -193,6 +193,20 @@ class AMGHierarchy:
     def J(self) -> int:
         return int(lib.ipd_amg_num_levels(self.handle))
 
+    def attach_mask_operator(self, p, q, tk) -> bool:
+        """Matrix-free level 1 (``ipd_amg_attach_mask_operator``): True when level 1 is exactly
+        Hybrid_AMG's rescaled operator for these ``p, q, tk`` and the 1-bit-per-entry sweeps are
+        now in use; False leaves the CSR kernels in place."""
+        p_, q_ = f64(p), f64(q)
+        dp = L.DeviceBuffer.from_array(p_)
+        dq = L.DeviceBuffer.from_array(q_)
+        got = c_int32(0)
+        check(lib.ipd_amg_attach_mask_operator(self.handle, dp.ptr, dq.ptr, c_int64(p_.size),
+                                               c_int64(q_.size), c_double(float(tk)), byref(got)))
+        _h_sync = get_ctx()
+        _h_sync.sync()
+        return bool(got.value)
+
     def level_dims(self, k: int):
         rows, nnz = c_int64(), c_int64()
         check(lib.ipd_amg_level_dims(self.handle, c_int(k), byref(rows), byref(nnz)))

@@ -400,6 +400,147 @@ void pcg_dev(ipd_ctx* ctx, const Csr& H, const double* e, const double* guess, d
 }
 
 // ---------------------------------------------------------------------------
+// matrix-free level-1 operator (the ASAtz.m idea, made to work)
+// ---------------------------------------------------------------------------
+// In Hybrid_AMG's rescaled system Ae = bk1*Q0^2 + (Q0*T*Q0 + Q0*H0*Q0)/tk the off-diagonal
+// block is the active-set mask times a rank-one matrix: Ae(j, n+i) = -s_ij * (q_j^2/tk) * p_i^2.
+// A Gauss-Seidel half sweep on the bipartite level therefore needs ONE BIT per entry plus
+// two scale vectors instead of 12 bytes: at rho = 1, m = n = 1024 a half sweep reads 128 KB of
+// mask instead of 12.6 MB of CSR.  The operator is derived from A_1's own CSR arrays and is
+// used only if every entry matches the rank-one form to 1e-12 (k_maskop_build verifies), so a
+// caller that hands in any other matrix silently keeps the CSR kernels.
+struct MaskOp {
+    int nf, nc;           // F rows (column constraints, n), C rows (row constraints, m)
+    int nwf, nwc;         // 64-bit words per F row (over i) and per C row (over j)
+    const unsigned long long* fbits;  // [nf][nwf]
+    const unsigned long long* cbits;  // [nc][nwc]
+    const double* alpha;  // nf: q_j^2 / tk
+    const double* beta;   // nc: p_i^2
+    const double* diag;   // nf + nc
+};
+
+// one wave per row: sets the row's bits, checks the rank-one form; bad[0] != 0 on any mismatch
+__global__ __launch_bounds__(256) void k_maskop_build(int N, int nf, const int* __restrict__ rp,
+                                                      const int* __restrict__ ci,
+                                                      const double* __restrict__ va,
+                                                      const double* __restrict__ alpha,
+                                                      const double* __restrict__ beta, int nwf,
+                                                      int nwc, unsigned long long* __restrict__ fbits,
+                                                      unsigned long long* __restrict__ cbits,
+                                                      double* __restrict__ diag, int* __restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < N; r += nwaves) {
+        const bool frow = r < nf;
+        bool wrong = false;
+        for (int t = rp[r] + lane; t < rp[r + 1]; t += 64) {
+            const int c = ci[t];
+            const double v = va[t];
+            if (c == r) {
+                diag[r] = v;
+                continue;
+            }
+            if (frow == (c < nf)) {   // an entry inside the F or the C block: not bipartite
+                wrong = true;
+                continue;
+            }
+            const int j = frow ? r : c, i = (frow ? c : r) - nf;
+            const double ref = -(alpha[j] * beta[i]);
+            if (!(fabs(v - ref) <= 1e-12 * fabs(ref))) wrong = true;
+            if (frow)
+                atomicOr(&fbits[(size_t)r * nwf + (i >> 6)], 1ull << (i & 63));
+            else
+                atomicOr(&cbits[(size_t)(r - nf) * nwc + (j >> 6)], 1ull << (j & 63));
+        }
+        if (wrong) atomicExch(bad, 1);
+    }
+}
+
+// One half (F rows or C rows) of the bigraph Gauss-Seidel sweep, same arithmetic as
+// phase_smooth (SmoothArgs semantics) with the row sums taken from the bit mask.  A wave owns
+// a row; lane l walks 16 bits of word l/4; the operand half vector is staged pre-scaled.
+static constexpr int MASK_RW = 1;   // rows per wave of k_smooth_mask
+
+__global__ __launch_bounds__(BT) void k_smooth_mask(const SmoothArgs a, const MaskOp mo) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    __shared__ double red[16];
+    const LevelDev& lv = a.lv;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool frows = a.row0 < mo.nf;          // this launch updates F rows; operands are C columns
+    const int oplen = frows ? mo.nc : mo.nf, opoff = frows ? mo.nf : 0;
+    const double* __restrict__ scale = frows ? mo.beta : mo.alpha;
+    const double* __restrict__ osc = frows ? mo.alpha : mo.beta;   // the row's own scale
+    const bool ez = a.eold_zero != 0;
+    const bool skip = ez && a.u0 >= a.u1;       // nothing to gather: A*e == 0
+    const bool nsp = a.isnsp != 0;
+    const int nw = frows ? mo.nwf : mo.nwc;
+    // ---- one burst of independent requests: the rows' own scalars, the pieces of
+    // xig = 1'r - (A1)'e_old, the operand half vector (pre-scaled, zero-padded to whole words)
+    const int RW = min(MASK_RW, 64 / nw);       // rows per wave: their mask words fill <= 64 lanes
+    const int row_first =
+        __builtin_amdgcn_readfirstlane(a.row0 + (blockIdx.x * (BT / 64) + wv) * RW);
+    // the wave's RW*nw mask words are contiguous: lane l fetches word l now, the row loops
+    // broadcast them with readlane (fetching them per row cost a global round trip per row)
+    unsigned long long wreg = 0;
+    {
+        const unsigned long long* __restrict__ bits0 = frows ? mo.fbits : mo.cbits;
+        const int lr0 = row_first - (frows ? 0 : mo.nf);
+        if (!skip && lane < RW * nw && row_first + lane / nw < a.row1)
+            wreg = bits0[(size_t)lr0 * nw + lane];
+    }
+    double eo[MASK_RW], rv[MASK_RW], dv[MASK_RW], axi[MASK_RW], dg[MASK_RW], os[MASK_RW];
+#pragma unroll
+    for (int u = 0; u < MASK_RW; ++u) {
+        const int row = min(row_first + u, a.row1 - 1);
+        eo[u] = ez ? 0.0 : a.eold[row];
+        rv[u] = lv.r[row];
+        dv[u] = lv.dinv[row];
+        axi[u] = nsp ? lv.Axi[row] : 0.0;
+        dg[u] = mo.diag[row];
+        os[u] = osc[row - (frows ? 0 : mo.nf)];
+    }
+    double cpart = 0.0;
+    if (nsp)
+        for (int j = tid; j < lv.N; j += BT) cpart += lv.r[j] - lv.Axi[j] * (ez ? 0.0 : a.eold[j]);
+    if (!skip)
+        for (int t = tid; t < nw * 64; t += BT) {
+            const int j = opoff + t;
+            double x = 0.0;
+            if (t < oplen) x = scale[t] * ((j >= a.u0 && j < a.u1) ? a.win[j] : (ez ? 0.0 : a.eold[j]));
+            xs[t] = x;
+        }
+    double c = 0.0;
+    if (nsp) c = block_sum(cpart, red) / lv.xx[0];   // MG_Vcycle.m:19 (block_sum synchronises)
+    else __syncthreads();
+    const unsigned wlo = (unsigned)wreg, whi = (unsigned)(wreg >> 32);
+#pragma unroll
+    for (int u = 0; u < MASK_RW; ++u) {
+        const int row = row_first + u;
+        if (u >= RW || row >= a.row1) break;   // wave-uniform
+        double s = 0.0;
+        if (!skip) {
+            // lane l owns bit l of every word; the operands xs[64*w + l] are conflict-free
+            for (int wi = 0; wi < nw; ++wi) {
+                const unsigned lo = __builtin_amdgcn_readlane(wlo, u * nw + wi);
+                const unsigned hi = __builtin_amdgcn_readlane(whi, u * nw + wi);
+                const unsigned half = lane < 32 ? lo : hi;
+                const double x = xs[wi * 64 + lane];
+                s += ((half >> (lane & 31)) & 1u) ? x : 0.0;
+            }
+            s = wave_sum(s);
+        }
+        if (lane == 0) {
+            const double ae = dg[u] * eo[u] - os[u] * s;        // (A x)_row
+            const double g_i = rv[u] - ae - axi[u] * c;
+            const double wvl = eo[u] + dv[u] * g_i;             // e + R*(g - Axi*c)
+            if (a.wout) a.wout[row] = wvl;
+            a.enew[row] = wvl + c;                              //   ... + xi*c
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // whole Class_AMG solve phase in ONE workgroup
 // ---------------------------------------------------------------------------
 // Realistic Newton systems have tiny hierarchies (every level a few thousand nonzeros,

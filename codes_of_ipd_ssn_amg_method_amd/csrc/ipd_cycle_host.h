@@ -36,6 +36,9 @@ struct CycleState {
     size_t solve_lds = 0;
     bool small_ok = false;
     bool solve_cached = false;
+    // matrix-free level-1 operator (bit mask + scale vectors), see k_smooth_mask
+    bool mask_ok = false;
+    MaskOp maskop{};
     // single-workgroup sub-cycle rooted at level k_sub (0 = none), see k_subcycle
     SolveDesc* d_sub = nullptr;
     int k_sub = 0;
@@ -679,6 +682,27 @@ static void launch_sweep(ipd_amg* h, CycleState* st, int k, int isnsp, bool post
         a.u0 = a.u1 = 0;
         a.wout = nullptr;
         run_rows(ctx, st, 0, lv.N, go, {a.enew});
+    } else if (k == 1 && st->mask_ok && st->shard_ranks == 1) {
+        // bit-mask operator: same two half sweeps, 1 bit per matrix entry
+        const MaskOp& mo = st->maskop;
+        const size_t dyn = sizeof(double) * 64 * (size_t)std::max(mo.nwf, mo.nwc);
+        auto half = [&](int r0, int r1) {
+            a.row0 = r0;
+            a.row1 = r1;
+            const int nwh = (r0 < mo.nf) ? mo.nwf : mo.nwc;
+            const int grid = std::max(1, cdiv(r1 - r0, std::min(MASK_RW, 64 / nwh) * (BT / 64)));
+            hipLaunchKernelGGL(k_smooth_mask, dim3(grid), dim3(BT), dyn, ctx->stream, a, mo);
+            IPD_KERNEL_CHECK();
+        };
+        const int f0 = post ? lv.nf : 0, f1 = post ? lv.N : lv.nf;
+        const int s0 = post ? 0 : lv.nf, s1 = post ? lv.nf : lv.N;
+        flush_fused(ctx, st);
+        a.u0 = a.u1 = 0;
+        half(f0, f1);
+        a.u0 = f0;
+        a.u1 = f1;
+        a.wout = nullptr;
+        half(s0, s1);
     } else {
         // pre: F rows then C rows (Rk{1});  post: C rows then F rows (Rk{1}')
         const int f0 = post ? lv.nf : 0, f1 = post ? lv.N : lv.nf;  // first half rows
@@ -692,6 +716,77 @@ static void launch_sweep(ipd_amg* h, CycleState* st, int k, int isnsp, bool post
     }
     rn.e_zero = false;
     std::swap(lv.e, lv.e2);
+}
+
+__global__ void k_maskop_scales(int nf, int nc, const double* __restrict__ p,
+                                const double* __restrict__ q, double itk,
+                                double* __restrict__ alpha, double* __restrict__ beta) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nf + nc; t += gridDim.x * blockDim.x) {
+        if (t < nf)
+            alpha[t] = q[t] * q[t] * itk;
+        else
+            beta[t - nf] = p[t - nf] * p[t - nf];
+    }
+}
+
+// Derives the bit-mask form of level 1 from its CSR arrays; keeps the CSR kernels (returns
+// false) unless A_1 is exactly Hybrid_AMG's rescaled operator for these p, q, tk.
+bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int m, int n, double tk) {
+    ipd_ctx* ctx = h->ctx;
+    CycleState* st = state_of(h);
+    if (!st) return false;
+    const char* env = std::getenv("IPD_NO_MASKOP");
+    if (env && env[0] == '1') return false;
+    const Level& lv = h->L[1];
+    if (h->J < 2 || lv.nf != n || lv.N != m + n || tk == 0.0) return false;
+    if (std::max(m, n) > 4096) return false;   // a row's mask words must fit one wave (64 words)
+    Arena& ar = *h->arena;
+    MaskOp mo;
+    mo.nf = n;
+    mo.nc = m;
+    mo.nwf = cdiv(m, 64);
+    mo.nwc = cdiv(n, 64);
+    unsigned long long* fb = ar.alloc<unsigned long long>((size_t)n * mo.nwf);
+    unsigned long long* cb = ar.alloc<unsigned long long>((size_t)m * mo.nwc);
+    double* alpha = ar.alloc<double>((size_t)n);
+    double* beta = ar.alloc<double>((size_t)m);
+    double* diag = ar.alloc<double>((size_t)lv.N);
+    int* bad = ctx->scratch->alloc<int>(1);
+    IPD_HIP(hipMemsetAsync(fb, 0, sizeof(unsigned long long) * (size_t)n * mo.nwf, ctx->stream));
+    IPD_HIP(hipMemsetAsync(cb, 0, sizeof(unsigned long long) * (size_t)m * mo.nwc, ctx->stream));
+    IPD_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_maskop_scales, dim3(cdiv(lv.N, 256)), dim3(256), 0, ctx->stream, n, m, p_dev,
+                       q_dev, 1.0 / tk, alpha, beta);
+    hipLaunchKernelGGL(k_maskop_build, dim3(std::max(1, std::min(cdiv(lv.N, 4), 2048))), dim3(256), 0,
+                       ctx->stream, lv.N, n, lv.A.rp, lv.A.ci, lv.A.va, (const double*)alpha,
+                       (const double*)beta, mo.nwf, mo.nwc, fb, cb, diag, bad);
+    IPD_KERNEL_CHECK();
+    if (ctx->fetch1(bad) != 0) return false;
+    mo.fbits = fb;
+    mo.cbits = cb;
+    mo.alpha = alpha;
+    mo.beta = beta;
+    mo.diag = diag;
+    st->maskop = mo;
+    st->mask_ok = true;
+    // captured graphs (if any) were recorded with the CSR sweeps
+    for (auto& g : st->gexec)
+        if (g) {
+            (void)hipGraphExecDestroy(g);
+            g = nullptr;
+        }
+    return true;
+}
+
+extern "C" int ipd_amg_attach_mask_operator(ipd_amg* h, const double* p_dev, const double* q_dev,
+                                            int64_t m, int64_t n, double tk, int32_t* attached) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && p_dev && q_dev && m > 0 && n > 0, IPD_E_ARG, "bad argument");
+        h->ctx->set_device();
+        CallScope scope(h->ctx);
+        const bool ok = amg_attach_maskop(h, p_dev, q_dev, (int)m, (int)n, tk);
+        if (attached) *attached = ok ? 1 : 0;
+    });
 }
 
 // Solves A_k e = r_k approximately; r in L[k].r, result in L[k].e.

@@ -371,9 +371,16 @@ static double host_sum(ipd_ctx* ctx, const double* d, int n) {
 }
 
 // Solves Ae u = f for one (sub)system with Class_AMG and returns its statistics.
+struct MaskHint {   // p, q, tk of the rescaled system when A is the whole Ae (else p == NULL)
+    const double* p = nullptr;
+    const double* q = nullptr;
+    int m = 0, n = 0;
+    double tk = 0.0;
+};
+
 static void class_amg_on(ipd_ctx* ctx, const Csr& A, const double* f, AmgOpts o, int isnsp,
                          long long fnode, double gscale, ipd_rng* rng, double* u_out, int* it,
-                         double* rel_res) {
+                         double* rel_res, const MaskHint& mh = MaskHint()) {
     const int N = A.nr;
     o.isnsp = isnsp;
     o.fnode = fnode;
@@ -386,6 +393,7 @@ static void class_amg_on(ipd_ctx* ctx, const Csr& A, const double* f, AmgOpts o,
     {
         ProfScope ps(ctx, PROF_AMG_SETUP);
         h.reset(amg_setup(ctx, A, o, rng));
+        if (mh.p && o.bigph) amg_attach_maskop(h.get(), mh.p, mh.q, mh.m, mh.n, mh.tk);
     }
     int32_t its = 0;
     double rr = 0.0;
@@ -441,7 +449,13 @@ void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const doub
         const int isnsp = sum_dk(nullptr, M) != 0.0 ? 0 : 1;
         int it = 0;
         double rr = 0.0;
-        class_amg_on(ctx, Ae, f, opts, isnsp, n, gscale, rng, u, &it, &rr);
+        MaskHint mh;
+        mh.p = p;
+        mh.q = q;
+        mh.m = m;
+        mh.n = n;
+        mh.tk = tk;
+        class_amg_on(ctx, Ae, f, opts, isnsp, n, gscale, rng, u, &it, &rr, mh);
         out->itamg = it;
         out->resamg = rr;
         out->it_num = 1;

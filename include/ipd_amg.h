@@ -312,6 +312,14 @@ int ipd_apd_eval(ipd_apd* h, const double* lam, uint8_t* s_out, double* t_out, d
 /* HIP-event timing of `reps` eval passes on the current workspace (bench.py).   */
 int ipd_apd_bench_eval(ipd_apd* h, int32_t reps, double* total_ms, double* bytes_per_pass);
 
+/* Matrix-free level-1 operator.  If level 1 of `h` is exactly Hybrid_AMG's
+ * rescaled operator Ae = bk1*Q0^2 + (Q0*T*Q0 + Q0*H0*Q0)/tk for these p, q, tk (checked entry by
+ * entry against A_1's CSR values), the level-1 Gauss-Seidel sweeps read one BIT per entry (the
+ * active-set mask) instead of 12 bytes.  *attached = 0 leaves the CSR kernels in place.
+ * ipd_hybrid_amg(_dev) and ipd_amg4pot attach it themselves.                               */
+int ipd_amg_attach_mask_operator(ipd_amg* h, const double* p_dev, const double* q_dev,
+                                 int64_t m, int64_t n, double tk, int32_t* attached);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------- */
 /* Runs `cycles` iterations of the Class_AMG loop body (residual, one V/W
  * cycle, norm) on the fixed hierarchy without convergence exit, timed with HIP
