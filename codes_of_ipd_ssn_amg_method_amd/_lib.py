@@ -66,7 +66,8 @@ class ipd_apd_data(Structure):
 class ipd_apd_opts(Structure):
     _fields_ = [("maxit", c_int32), ("kkt_tol", c_double), ("ssn_it", c_int32),
                 ("ssn_tol1", c_double), ("nu", c_double), ("delta", c_double),
-                ("ll_max", c_int32), ("prob", c_int32)]
+                ("ll_max", c_int32), ("prob", c_int32), ("inner_solver", c_int32),
+                ("pcg_retol", c_double), ("pcg_maxit", c_int64)]
 
 
 class ipd_ssn_rec(Structure):
@@ -122,7 +123,8 @@ EXPORTS = [
     "ipd_apd_opts_init", "ipd_apd_create", "ipd_apd_destroy", "ipd_apd_dims", "ipd_apd_warmup",
     "ipd_apd_set_state", "ipd_apd_get_state", "ipd_apd_run", "ipd_apd_history",
     "ipd_apd_records", "ipd_apd_begin", "ipd_apd_eval", "ipd_apd_bench_eval", "ipd_prof_read", "ipd_amg_bench_subcycle",
-    "ipd_amg_attach_mask_operator",
+    "ipd_amg_attach_mask_operator", "ipd_twogrid_bigph", "ipd_hybrid_twogrid", "ipd_amg4pot_twogrid",
+    "ipd_aug_pcg", "ipd_pcg4pot",
 ]
 
 

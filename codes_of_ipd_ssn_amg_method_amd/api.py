@@ -28,7 +28,8 @@ __all__ = [
     "Ax", "Aty", "ASAt", "invAAt", "invHHt", "strength", "cf_split", "mis_set", "transfer",
     "Class_AMG", "AMGHierarchy", "MG_Vcycle", "MG_Wcycle", "PCG", "components", "Hybrid_AMG",
     "AMG4POT", "MatlabRand", "IpdError", "amg_options", "APDWorkspace", "warmup_class1",
-    "warmup_class2", "APD_SsN_Class1", "APD_SsN_Class2",
+    "warmup_class2", "APD_SsN_Class1", "APD_SsN_Class2", "twogrid_bigph", "Hybrid_twogrid",
+    "aug_PCG", "PCG4POT",
 ]
 
 
@@ -376,11 +377,86 @@ def Hybrid_AMG(prob_data: dict, amg_options: dict, rng: MatlabRand | None = None
     return zeta, int(it.value), float(res.value), info
 
 
+def Hybrid_twogrid(prob_data: dict, amg_options: dict, rng: MatlabRand | None = None):
+    """``[zeta,itamg,resamg,info] = Hybrid_twogrid(prob_data,amg_options)``
+    (``Hybrid_twogrid.m:1``)."""
+    rng = rng or MatlabRand()
+    s, keep, m, n = _prob_struct(prob_data, False)
+    o = _opts_struct(amg_options)
+    zeta = np.empty(m + n)
+    it = c_int32()
+    res = c_double()
+    info = np.zeros(2, np.int64)
+    check(lib.ipd_hybrid_twogrid(_h(), byref(s), byref(o), rng.handle, dptr(zeta), byref(it),
+                                 byref(res), iptr(info)))
+    return zeta, int(it.value), float(res.value), info
+
+
+def twogrid_bigph(A, b, amg_options: dict | None = None):
+    """``[x,it,rel_res,rel_resk,rhok] = twogrid_bigph(A,b,amg_options)``
+    (``AMG/twogrid_bigph.m:1``); ``amg_options.fnode`` is required."""
+    b = f64(b)
+    if amg_options is None:                       # :6-9 (fnode = 0 cannot work; kept as an error)
+        amg_options = dict(retol=1e-12, maxit=20, fnode=0, smoth=10, isnsp=1, guess=None)
+    a = CscIn(A)
+    o = _opts_struct(dict(amg_options))
+    maxit = int(o.maxit) if o.maxit >= 0 else 50
+    x = np.empty(b.size)
+    it = c_int32()
+    rel = c_double()
+    rel_resk = np.full(maxit + 2, np.nan)
+    rhok = np.full(maxit + 2, np.nan)
+    g = amg_options.get("guess")
+    g = f64(g) if g is not None else None
+    check(lib.ipd_twogrid_bigph(_h(), a.ref(), dptr(b), dptr(g) if g is not None else None, byref(o),
+                                dptr(x), byref(it), byref(rel), dptr(rel_resk), dptr(rhok)))
+    k = it.value + 1
+    return x, int(it.value), float(rel.value), rel_resk[:k].copy(), rhok[:k].copy()
+
+
+def _pcg_opts_struct(o: dict | None) -> L.ipd_pcg_opts:
+    s = L.ipd_pcg_opts()
+    lib.ipd_pcg_opts_init(byref(s))
+    if o:
+        if o.get("retol") is not None:
+            s.retol = float(o["retol"])
+        if o.get("maxit") is not None:
+            s.maxit = int(o["maxit"])
+        if o.get("precd") is not None:
+            s.precd = int(o["precd"])
+    return s
+
+
+def aug_PCG(prob_data: dict, pcg_options: dict | None = None):
+    """``[zeta,itpcg,respcg,info] = aug_PCG(prob_data,pcg_options)`` (``aug_PCG.m:1``)."""
+    s, keep, m, n = _prob_struct(prob_data, False)
+    o = _pcg_opts_struct(pcg_options)
+    zeta = np.empty(m + n)
+    it = c_int64()
+    res = c_double()
+    info = np.zeros(2, np.int64)
+    check(lib.ipd_aug_pcg(_h(), byref(s), byref(o), dptr(zeta), byref(it), byref(res), iptr(info)))
+    return zeta, int(it.value), float(res.value), info
+
+
+def PCG4POT(prob_data: dict, pcg_options: dict | None = None):
+    """``[zeta,itpcg,respcg,info] = PCG4POT(prob_data,pcg_options)``
+    (``Class2/PCG4POT.m:1``)."""
+    s, keep, m, n = _prob_struct(prob_data, True)
+    o = _pcg_opts_struct(pcg_options)
+    zeta = np.empty(m + n + 1)
+    it = c_int64()
+    res = c_double()
+    info = np.zeros(2, np.int64)
+    check(lib.ipd_pcg4pot(_h(), byref(s), byref(o), dptr(zeta), byref(it), byref(res), iptr(info)))
+    return zeta, int(it.value), float(res.value), info
+
+
 def AMG4POT(prob_data: dict, amg_options: dict, str_: str = "amg", rng: MatlabRand | None = None):
     """``[zeta,itamg,resamg,info] = AMG4POT(prob_data,amg_options,str)``
-    (``Class2/AMG4POT.m:1``)."""
-    if str_ != "amg":
-        raise IpdError(L.IPD_E_UNSUPPORTED, "only the 'amg' inner solver is built (SURVEY f4)")
+    (``Class2/AMG4POT.m:1``); ``str`` = ``'amg'`` or ``'twogrid'`` (``:44-51``)."""
+    if str_ not in ("amg", "twogrid"):
+        raise ValueError("AMG4POT: str must be 'amg' or 'twogrid'")
     rng = rng or MatlabRand()
     s, keep, m, n = _prob_struct(prob_data, True)
     o = _opts_struct(amg_options)
@@ -388,8 +464,8 @@ def AMG4POT(prob_data: dict, amg_options: dict, str_: str = "amg", rng: MatlabRa
     it = c_int32()
     res = c_double()
     info = np.zeros(2, np.int64)
-    check(lib.ipd_amg4pot(_h(), byref(s), byref(o), rng.handle, dptr(zeta), byref(it), byref(res),
-                          iptr(info)))
+    fn = lib.ipd_amg4pot if str_ == "amg" else lib.ipd_amg4pot_twogrid
+    check(fn(_h(), byref(s), byref(o), rng.handle, dptr(zeta), byref(it), byref(res), iptr(info)))
     return zeta, int(it.value), float(res.value), info
 
 

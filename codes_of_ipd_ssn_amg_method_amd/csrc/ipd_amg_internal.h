@@ -15,7 +15,12 @@ struct AmgOpts {
     int isnsp = 0;
     int inter = 1;
     long long fnode = -1;
+    // AMG/twogrid_bigph.m as a special case of the hierarchy: exactly two levels whatever the
+    // size (:25-38), coarse solve PCG(Ac, rrc, struct('retol',[],'maxit',1e2,'precd',2)) (:72-73)
+    bool twogrid = false;
+    long long pcg_maxit = 10000;   // MG_Vcycle.m:43 PCG(A,r): PCG.m:20 defaults
 };
+AmgOpts amg_fill_twogrid_defaults(const ipd_amg_opts* o);
 AmgOpts amg_fill_defaults(const ipd_amg_opts* o);
 
 struct Level {
@@ -83,6 +88,7 @@ struct HybridOut {
     double resamg = 0.0;
     long long num_comp = 0, it_num = 0;
 };
+// opts.twogrid selects Hybrid_twogrid.m (twogrid_bigph on every large component)
 void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
                     const double* q, int m, int n, double bk1, double tk, const double* z,
                     const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out);
@@ -90,3 +96,13 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
                  const double* q, int m, int n, double bk1, double tk, const double* z,
                  const uint8_t* s, const double* phi, const AmgOpts& opts, ipd_rng* rng,
                  double* zeta, HybridOut* out);
+// aug_PCG.m / Class2/PCG4POT.m (inner_solver = 3): PCG on the kernel-augmented system
+void aug_pcg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p, const double* q,
+                 int m, int n, double bk1, double tk, const double* z, double tol, long long maxit,
+                 double* zeta, HybridOut* out);
+void pcg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p, const double* q,
+                 int m, int n, double bk1, double tk, const double* z, const uint8_t* s,
+                 const double* phi, double tol, long long maxit, double* zeta, HybridOut* out);
+// Jk = bk1*I + (T + H0)/tk (APD_SsN_Class1.m:151, inner_solver = 2)
+void build_jk(ipd_ctx* ctx, Arena& dst, const Csr& H0, const double* tdiag, double bk1, double tk,
+              Csr* J);

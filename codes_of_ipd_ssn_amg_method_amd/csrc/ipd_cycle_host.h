@@ -226,7 +226,7 @@ void amg_prepare_levels(ipd_amg* h) {
         a.d = cl.e;
         a.work = ar.alloc<double>(4 * (size_t)cl.A.nr);
         a.tol = 1e-11;
-        a.maxit = 10000;
+        a.maxit = h->opts.pcg_maxit;
         a.precd = 2;
         a.out = nullptr;
         a.nresk = 0;

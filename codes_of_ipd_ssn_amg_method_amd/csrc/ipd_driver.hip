@@ -1189,6 +1189,7 @@ void copy_dev(ipd_apd* h, double* dst, const double* src, size_t n) {
 
 // one APD iteration                                       Class1 :101-275, Class2 :95-285
 void apd_iterate(ipd_apd* h, const ipd_apd_opts& o, const AmgOpts& amg, ipd_rng* rng) {
+    const int solver = o.inner_solver;
     ipd_ctx* ctx = h->ctx;
     const int k = ++h->k;
     const bool c2 = h->cls == 2;
@@ -1227,19 +1228,38 @@ void apd_iterate(ipd_apd* h, const ipd_apd_opts& o, const AmgOpts& amg, ipd_rng*
             hipLaunchKernelGGL(k_negate, dim3(cdiv(h->L, 256)), dim3(256), 0, ctx->stream, h->L,
                                (const double*)F_old, h->negF);                     // z = -Fk_old
             IPD_KERNEL_CHECK();
-            if (c2)
+            if (solver == 2) {                                     // :149-152  PCG(Jk,-Fk_old)
+                Csr Jk;
+                build_jk(ctx, *ctx->scratch, H0, nullptr, bk1, tk, &Jk);
+                long long it2 = 0;
+                double res2 = 0.0;
+                pcg_dev(ctx, Jk, h->negF, nullptr, o.pcg_retol, o.pcg_maxit, 2, h->zeta, &it2, &res2,
+                        nullptr);
+                ho.itamg = (int)std::min<long long>(it2, 2147483647LL);
+                ho.resamg = res2;
+            } else if (solver == 3) {                              // :157-159 / Class2 :167-169
+                if (c2)
+                    pcg4pot_dev(ctx, H0, h->tmask, h->p, h->q, h->m, h->n, bk1, tk, h->negF, h->s,
+                                h->phi, o.pcg_retol, o.pcg_maxit, h->zeta, &ho);
+                else
+                    aug_pcg_dev(ctx, H0, nullptr, h->p, h->q, h->m, h->n, bk1, tk, h->negF,
+                                o.pcg_retol, o.pcg_maxit, h->zeta, &ho);
+            } else if (c2) {                                       // 4: 'amg', 5: 'twogrid'
                 amg4pot_dev(ctx, H0, h->tmask, h->p, h->q, h->m, h->n, bk1, tk, h->negF, h->s,
                             h->phi, amg, rng, h->zeta, &ho);                       // Class2 :171
-            else
+            } else {
                 hybrid_amg_dev(ctx, H0, nullptr, h->p, h->q, h->m, h->n, bk1, tk, h->negF, amg,
                                rng, h->zeta, &ho);                                 // Class1 :161
+            }
         }
         const int itpcg = ho.itamg;
-        if (itpcg == amg.maxit)
-            ++h->fail_amg;                                                         // :163-169
-        else
-            h->max_amg = std::max<long long>(h->max_amg, itpcg);
-        if (itpcg > 0) ++h->total_amg;
+        if (solver >= 4) {
+            if (itpcg == amg.maxit)
+                ++h->fail_amg;                                                     // :163-169
+            else
+                h->max_amg = std::max<long long>(h->max_amg, itpcg);
+            if (itpcg > 0) ++h->total_amg;
+        }
         pmin = std::min<long long>(pmin, itpcg);
         pmax = std::max<long long>(pmax, itpcg);
         psum += itpcg;
@@ -1472,6 +1492,9 @@ extern "C" void ipd_apd_opts_init(int32_t cls, ipd_apd_opts* o) {
     o->delta = 0.9;
     o->ll_max = 500;
     o->prob = 2;
+    o->inner_solver = 4;
+    o->pcg_retol = 1e-11;
+    o->pcg_maxit = 10000;
 }
 
 extern "C" int ipd_apd_create(ipd_ctx* ctx, const ipd_apd_data* d, ipd_apd** out) {
@@ -1635,7 +1658,11 @@ extern "C" int ipd_apd_run(ipd_apd* h, const ipd_apd_opts* o, const ipd_amg_opts
         IPD_REQUIRE(oo.maxit > 0 && oo.ssn_it > 0 && oo.ll_max >= 0 && oo.delta > 0.0 &&
                         oo.delta < 1.0,
                     IPD_E_ARG, "bad driver options");
-        const AmgOpts ao = amg_fill_defaults(amg);
+        IPD_REQUIRE(oo.inner_solver >= 2 && oo.inner_solver <= 5, IPD_E_UNSUPPORTED,
+                    "inner_solver must be 2, 3, 4 or 5 (1, the direct solve, is not built)");
+        IPD_REQUIRE(!(oo.inner_solver == 2 && h->cls == 2), IPD_E_UNSUPPORTED,
+                    "inner_solver = 2 (PCG on the bordered system) is not built for class 2");
+        const AmgOpts ao = oo.inner_solver == 5 ? amg_fill_twogrid_defaults(amg) : amg_fill_defaults(amg);
         h->ctx->set_device();
         ensure_kkt(h);
         for (int it = 0; it < iters && h->k < oo.maxit && !h->converged; ++it)

@@ -587,10 +587,11 @@ __global__ void k_axpby(int n, double a, const double* __restrict__ x, double b,
         out[i] = a * x[i] + b * y[i];
 }
 
-void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
-                        const double* q, int m, int n, double bk1, double tk, const double* z,
-                        const uint8_t* s, const double* phi, const AmgOpts& opts, ipd_rng* rng,
-                        double* zeta, HybridOut* out) {
+template <class SOLVE>
+static void pot_reduce(ipd_ctx* ctx, const Csr& H0, const double* p, const double* q, int m, int n,
+                       double bk1, double tk, const double* z, const uint8_t* s, const double* phi,
+                       double* zeta, HybridOut* out, SOLVE solve) {
+    (void)H0;
     const int M = m + n;
     const size_t mn = (size_t)m * n;
     Arena& tmp = *ctx->scratch;
@@ -611,8 +612,8 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
     double* vv = tmp.alloc<double>((size_t)M);
     double* ww = tmp.alloc<double>((size_t)M);
     HybridOut o1, o2;
-    hybrid_amg_dev(ctx, H0, tdiag, p, q, m, n, bk1, tk, v, opts, rng, vv, &o1);   // :46
-    hybrid_amg_dev(ctx, H0, tdiag, p, q, m, n, bk1, tk, w, opts, rng, ww, &o2);   // :47
+    solve(v, vv, &o1);                                                    // :46
+    solve(w, ww, &o2);                                                    // :47
     const double vvv = host_dot(ctx, v, vv, M);
     const double vww = host_dot(ctx, v, ww, M);
     const double tt = sg * sg / (phi_e - sg * sg * vvv);                  // :53
@@ -626,6 +627,212 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
     out->resamg = std::max(o1.resamg, o2.resamg);
     out->num_comp = std::max(o1.num_comp, o2.num_comp);
     out->it_num = std::max(o1.it_num, o2.it_num);
+}
+
+void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
+                 const double* q, int m, int n, double bk1, double tk, const double* z,
+                 const uint8_t* s, const double* phi, const AmgOpts& opts, ipd_rng* rng,
+                 double* zeta, HybridOut* out) {
+    auto solve = [&](const double* rhs, double* x, HybridOut* o) {
+        hybrid_amg_dev(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o);
+    };
+    pot_reduce(ctx, H0, p, q, m, n, bk1, tk, z, s, phi, zeta, out, solve);
+}
+
+// ---------------------------------------------------------------------------
+// aug_PCG                                                          (aug_PCG.m:11-36)
+// ---------------------------------------------------------------------------
+// augAe = [Y'QK Y  Y'QK ; QK Y  Ae] with Y the component indicators and QK = bk1*Q + K/tk
+// diagonal, so the first nc rows are  [d_c , qk_i for the members i of c]  and row nc+i is
+// [qk_i at column c(i) , row i of Ae shifted by nc]; columns come out sorted.
+__global__ void k_aug_qk(int M, int n, const double* __restrict__ p, const double* __restrict__ q,
+                         const double* __restrict__ t, double bk1, double itk,
+                         double* __restrict__ qk) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+        const double qp = i < n ? q[i] : -p[i - n];
+        const double kk = t ? (qp * t[i]) * qp : 0.0;          // K = Q0*T*Q0
+        qk[i] = bk1 * (qp * qp) + itk * kk;                     // aug_PCG.m:27
+    }
+}
+__global__ void k_aug_rowlen(int nc, int M, const int* __restrict__ cr, const int* __restrict__ rp,
+                             int* __restrict__ len) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nc + M; r += gridDim.x * blockDim.x)
+        len[r] = r < nc ? 1 + cr[r + 1] - cr[r] : 1 + rp[r - nc + 1] - rp[r - nc];
+}
+// one wave per row of the augmented matrix; also the right-hand side [Y'f ; f]
+__global__ __launch_bounds__(256) void k_aug_fill(int nc, int M, const int* __restrict__ cr,
+                                                  const int* __restrict__ cp,
+                                                  const int* __restrict__ blocks,
+                                                  const double* __restrict__ qk,
+                                                  const double* __restrict__ f,
+                                                  const int* __restrict__ rp,
+                                                  const int* __restrict__ ci,
+                                                  const double* __restrict__ va,
+                                                  const int* __restrict__ orp, int* __restrict__ oci,
+                                                  double* __restrict__ ova, double* __restrict__ of) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int r = wave; r < nc + M; r += nwaves) {
+        const int ob = orp[r];
+        if (r < nc) {
+            const int b = cr[r], e = cr[r + 1];
+            if (lane == 0) {   // sums in ascending member order, like the sparse products
+                double d = 0.0, fs = 0.0;
+                for (int t = b; t < e; ++t) {
+                    d += qk[cp[t]];
+                    fs += f[cp[t]];
+                }
+                oci[ob] = r;
+                ova[ob] = d;
+                of[r] = fs;
+            }
+            for (int t = b + lane; t < e; t += 64) {
+                oci[ob + 1 + (t - b)] = nc + cp[t];
+                ova[ob + 1 + (t - b)] = qk[cp[t]];
+            }
+        } else {
+            const int i = r - nc, b = rp[i];
+            if (lane == 0) {
+                oci[ob] = blocks[i];
+                ova[ob] = qk[i];
+                of[r] = f[i];
+            }
+            for (int t = b + lane; t < rp[i + 1]; t += 64) {
+                oci[ob + 1 + (t - b)] = nc + ci[t];
+                ova[ob + 1 + (t - b)] = va[t];
+            }
+        }
+    }
+}
+__global__ void k_aug_back(int M, int n, int nc, const int* __restrict__ blocks,
+                           const double* __restrict__ U, const double* __restrict__ p,
+                           const double* __restrict__ q, double* __restrict__ zeta) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+        const double qp = i < n ? q[i] : -p[i - n];
+        zeta[i] = qp * (U[blocks[i]] + U[nc + i]);              // :35-36
+    }
+}
+
+void aug_pcg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p, const double* q,
+                 int m, int n, double bk1, double tk, const double* z, double tol, long long maxit,
+                 double* zeta, HybridOut* out) {
+    IPD_REQUIRE(tk != 0.0, IPD_E_ARG, "tk must be nonzero");
+    const int M = m + n;
+    Arena& tmp = *ctx->scratch;
+    Csr Ae;
+    build_Ae(ctx, tmp, H0, tdiag, p, q, m, n, bk1, tk, &Ae);
+    double* f = tmp.alloc<double>((size_t)M);
+    const int g = elems_grid(M);
+    hipLaunchKernelGGL(k_scale_qp, dim3(g), dim3(256), 0, ctx->stream, M, n, p, q, z, f);
+    IPD_KERNEL_CHECK();
+    Components cc;
+    find_components(ctx, H0, &cc);                                                  // :24
+    const int nc = cc.ncomp;
+    int* d_cr = tmp.alloc<int>((size_t)nc + 1);
+    int* d_cp = tmp.alloc<int>((size_t)M);
+    int* d_bl = tmp.alloc<int>((size_t)M);
+    ctx->upload(d_cr, cc.r.data(), (size_t)nc + 1);
+    ctx->upload(d_cp, cc.p.data(), (size_t)M);
+    ctx->upload(d_bl, cc.blocks.data(), (size_t)M);
+    double* qk = tmp.alloc<double>((size_t)M);
+    hipLaunchKernelGGL(k_aug_qk, dim3(g), dim3(256), 0, ctx->stream, M, n, p, q, tdiag, bk1, 1.0 / tk, qk);
+    Csr aug;
+    aug.nr = aug.nc = nc + M;
+    int* len = tmp.alloc<int>((size_t)aug.nr + 1);
+    aug.rp = tmp.alloc<int>((size_t)aug.nr + 1);
+    hipLaunchKernelGGL(k_aug_rowlen, dim3(elems_grid(aug.nr)), dim3(256), 0, ctx->stream, nc, M,
+                       (const int*)d_cr, (const int*)Ae.rp, len);
+    IPD_KERNEL_CHECK();
+    exclusive_scan_i32(ctx, len, aug.rp, aug.nr);
+    aug.nnz = ctx->fetch1(aug.rp + aug.nr);
+    aug.ci = tmp.alloc<int>((size_t)aug.nnz);
+    aug.va = tmp.alloc<double>((size_t)aug.nnz);
+    double* augf = tmp.alloc<double>((size_t)aug.nr);
+    double* U = tmp.alloc<double>((size_t)aug.nr);
+    hipLaunchKernelGGL(k_aug_fill, dim3(rows_grid(aug.nr)), dim3(256), 0, ctx->stream, nc, M,
+                       (const int*)d_cr, (const int*)d_cp, (const int*)d_bl, (const double*)qk,
+                       (const double*)f, (const int*)Ae.rp, (const int*)Ae.ci, (const double*)Ae.va,
+                       (const int*)aug.rp, aug.ci, aug.va, augf);
+    IPD_KERNEL_CHECK();
+    long long it = 0;
+    double res = 0.0;
+    pcg_dev(ctx, aug, augf, nullptr, tol, maxit, 2, U, &it, &res, nullptr);         // :29-34
+    hipLaunchKernelGGL(k_aug_back, dim3(g), dim3(256), 0, ctx->stream, M, n, nc, (const int*)d_bl,
+                       (const double*)U, p, q, zeta);
+    IPD_KERNEL_CHECK();
+    out->itamg = (int)std::min<long long>(it, 2147483647LL);
+    out->resamg = res;
+    out->num_comp = nc;
+    out->it_num = 1;
+}
+
+// PCG4POT (Class2/PCG4POT.m:27-39) = amg4pot_dev's reduction with aug_PCG as the inner solve
+void pcg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p, const double* q,
+                 int m, int n, double bk1, double tk, const double* z, const uint8_t* s,
+                 const double* phi, double tol, long long maxit, double* zeta, HybridOut* out) {
+    auto solve = [&](const double* rhs, double* x, HybridOut* o) {
+        aug_pcg_dev(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, tol, maxit, x, o);
+    };
+    pot_reduce(ctx, H0, p, q, m, n, bk1, tk, z, s, phi, zeta, out, solve);
+}
+
+// ---------------------------------------------------------------------------
+// Jk = bk1*I + (T + H0)/tk                              (APD_SsN_Class1.m:151)
+// ---------------------------------------------------------------------------
+// H0 stores a diagonal entry only on rows that have active entries, Jk on every row.
+__global__ void k_jk_count(int M, const int* __restrict__ rp, const int* __restrict__ ci,
+                           int* __restrict__ len) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < M; r += gridDim.x * blockDim.x) {
+        bool has = false;
+        for (int t = rp[r]; t < rp[r + 1]; ++t) has = has || ci[t] == r;
+        len[r] = rp[r + 1] - rp[r] + (has ? 0 : 1);
+    }
+}
+__global__ void k_jk_fill(int M, const int* __restrict__ rp, const int* __restrict__ ci,
+                          const double* __restrict__ va, const double* __restrict__ t, double bk1,
+                          double tk, const int* __restrict__ orp, int* __restrict__ oci,
+                          double* __restrict__ ova) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < M; r += gridDim.x * blockDim.x) {
+        int o = orp[r];
+        bool placed = false;
+        const double tr = t ? t[r] : 0.0;
+        for (int k = rp[r]; k < rp[r + 1]; ++k) {
+            const int c = ci[k];
+            if (!placed && c > r) {   // the missing diagonal goes in before the first larger column
+                oci[o] = r;
+                ova[o++] = bk1 + (tr + 0.0) / tk;
+                placed = true;
+            }
+            oci[o] = c;
+            if (c == r) {
+                ova[o++] = bk1 + (tr + va[k]) / tk;
+                placed = true;
+            } else {
+                ova[o++] = va[k] / tk;
+            }
+        }
+        if (!placed) {
+            oci[o] = r;
+            ova[o] = bk1 + (tr + 0.0) / tk;
+        }
+    }
+}
+void build_jk(ipd_ctx* ctx, Arena& dst, const Csr& H0, const double* tdiag, double bk1, double tk,
+              Csr* J) {
+    const int M = H0.nr;
+    int* len = ctx->scratch->alloc<int>((size_t)M + 1);
+    J->nr = J->nc = M;
+    J->rp = dst.alloc<int>((size_t)M + 1);
+    hipLaunchKernelGGL(k_jk_count, dim3(elems_grid(M)), dim3(256), 0, ctx->stream, M, H0.rp, H0.ci, len);
+    IPD_KERNEL_CHECK();
+    exclusive_scan_i32(ctx, len, J->rp, M);
+    J->nnz = ctx->fetch1(J->rp + M);
+    J->ci = dst.alloc<int>((size_t)J->nnz);
+    J->va = dst.alloc<double>((size_t)J->nnz);
+    hipLaunchKernelGGL(k_jk_fill, dim3(elems_grid(M)), dim3(256), 0, ctx->stream, M, H0.rp, H0.ci,
+                       H0.va, tdiag, bk1, tk, (const int*)J->rp, J->ci, J->va);
+    IPD_KERNEL_CHECK();
 }
 
 // ---------------------------------------------------------------------------
@@ -658,8 +865,8 @@ static void check_prob(const ipd_prob* pd, bool pot) {
     if (pot) IPD_REQUIRE(pd->s && pd->phi, IPD_E_ARG, "AMG4POT needs prob_data.s and .phi");
 }
 
-extern "C" int ipd_hybrid_amg(ipd_ctx* ctx, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
-                              double* zeta, int32_t* itamg, double* resamg, int64_t info[2]) {
+static int hybrid_host(ipd_ctx* ctx, const ipd_prob* pd, const AmgOpts& ao, ipd_rng* rng,
+                       double* zeta, int32_t* itamg, double* resamg, int64_t info[2]) {
     return ipd_guard([&] {
         IPD_REQUIRE(ctx && zeta, IPD_E_ARG, "NULL argument");
         check_prob(pd, false);
@@ -681,8 +888,7 @@ extern "C" int ipd_hybrid_amg(ipd_ctx* ctx, const ipd_prob* pd, const ipd_amg_op
         }
         double* dzeta = tmp.alloc<double>((size_t)M);
         HybridOut ho;
-        hybrid_amg_dev(ctx, H0, dt, dp, dq, m, n, pd->bk1, pd->tk, dz, amg_fill_defaults(o), rng,
-                       dzeta, &ho);
+        hybrid_amg_dev(ctx, H0, dt, dp, dq, m, n, pd->bk1, pd->tk, dz, ao, rng, dzeta, &ho);
         ctx->fetch(dzeta, zeta, (size_t)M);
         if (itamg) *itamg = ho.itamg;
         if (resamg) *resamg = ho.resamg;
@@ -691,6 +897,16 @@ extern "C" int ipd_hybrid_amg(ipd_ctx* ctx, const ipd_prob* pd, const ipd_amg_op
             info[1] = ho.it_num;
         }
     });
+}
+
+extern "C" int ipd_hybrid_amg(ipd_ctx* ctx, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
+                              double* zeta, int32_t* itamg, double* resamg, int64_t info[2]) {
+    return hybrid_host(ctx, pd, amg_fill_defaults(o), rng, zeta, itamg, resamg, info);
+}
+extern "C" int ipd_hybrid_twogrid(ipd_ctx* ctx, const ipd_prob* pd, const ipd_amg_opts* o,
+                                  ipd_rng* rng, double* zeta, int32_t* itamg, double* resamg,
+                                  int64_t info[2]) {
+    return hybrid_host(ctx, pd, amg_fill_twogrid_defaults(o), rng, zeta, itamg, resamg, info);
 }
 
 extern "C" int ipd_hybrid_amg_dev(ipd_ctx* ctx, const ipd_dmat* H0, const double* t_dev,
@@ -715,8 +931,8 @@ extern "C" int ipd_hybrid_amg_dev(ipd_ctx* ctx, const ipd_dmat* H0, const double
     });
 }
 
-extern "C" int ipd_amg4pot(ipd_ctx* ctx, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
-                           double* zeta, int32_t* itamg, double* resamg, int64_t info[2]) {
+static int amg4pot_host(ipd_ctx* ctx, const ipd_prob* pd, const AmgOpts& ao, ipd_rng* rng,
+                        double* zeta, int32_t* itamg, double* resamg, int64_t info[2]) {
     return ipd_guard([&] {
         IPD_REQUIRE(ctx && zeta, IPD_E_ARG, "NULL argument");
         check_prob(pd, true);
@@ -743,8 +959,7 @@ extern "C" int ipd_amg4pot(ipd_ctx* ctx, const ipd_prob* pd, const ipd_amg_opts*
         }
         double* dzeta = tmp.alloc<double>((size_t)M + 1);
         HybridOut ho;
-        amg4pot_dev(ctx, H0, dt, dp, dq, m, n, pd->bk1, pd->tk, dz, ds, dphi, amg_fill_defaults(o),
-                    rng, dzeta, &ho);
+        amg4pot_dev(ctx, H0, dt, dp, dq, m, n, pd->bk1, pd->tk, dz, ds, dphi, ao, rng, dzeta, &ho);
         ctx->fetch(dzeta, zeta, (size_t)M + 1);
         if (itamg) *itamg = ho.itamg;
         if (resamg) *resamg = ho.resamg;
@@ -753,4 +968,70 @@ extern "C" int ipd_amg4pot(ipd_ctx* ctx, const ipd_prob* pd, const ipd_amg_opts*
             info[1] = ho.it_num;
         }
     });
+}
+
+extern "C" int ipd_amg4pot(ipd_ctx* ctx, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
+                           double* zeta, int32_t* itamg, double* resamg, int64_t info[2]) {
+    return amg4pot_host(ctx, pd, amg_fill_defaults(o), rng, zeta, itamg, resamg, info);
+}
+// AMG4POT(prob_data, amg_options, 'twogrid')                      Class2/AMG4POT.m:48-51
+extern "C" int ipd_amg4pot_twogrid(ipd_ctx* ctx, const ipd_prob* pd, const ipd_amg_opts* o,
+                                   ipd_rng* rng, double* zeta, int32_t* itamg, double* resamg,
+                                   int64_t info[2]) {
+    return amg4pot_host(ctx, pd, amg_fill_twogrid_defaults(o), rng, zeta, itamg, resamg, info);
+}
+
+// [zeta,itpcg,respcg,info] = aug_PCG(prob_data,pcg_options) (aug_PCG.m:1) and
+// PCG4POT(prob_data,pcg_options) (Class2/PCG4POT.m:1); precd is forced to 2 (aug_PCG.m:32)
+static int aug_host(ipd_ctx* ctx, const ipd_prob* pd, const ipd_pcg_opts* o, bool pot, double* zeta,
+                    int64_t* itpcg, double* respcg, int64_t info[2]) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && zeta, IPD_E_ARG, "NULL argument");
+        check_prob(pd, pot);
+        const double tol = (o && o->retol >= 0) ? o->retol : 1e-11;                 // PCG.m:25-26
+        const long long maxit = (o && o->maxit >= 0) ? o->maxit : 10000;
+        CallScope scope(ctx);
+        Arena& tmp = *ctx->scratch;
+        const int m = (int)pd->m, n = (int)pd->n, M = m + n;
+        const size_t mn = (size_t)m * n;
+        Csr H0;
+        csr_upload_from_csc(ctx, tmp, pd->H0, true, &H0);
+        double* dp = tmp.alloc<double>((size_t)m);
+        double* dq = tmp.alloc<double>((size_t)n);
+        double* dz = tmp.alloc<double>((size_t)M + 1);
+        double* dt = nullptr;
+        ctx->upload(dp, pd->p, (size_t)m);
+        ctx->upload(dq, pd->q, (size_t)n);
+        ctx->upload(dz, pd->z, (size_t)M + (pot ? 1 : 0));
+        if (pd->t) {
+            dt = tmp.alloc<double>((size_t)M);
+            ctx->upload(dt, pd->t, (size_t)M);
+        }
+        double* dzeta = tmp.alloc<double>((size_t)M + 1);
+        HybridOut ho;
+        if (pot) {
+            double* dphi = tmp.alloc<double>(mn);
+            uint8_t* ds = tmp.alloc<uint8_t>(mn);
+            ctx->upload(dphi, pd->phi, mn);
+            ctx->upload(ds, pd->s, mn);
+            pcg4pot_dev(ctx, H0, dt, dp, dq, m, n, pd->bk1, pd->tk, dz, ds, dphi, tol, maxit, dzeta, &ho);
+        } else {
+            aug_pcg_dev(ctx, H0, dt, dp, dq, m, n, pd->bk1, pd->tk, dz, tol, maxit, dzeta, &ho);
+        }
+        ctx->fetch(dzeta, zeta, (size_t)M + (pot ? 1 : 0));
+        if (itpcg) *itpcg = ho.itamg;
+        if (respcg) *respcg = ho.resamg;
+        if (info) {
+            info[0] = ho.num_comp;
+            info[1] = ho.it_num;
+        }
+    });
+}
+extern "C" int ipd_aug_pcg(ipd_ctx* ctx, const ipd_prob* pd, const ipd_pcg_opts* o, double* zeta,
+                           int64_t* itpcg, double* respcg, int64_t info[2]) {
+    return aug_host(ctx, pd, o, false, zeta, itpcg, respcg, info);
+}
+extern "C" int ipd_pcg4pot(ipd_ctx* ctx, const ipd_prob* pd, const ipd_pcg_opts* o, double* zeta,
+                           int64_t* itpcg, double* respcg, int64_t info[2]) {
+    return aug_host(ctx, pd, o, true, zeta, itpcg, respcg, info);
 }

@@ -685,6 +685,27 @@ AmgOpts amg_fill_defaults(const ipd_amg_opts* in) {
     return o;
 }
 
+// twogrid_bigph.m:6-15: nargin/empty-field defaults differ from Class_AMG's
+AmgOpts amg_fill_twogrid_defaults(const ipd_amg_opts* in) {
+    AmgOpts o;
+    o.retol = 0.0;
+    o.maxit = 50;
+    o.smoth = 3;
+    o.isnsp = 0;
+    if (in) {
+        if (in->retol >= 0) o.retol = in->retol;
+        if (in->maxit >= 0) o.maxit = in->maxit;
+        if (in->smoth >= 0) o.smoth = in->smoth;
+        if (in->isnsp >= 0) o.isnsp = in->isnsp;
+        o.fnode = in->fnode;
+    }
+    o.bigph = 1;
+    o.cycle = 'v';       // two levels: a V cycle is twogrid_it (:55-84)
+    o.twogrid = true;
+    o.pcg_maxit = 100;   // :72
+    return o;
+}
+
 // 1 + fix(size(A,1)^(1/3)) in floating point (Class_AMG.m:76)
 int amg_coarsest_threshold(int N) { return 1 + (int)std::floor(std::pow((double)N, 1.0 / 3.0)); }
 
@@ -702,7 +723,11 @@ ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng) {
     csr_copy(ctx, *h->arena, A, &h->L[1].A);
     h->L[1].N = A.nr;
     const int thr = amg_coarsest_threshold(A.nr);
-    while (h->L[h->J].A.nr > thr) {                                          // :76
+    auto more = [&] {   // Class_AMG.m:76; twogrid_bigph.m builds exactly one coarse level
+        return o.twogrid ? h->J < 2 : h->L[h->J].A.nr > thr;
+    };
+    if (o.twogrid) IPD_REQUIRE(o.bigph && A.nr >= 2, IPD_E_ARG, "twogrid_bigph needs a bigraph of >= 2 nodes");
+    while (more()) {
         IPD_REQUIRE(h->J < 40, IPD_E_NUMERIC, "Class_AMG: coarsening stalled (40 levels)");
         const Csr& Ak = h->L[h->J].A;
         Level nl;
@@ -833,6 +858,26 @@ extern "C" int ipd_amg_setup(ipd_ctx* ctx, const ipd_csc* A, const ipd_amg_opts*
         *out = amg_setup(ctx, a, amg_fill_defaults(o), rng);
         ctx->sync();
     });
+}
+
+// [x,it,rel_res,rel_resk,rhok] = twogrid_bigph(A,b,amg_options)      AMG/twogrid_bigph.m:1
+extern "C" int ipd_twogrid_bigph(ipd_ctx* ctx, const ipd_csc* A, const double* b,
+                                 const double* guess, const ipd_amg_opts* o, double* x, int32_t* it,
+                                 double* rel_res, double* rel_resk, double* rhok) {
+    ipd_amg* h = nullptr;
+    int rc = ipd_guard([&] {
+        IPD_REQUIRE(ctx && A && b && x, IPD_E_ARG, "NULL argument");
+        CallScope scope(ctx);
+        Arena up(&ctx->pool);
+        Csr a;
+        csr_upload_from_csc(ctx, up, A, false, &a);
+        h = amg_setup(ctx, a, amg_fill_twogrid_defaults(o), nullptr);
+        ctx->sync();
+    });
+    if (rc != IPD_OK) return rc;
+    rc = ipd_amg_solve(h, b, guess, x, it, rel_res, rel_resk, rhok);
+    ipd_amg_destroy(h);
+    return rc;
 }
 
 extern "C" void ipd_amg_destroy(ipd_amg* h) {

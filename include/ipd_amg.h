@@ -178,6 +178,13 @@ int ipd_amg_wcycle(ipd_amg* h, const double* r, int isnsp, int k,
 int ipd_class_amg(ipd_ctx*, const ipd_csc* A, const double* b, const double* guess,
                   const ipd_amg_opts* o, ipd_rng* rng, double* x, int32_t* it,
                   double* rel_res, double* rel_resk, double* rhok);
+/* [x,it,rel_res,rel_resk,rhok] = twogrid_bigph(A,b,amg_options) AMG/twogrid_bigph.m:1:
+ * the two-level special case (exactly one coarse level, coarse PCG with maxit 100); empty
+ * fields take twogrid_bigph.m:11-15's defaults (retol 0, maxit 50, smoth 3, isnsp 0);
+ * amg_options.fnode is required.  rel_resk/rhok need maxit+1 slots.                     */
+int ipd_twogrid_bigph(ipd_ctx*, const ipd_csc* A, const double* b, const double* guess,
+                      const ipd_amg_opts* o, double* x, int32_t* it, double* rel_res,
+                      double* rel_resk, double* rhok);
 /* [d,it,res,resk] = PCG(H,e,pcg_options)   PCG.m:1 ; resk needs maxit slots
  * or NULL                                                                    */
 int ipd_pcg(ipd_ctx*, const ipd_csc* H, const double* e, const double* guess,
@@ -192,6 +199,19 @@ int ipd_components(ipd_ctx*, const ipd_csc* A, int64_t* blocks, int64_t* sizes,
 int ipd_hybrid_amg(ipd_ctx*, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
                    double* zeta, int32_t* itamg, double* resamg, int64_t info[2]);
 /* [zeta,...] = AMG4POT(prob_data,amg_options,'amg')  Class2/AMG4POT.m:1       */
+/* [zeta,itpcg,respcg,info] = aug_PCG(prob_data,pcg_options) aug_PCG.m:1 and
+ * PCG4POT(prob_data,pcg_options) Class2/PCG4POT.m:1 (inner_solver = 3): Jacobi-PCG on the
+ * system augmented with one kernel vector per connected component                          */
+int ipd_aug_pcg(ipd_ctx*, const ipd_prob* pd, const ipd_pcg_opts* o, double* zeta,
+                int64_t* itpcg, double* respcg, int64_t info[2]);
+int ipd_pcg4pot(ipd_ctx*, const ipd_prob* pd, const ipd_pcg_opts* o, double* zeta,
+                int64_t* itpcg, double* respcg, int64_t info[2]);
+/* [zeta,itamg,resamg,info] = Hybrid_twogrid(prob_data,amg_options) Hybrid_twogrid.m:1 and
+ * AMG4POT(prob_data,amg_options,'twogrid') Class2/AMG4POT.m:48-51 (inner_solver = 5)       */
+int ipd_hybrid_twogrid(ipd_ctx*, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
+                       double* zeta, int32_t* itamg, double* resamg, int64_t info[2]);
+int ipd_amg4pot_twogrid(ipd_ctx*, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
+                        double* zeta, int32_t* itamg, double* resamg, int64_t info[2]);
 int ipd_amg4pot(ipd_ctx*, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
                 double* zeta, int32_t* itamg, double* resamg, int64_t info[2]);
 
@@ -257,6 +277,10 @@ typedef struct ipd_apd_opts {
     double nu, delta;     /* 0.2, 0.9                                                  */
     int32_t ll_max;       /* 500                                                       */
     int32_t prob;         /* class 1 only: `prob` of :19-23; 3 selects the merit of :186 */
+    int32_t inner_solver; /* :66-71: 4 AMG (default), 5 two-grid, 3 aug_PCG / PCG4POT,
+                             2 plain PCG (class 1 only); 1 (direct) is not built         */
+    double pcg_retol;     /* pcg_options of :81,84: 1e-11                               */
+    int64_t pcg_maxit;    /*                        1e4                                 */
 } ipd_apd_opts;
 void ipd_apd_opts_init(int32_t cls, ipd_apd_opts* o);
 

@@ -669,7 +669,7 @@ def build_Ae(H0, T, p, q, bk1, tk):
 
 
 def Hybrid_AMG(prob_data: dict, amg_options: dict, rng: np.random.RandomState,
-               N0: int = 100, trace: Optional[list] = None):
+               N0: int = 100, trace: Optional[list] = None, solver=None):
     """``Hybrid_AMG.m:12-113``: ``[zeta,itamg,resamg,info]``.
 
     ``trace`` (optional list) receives one dict per Class_AMG call with the
@@ -690,7 +690,11 @@ def Hybrid_AMG(prob_data: dict, amg_options: dict, rng: np.random.RandomState,
         o["isnsp"] = 0 if dK.sum() else 1                                # :32-38
         o["fnode"] = n
         o["guess"] = bk1 * tk * rng.random_sample(M)                     # :40
-        x, itamg, resamg, rel_resk, rhok, h = Class_AMG(Ae, f, o, rng, True)
+        if solver is not None:
+            x, itamg, resamg, rel_resk, rhok = solver(Ae, f, o)
+            h = None
+        else:
+            x, itamg, resamg, rel_resk, rhok, h = Class_AMG(Ae, f, o, rng, True)
         if trace is not None:
             trace.append(dict(pk=np.arange(M), h=h, rel_resk=rel_resk, rhok=rhok, it=itamg,
                               isnsp=o["isnsp"], fnode=n, guess=o["guess"], x=x))
@@ -706,7 +710,11 @@ def Hybrid_AMG(prob_data: dict, amg_options: dict, rng: np.random.RandomState,
             o["isnsp"] = 0 if dK[pk].sum() else 1                        # :60-66
             o["fnode"] = int((pk < n).sum())                             # :68 (pk<=n, 1-based)
             o["guess"] = bk1 * tk * rng.random_sample(len(pk))           # :69
-            dk, itk, resk_, rel_resk, rhok, h = Class_AMG(Aek, fk, o, rng, True)
+            if solver is not None:
+                dk, itk, resk_, rel_resk, rhok = solver(Aek, fk, o)
+                h = None
+            else:
+                dk, itk, resk_, rel_resk, rhok, h = Class_AMG(Aek, fk, o, rng, True)
             if trace is not None:
                 trace.append(dict(pk=pk, h=h, rel_resk=rel_resk, rhok=rhok, it=itk,
                                   isnsp=o["isnsp"], fnode=o["fnode"], guess=o["guess"], x=dk))
@@ -724,12 +732,140 @@ def Hybrid_AMG(prob_data: dict, amg_options: dict, rng: np.random.RandomState,
     return zeta, itamg, resamg, np.array([num_comp, it_num])
 
 
+def twogrid_bigph(A, b, amg_options: Optional[dict] = None):
+    """``AMG/twogrid_bigph.m:1-53`` with ``twogrid_it`` (``:55-84``): two-level method on the
+    bigraph blocks; coarse solve ``PCG(Ac,rrc,struct('retol',[],'maxit',1e2,'precd',2))``.
+    Returns ``x, it, rel_res, rel_resk, rhok``."""
+    b = np.asarray(b, float)
+    if amg_options is None:
+        amg_options = dict(retol=1e-12, maxit=20, fnode=0, smoth=10, isnsp=1, guess=np.zeros_like(b))
+    o = dict(amg_options)
+    retol = 0 if o.get("retol") is None else o["retol"]                  # :11-15
+    maxit = 50 if o.get("maxit") is None else int(o["maxit"])
+    smoth = 3 if o.get("smoth") is None else int(o["smoth"])
+    isnsp = 0 if o.get("isnsp") is None else int(o["isnsp"])
+    guess = np.zeros_like(b) if o.get("guess") is None else np.asarray(o["guess"], float)
+    A = _csr(A)
+    N = A.shape[0]
+    Nf = int(o["fnode"])
+    Nc = N - Nf
+    Aff, Afc, Acc = A[:Nf, :Nf], _csr(A[:Nf, Nf:]), A[Nf:, Nf:]           # :22-23
+    invV = sp.diags(1.0 / Aff.diagonal(), format="csr")
+    invT = sp.diags(1.0 / Acc.diagonal(), format="csr")
+    R = _csr(sp.bmat([[invV, None], [-_spgemm(_spgemm(invT, _csr(Afc.T)), invV), invT]]))  # :26
+    W = _csr(-(sp.diags(1.0 / Aff.diagonal()) @ Afc))                     # :28 Aff\Afc, Aff diagonal
+    if isnsp == 1:
+        W = _csr(sp.diags(1.0 / np.asarray(W @ np.ones(Nc)).ravel()) @ W)  # :29-31
+    Pro = _csr(sp.vstack([W, sp.identity(Nc, format="csr")]))
+    Ac = _spgemm(_spgemm(_csr(Pro.T), A), Pro)                            # :33 left to right
+    Rt = _csr(R.T)
+    xi = np.ones(N)
+    Axi = A @ xi
+    xx = xi @ Axi
+
+    def it_(r):                                                           # twogrid_it :55-84
+        e = np.zeros_like(r)
+        for Rm in (R, None, Rt):
+            if Rm is None:
+                rr = r - A @ e
+                eec = PCG(Ac, Pro.T @ rr, dict(retol=None, maxit=100, precd=2, guess=None))[0]
+                e = e + Pro @ eec
+                continue
+            for _ in range(smoth):
+                g = r - A @ e
+                if isnsp:
+                    xig = xi @ g
+                    g = xi * (xig / xx) + Rm @ (g - Axi * (xig / xx))
+                else:
+                    g = Rm @ g
+                e = e + g
+        return e
+
+    it = 0
+    rhok = np.full(maxit + 2, np.nan)
+    rel_resk = np.ones(maxit + 2)
+    x = guess.copy()
+    res0 = np.linalg.norm(A @ x - b)
+    if res0 == 0:
+        return x, 0, 0.0, np.array([0.0]), np.array([np.inf])
+    it = 1
+    rel_res = 1.0
+    while rel_resk[it - 1] > retol and it <= maxit:                       # :42 (1-based it)
+        r = b - A @ x
+        x = x + it_(r)
+        res = np.linalg.norm(A @ x - b)
+        rel_res = res / res0
+        rel_resk[it] = rel_res
+        rhok[it] = res / np.linalg.norm(r)
+        it += 1
+        if rhok[it - 1] > 1:
+            break
+    return x, it - 1, rel_res, rel_resk[:it].copy(), rhok[:it].copy()
+
+
+def Hybrid_twogrid(prob_data: dict, amg_options: dict, rng: np.random.RandomState,
+                   trace: Optional[list] = None):
+    """``Hybrid_twogrid.m``: `Hybrid_AMG` with `twogrid_bigph` on the connected system / the large
+    components (``:39,63``); everything else (rescaling, isnsp rule, guesses, small blocks) is the
+    same text."""
+    return Hybrid_AMG(prob_data, amg_options, rng, trace=trace,
+                      solver=lambda A, f, o: twogrid_bigph(A, f, o))
+
+
+def aug_PCG(prob_data: dict, pcg_options: dict):
+    """``aug_PCG.m:11-36``: PCG on the system augmented with the kernel vectors of A0 (one
+    indicator vector per connected component)."""
+    bk1, tk = prob_data["bk1"], prob_data["tk"]
+    q, p = np.asarray(prob_data["q"], float), np.asarray(prob_data["p"], float)
+    H0, z, T = prob_data["H0"], np.asarray(prob_data["z"], float), prob_data["T"]
+    Ae, A0, Q, K, Q0, qp = build_Ae(H0, T, p, q, bk1, tk)
+    f = qp * z
+    M = len(qp)
+    blocks, sizes, _, _ = components(A0)                                  # :24
+    nc = len(sizes)
+    Y = sp.csr_matrix((np.ones(M), (np.arange(M), blocks)), shape=(M, nc))  # :25
+    QK = _csr(bk1 * Q + 1 / tk * K)                                       # :27
+    augAe = sp.bmat([[Y.T @ QK @ Y, Y.T @ QK], [QK @ Y, Ae]], format="csr")  # :28
+    augf = np.concatenate([Y.T @ f, f])
+    o = dict(pcg_options)
+    o["guess"] = np.zeros(nc + M)                                         # :29
+    o["precd"] = 2                                                        # :32
+    U, itpcg, respcg, _ = PCG(augAe, augf, o)
+    u = Y @ U[:nc] + U[nc:]                                               # :35
+    return qp * u, itpcg, respcg, np.array([nc, 1])
+
+
+def PCG4POT(prob_data: dict, pcg_options: dict):
+    """``Class2/PCG4POT.m:27-39``: the Sherman-Morrison reduction of `AMG4POT` with `aug_PCG`."""
+    p, q = prob_data["p"], prob_data["q"]
+    bk1, tk = prob_data["bk1"], prob_data["tk"]
+    phi = np.asarray(prob_data["phi"], float)
+    z = np.asarray(prob_data["z"], float)
+    s = np.asarray(prob_data["s"], float)
+    z1, z2 = z[:-1], z[-1]
+    epss, sg = bk1, 1 / tk
+    phi_e = epss + sg * (phi @ (s * phi))
+    v = Ax(s * phi, p, q)
+    w = z1 - sg / phi_e * z2 * v
+    pd = dict(prob_data)
+    pd["z"] = v
+    vv, it1, res1, info1 = aug_PCG(pd, pcg_options)
+    pd["z"] = w
+    ww, it2, res2, info2 = aug_PCG(pd, pcg_options)
+    tt = sg ** 2 / (phi_e - sg ** 2 * (v @ vv))
+    zeta1 = ww + tt * vv * (v @ ww)
+    zeta2 = (z2 - sg * (v @ zeta1)) / phi_e
+    return (np.concatenate([zeta1, [zeta2]]), max(it1, it2), max(res1, res2),
+            np.maximum(info1, info2))
+
+
 def AMG4POT(prob_data: dict, amg_options: dict, rng: np.random.RandomState,
             str_: str = "amg", trace: Optional[list] = None):
     """``Class2/AMG4POT.m:27-55``: bordered partial-OT system through
     Sherman-Morrison and two ``Hybrid_AMG`` solves on the same ``Ae``."""
-    if str_ != "amg":
-        raise NotImplementedError("Hybrid_twogrid is out of scope (SURVEY f4)")
+    if str_ not in ("amg", "twogrid"):
+        raise ValueError("AMG4POT: str must be 'amg' or 'twogrid'")
+    hybrid = Hybrid_AMG if str_ == "amg" else Hybrid_twogrid               # :44-51
     p, q = prob_data["p"], prob_data["q"]
     bk1, tk = prob_data["bk1"], prob_data["tk"]
     phi = np.asarray(prob_data["phi"], float)
@@ -742,9 +878,9 @@ def AMG4POT(prob_data: dict, amg_options: dict, rng: np.random.RandomState,
     w = z1 - sg / phi_e * z2 * v
     pd = dict(prob_data)
     pd["z"] = v
-    vv, it1, res1, info1 = Hybrid_AMG(pd, amg_options, rng, trace=trace)  # :46
+    vv, it1, res1, info1 = hybrid(pd, amg_options, rng, trace=trace)      # :46
     pd["z"] = w
-    ww, it2, res2, info2 = Hybrid_AMG(pd, amg_options, rng, trace=trace)  # :47
+    ww, it2, res2, info2 = hybrid(pd, amg_options, rng, trace=trace)      # :47
     tt = sg ** 2 / (phi_e - sg ** 2 * (v @ vv))                          # :53
     zeta1 = ww + tt * vv * (v @ ww)
     zeta2 = (z2 - sg * (v @ zeta1)) / phi_e
