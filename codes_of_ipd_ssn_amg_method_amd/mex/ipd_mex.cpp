@@ -174,8 +174,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (nlhs > 1) { plhs[1] = mxCreateDoubleMatrix(1, (mwSize)nc, mxREAL); for (int64_t c = 0; c < nc; ++c) mxGetDoubles(plhs[1])[c] = (double)sz[(size_t)c]; }
         if (nlhs > 2) { plhs[2] = mxCreateDoubleMatrix(1, (mwSize)N, mxREAL); for (size_t i = 0; i < N; ++i) mxGetDoubles(plhs[2])[i] = (double)(p[i] + 1); }
         if (nlhs > 3) { plhs[3] = mxCreateDoubleMatrix(1, (mwSize)nc + 1, mxREAL); for (int64_t c = 0; c <= nc; ++c) mxGetDoubles(plhs[3])[c] = (double)(r[(size_t)c] + 1); }
-    } else if (fn == "Hybrid_AMG" || fn == "AMG4POT") {   // [zeta,itamg,resamg,info] = f(prob_data,amg_options)
-        const mxArray* pd = a[0]; const bool pot = fn == "AMG4POT";
+    } else if (fn == "Hybrid_AMG" || fn == "AMG4POT" || fn == "Hybrid_twogrid" || fn == "AMG4POT_twogrid" ||
+               fn == "aug_PCG" || fn == "PCG4POT") {   // [zeta,it,res,info] = f(prob_data,options)
+        const mxArray* pd = a[0]; const bool pot = fn == "AMG4POT" || fn == "AMG4POT_twogrid" || fn == "PCG4POT";
         const mxArray *p = mxGetField(pd, 0, "p"), *q = mxGetField(pd, 0, "q");
         ipd_prob P; std::memset(&P, 0, sizeof(P));
         P.m = (int64_t)mxGetNumberOfElements(p); P.n = (int64_t)mxGetNumberOfElements(q);
@@ -185,10 +186,21 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         bool anyT = false; std::vector<double> t = diag_of_sparse(mxGetField(pd, 0, "T"), (size_t)(P.m + P.n), &anyT);
         P.t = anyT ? t.data() : nullptr;
         if (pot) { P.s = (const uint8_t*)mxGetLogicals(mxGetField(pd, 0, "s")); P.phi = mxGetDoubles(mxGetField(pd, 0, "phi")); }
-        ipd_amg_opts o = opts_of(a[1]); int32_t it = 0; double res = 0; int64_t info[2] = {0, 0};
+        int32_t it = 0; double res = 0; int64_t info[2] = {0, 0};
         plhs[0] = col((size_t)(P.m + P.n + (pot ? 1 : 0)));
-        chk(pot ? ipd_amg4pot(g_ctx, &P, &o, g_rng, mxGetDoubles(plhs[0]), &it, &res, info)
-                : ipd_hybrid_amg(g_ctx, &P, &o, g_rng, mxGetDoubles(plhs[0]), &it, &res, info));
+        if (fn == "aug_PCG" || fn == "PCG4POT") {          // pcg_options: retol, maxit (precd forced to 2)
+            ipd_pcg_opts po; ipd_pcg_opts_init(&po); int64_t it64 = 0;
+            po.retol = field(a[1], "retol", -1); po.maxit = (int64_t)field(a[1], "maxit", -1);
+            chk(pot ? ipd_pcg4pot(g_ctx, &P, &po, mxGetDoubles(plhs[0]), &it64, &res, info)
+                    : ipd_aug_pcg(g_ctx, &P, &po, mxGetDoubles(plhs[0]), &it64, &res, info));
+            it = (int32_t)it64;
+        } else {
+            ipd_amg_opts o = opts_of(a[1]);
+            if (fn == "Hybrid_AMG") chk(ipd_hybrid_amg(g_ctx, &P, &o, g_rng, mxGetDoubles(plhs[0]), &it, &res, info));
+            else if (fn == "AMG4POT") chk(ipd_amg4pot(g_ctx, &P, &o, g_rng, mxGetDoubles(plhs[0]), &it, &res, info));
+            else if (fn == "Hybrid_twogrid") chk(ipd_hybrid_twogrid(g_ctx, &P, &o, g_rng, mxGetDoubles(plhs[0]), &it, &res, info));
+            else chk(ipd_amg4pot_twogrid(g_ctx, &P, &o, g_rng, mxGetDoubles(plhs[0]), &it, &res, info));
+        }
         if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(it);
         if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(res);
         if (nlhs > 3) { plhs[3] = mxCreateDoubleMatrix(1, 2, mxREAL); mxGetDoubles(plhs[3])[0] = (double)info[0]; mxGetDoubles(plhs[3])[1] = (double)info[1]; }
