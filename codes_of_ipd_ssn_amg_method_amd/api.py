@@ -28,7 +28,7 @@ __all__ = [
     "Ax", "Aty", "ASAt", "invAAt", "invHHt", "strength", "cf_split", "mis_set", "transfer",
     "Class_AMG", "AMGHierarchy", "MG_Vcycle", "MG_Wcycle", "PCG", "components", "Hybrid_AMG",
     "AMG4POT", "MatlabRand", "IpdError", "amg_options", "APDWorkspace", "warmup_class1",
-    "warmup_class2", "APD_SsN_Class1", "APD_SsN_Class2", "twogrid_bigph", "Hybrid_twogrid",
+    "warmup_class2", "APD_SsN_Class1", "APD_SsN_Class2", "twogrid_bigph", "twogrid", "Hybrid_twogrid",
     "aug_PCG", "PCG4POT",
 ]
 
@@ -410,6 +410,30 @@ def twogrid_bigph(A, b, amg_options: dict | None = None):
     g = f64(g) if g is not None else None
     check(lib.ipd_twogrid_bigph(_h(), a.ref(), dptr(b), dptr(g) if g is not None else None, byref(o),
                                 dptr(x), byref(it), byref(rel), dptr(rel_resk), dptr(rhok)))
+    k = it.value + 1
+    return x, int(it.value), float(rel.value), rel_resk[:k].copy(), rhok[:k].copy()
+
+
+def twogrid(A, b, amg_options: dict | None = None, rng: MatlabRand | None = None):
+    """``[x,it,rel_res,rel_resk,rhok] = twogrid(A,b,amg_options)`` (``AMG/twogrid.m:1``)."""
+    b = f64(b)
+    if amg_options is None:                                               # :6-9
+        amg_options = dict(retol=1e-12, bigph=0, maxit=20, smoth=10, isnsp=1, guess=None)
+    if amg_options.get("bigph") and not (amg_options.get("fnode") or 0) > 0:
+        raise ValueError("bigph = 1 requires fnode > 0")                  # :24-26
+    rng = rng or MatlabRand()
+    a = CscIn(A)
+    o = _opts_struct(dict(amg_options))
+    maxit = int(o.maxit) if o.maxit >= 0 else 50
+    x = np.empty(b.size)
+    it = c_int32()
+    rel = c_double()
+    rel_resk = np.full(maxit + 2, np.nan)
+    rhok = np.full(maxit + 2, np.nan)
+    g = amg_options.get("guess")
+    g = f64(g) if g is not None else None
+    check(lib.ipd_twogrid(_h(), a.ref(), dptr(b), dptr(g) if g is not None else None, byref(o),
+                          rng.handle, dptr(x), byref(it), byref(rel), dptr(rel_resk), dptr(rhok)))
     k = it.value + 1
     return x, int(it.value), float(rel.value), rel_resk[:k].copy(), rhok[:k].copy()
 

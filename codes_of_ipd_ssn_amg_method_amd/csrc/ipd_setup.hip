@@ -726,7 +726,7 @@ ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng) {
     auto more = [&] {   // Class_AMG.m:76; twogrid_bigph.m builds exactly one coarse level
         return o.twogrid ? h->J < 2 : h->L[h->J].A.nr > thr;
     };
-    if (o.twogrid) IPD_REQUIRE(o.bigph && A.nr >= 2, IPD_E_ARG, "twogrid_bigph needs a bigraph of >= 2 nodes");
+    if (o.twogrid) IPD_REQUIRE(A.nr >= 2, IPD_E_ARG, "twogrid needs at least 2 nodes");
     while (more()) {
         IPD_REQUIRE(h->J < 40, IPD_E_NUMERIC, "Class_AMG: coarsening stalled (40 levels)");
         const Csr& Ak = h->L[h->J].A;
@@ -860,10 +860,9 @@ extern "C" int ipd_amg_setup(ipd_ctx* ctx, const ipd_csc* A, const ipd_amg_opts*
     });
 }
 
-// [x,it,rel_res,rel_resk,rhok] = twogrid_bigph(A,b,amg_options)      AMG/twogrid_bigph.m:1
-extern "C" int ipd_twogrid_bigph(ipd_ctx* ctx, const ipd_csc* A, const double* b,
-                                 const double* guess, const ipd_amg_opts* o, double* x, int32_t* it,
-                                 double* rel_res, double* rel_resk, double* rhok) {
+static int twogrid_host(ipd_ctx* ctx, const ipd_csc* A, const double* b, const double* guess,
+                        const AmgOpts& ao, ipd_rng* rng, double* x, int32_t* it, double* rel_res,
+                        double* rel_resk, double* rhok) {
     ipd_amg* h = nullptr;
     int rc = ipd_guard([&] {
         IPD_REQUIRE(ctx && A && b && x, IPD_E_ARG, "NULL argument");
@@ -871,13 +870,38 @@ extern "C" int ipd_twogrid_bigph(ipd_ctx* ctx, const ipd_csc* A, const double* b
         Arena up(&ctx->pool);
         Csr a;
         csr_upload_from_csc(ctx, up, A, false, &a);
-        h = amg_setup(ctx, a, amg_fill_twogrid_defaults(o), nullptr);
+        h = amg_setup(ctx, a, ao, rng);
         ctx->sync();
     });
     if (rc != IPD_OK) return rc;
     rc = ipd_amg_solve(h, b, guess, x, it, rel_res, rel_resk, rhok);
     ipd_amg_destroy(h);
     return rc;
+}
+// [x,it,rel_res,rel_resk,rhok] = twogrid_bigph(A,b,amg_options)      AMG/twogrid_bigph.m:1
+extern "C" int ipd_twogrid_bigph(ipd_ctx* ctx, const ipd_csc* A, const double* b,
+                                 const double* guess, const ipd_amg_opts* o, double* x, int32_t* it,
+                                 double* rel_res, double* rel_resk, double* rhok) {
+    return twogrid_host(ctx, A, b, guess, amg_fill_twogrid_defaults(o), nullptr, x, it, rel_res,
+                        rel_resk, rhok);
+}
+// [x,it,rel_res,rel_resk,rhok] = twogrid(A,b,amg_options)                  AMG/twogrid.m:1
+extern "C" int ipd_twogrid(ipd_ctx* ctx, const ipd_csc* A, const double* b, const double* guess,
+                           const ipd_amg_opts* o, ipd_rng* rng, double* x, int32_t* it,
+                           double* rel_res, double* rel_resk, double* rhok) {
+    AmgOpts ao = amg_fill_twogrid_defaults(o);
+    ao.bigph = (o && o->bigph >= 0) ? o->bigph : 0;                       // twogrid.m:12
+    ao.theta = 0.25;                                                      // mis_set(A,1/4), :50
+    ao.inter = 1;
+    if (ao.bigph && ao.fnode <= 0) {                                      // :24-26
+        ipd_set_error("bigph = 1 requires fnode > 0");
+        return IPD_E_ARG;
+    }
+    if (!ao.bigph && !rng) {
+        ipd_set_error("twogrid: mis_set needs a rand stream");
+        return IPD_E_ARG;
+    }
+    return twogrid_host(ctx, A, b, guess, ao, rng, x, it, rel_res, rel_resk, rhok);
 }
 
 extern "C" void ipd_amg_destroy(ipd_amg* h) {

@@ -185,6 +185,11 @@ int ipd_class_amg(ipd_ctx*, const ipd_csc* A, const double* b, const double* gue
 int ipd_twogrid_bigph(ipd_ctx*, const ipd_csc* A, const double* b, const double* guess,
                       const ipd_amg_opts* o, double* x, int32_t* it, double* rel_res,
                       double* rel_resk, double* rhok);
+/* [x,it,rel_res,rel_resk,rhok] = twogrid(A,b,amg_options) AMG/twogrid.m:1: bigph = 0 (default)
+ * smooths with .5*D^-1 and coarsens with mis_set(A,1/4) (needs `rng`); bigph = 1 as above    */
+int ipd_twogrid(ipd_ctx*, const ipd_csc* A, const double* b, const double* guess,
+                const ipd_amg_opts* o, ipd_rng* rng, double* x, int32_t* it, double* rel_res,
+                double* rel_resk, double* rhok);
 /* [d,it,res,resk] = PCG(H,e,pcg_options)   PCG.m:1 ; resk needs maxit slots
  * or NULL                                                                    */
 int ipd_pcg(ipd_ctx*, const ipd_csc* H, const double* e, const double* guess,

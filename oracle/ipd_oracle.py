@@ -758,6 +758,13 @@ def twogrid_bigph(A, b, amg_options: Optional[dict] = None):
         W = _csr(sp.diags(1.0 / np.asarray(W @ np.ones(Nc)).ravel()) @ W)  # :29-31
     Pro = _csr(sp.vstack([W, sp.identity(Nc, format="csr")]))
     Ac = _spgemm(_spgemm(_csr(Pro.T), A), Pro)                            # :33 left to right
+    return _twogrid_loop(A, b, R, Pro, Ac, retol, maxit, smoth, isnsp, guess)
+
+
+def _twogrid_loop(A, b, R, Pro, Ac, retol, maxit, smoth, isnsp, guess):
+    """The iteration shared by ``twogrid_bigph.m:35-52`` and ``twogrid.m:67-84`` with their
+    (identical) ``twogrid_it`` / ``twogrid_iteration``."""
+    N = A.shape[0]
     Rt = _csr(R.T)
     xi = np.ones(N)
     Axi = A @ xi
@@ -801,6 +808,34 @@ def twogrid_bigph(A, b, amg_options: Optional[dict] = None):
         if rhok[it - 1] > 1:
             break
     return x, it - 1, rel_res, rel_resk[:it].copy(), rhok[:it].copy()
+
+
+
+def twogrid(A, b, amg_options: Optional[dict], rng: np.random.RandomState):
+    """``AMG/twogrid.m:1-85``: the two-level method for a general matrix (``bigph = 0``: Jacobi
+    smoother ``.5*D^{-1}``, C/F split by ``mis_set(A,1/4)``, interpolation ``W1 + 0.5*W2`` -- the
+    ``~isempty`` test of ``:58`` is always true) or a bigraph (``bigph = 1``: as twogrid_bigph)."""
+    b = np.asarray(b, float)
+    if amg_options is None:
+        amg_options = dict(retol=1e-12, bigph=0, maxit=20, smoth=10, isnsp=1, guess=np.zeros_like(b))
+    o = dict(amg_options)
+    retol = 0 if o.get("retol") is None else o["retol"]                  # :11-16
+    bigph = 0 if o.get("bigph") is None else int(o["bigph"])
+    maxit = 50 if o.get("maxit") is None else int(o["maxit"])
+    smoth = 3 if o.get("smoth") is None else int(o["smoth"])
+    isnsp = 0 if o.get("isnsp") is None else int(o["isnsp"])
+    guess = np.zeros_like(b) if o.get("guess") is None else np.asarray(o["guess"], float)
+    fnode = 0 if o.get("fnode") is None else int(o["fnode"])
+    if bigph and fnode <= 0:
+        raise ValueError("bigph = 1 requires fnode > 0")                  # :24-26
+    if bigph:
+        return twogrid_bigph(A, b, dict(retol=retol, maxit=maxit, smoth=smoth, isnsp=isnsp,
+                                        guess=guess, fnode=fnode))
+    A = _csr(A)
+    N = A.shape[0]
+    R = _csr(0.5 * sp.diags(1.0 / A.diagonal()))                          # :40
+    Ac, Pro, _ = transfer(A, dict(bigph=0, theta=1 / 4, isnsp=isnsp, inter=1), 2, rng)  # :50-66
+    return _twogrid_loop(A, b, R, Pro, Ac, retol, maxit, smoth, isnsp, guess)
 
 
 def Hybrid_twogrid(prob_data: dict, amg_options: dict, rng: np.random.RandomState,

@@ -57,6 +57,23 @@ def test_twogrid_bigph_matches_oracle(m, n, rho, isnsp):
     assert np.linalg.norm(A @ x - b) <= 1e-9 * np.linalg.norm(b)
 
 
+@pytest.mark.parametrize("N,isnsp", [(120, 1), (300, 1), (90, 0)])
+def test_twogrid_general_matrix_matches_oracle(N, isnsp):
+    """`AMG/twogrid.m` with bigph = 0: Jacobi smoother, mis_set coarsening (consumes rand)."""
+    A = PR.random_sym_graph_laplacian(N, deg=3, seed=1)
+    b = np.random.RandomState(2).standard_normal(N)
+    o = dict(retol=1e-10, bigph=0, maxit=25, smoth=3, isnsp=isnsp, guess=None)
+    rng = ipd().MatlabRand(5489)
+    x, it, rr, hist, _ = ipd().twogrid(sp.csc_matrix(A), b, o, rng)
+    orng = O.matlab_rng()
+    xr, itr, rrr, histr, _ = O.twogrid(A, b, o, orng)
+    assert it == itr
+    assert np.allclose(hist, histr, rtol=1e-6, atol=1e-12)
+    assert np.linalg.norm(A @ (x - xr)) <= 1e-9 * np.linalg.norm(b)
+    with pytest.raises(ValueError, match="bigph = 1 requires fnode > 0"):
+        ipd().twogrid(sp.csc_matrix(A), b, dict(o, bigph=1))
+
+
 @pytest.mark.parametrize("m,n,rho", [(90, 80, 0.06), (40, 36, 0.12), (120, 110, 0.02)])
 def test_hybrid_twogrid_matches_oracle(m, n, rho):
     pd = prob(m, n, rho, 3)
