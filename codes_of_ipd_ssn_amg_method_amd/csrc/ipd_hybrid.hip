@@ -378,9 +378,22 @@ struct MaskHint {   // p, q, tk of the rescaled system when A is the whole Ae (e
     double tk = 0.0;
 };
 
+// Row f3 (opt-in, IPD_REUSE_HIERARCHY=1): AMG4POT solves two systems with the same Ae
+// (Class2/AMG4POT.m:46-47) and the reference sets the hierarchy up twice.  The second setup draws
+// fresh random numbers in mis_set, so its hierarchy differs from the first; reusing the first one
+// changes zeta within the solver tolerance only, but not bit for bit -- hence off by default.
+struct HybridCache {
+    bool valid = false;
+    Csr Ae;
+    Components cc;
+    std::vector<std::unique_ptr<ipd_amg, void (*)(ipd_amg*)>> hier;   // in order of use
+    size_t next = 0;
+};
+
 static void class_amg_on(ipd_ctx* ctx, const Csr& A, const double* f, AmgOpts o, int isnsp,
                          long long fnode, double gscale, ipd_rng* rng, double* u_out, int* it,
-                         double* rel_res, const MaskHint& mh = MaskHint()) {
+                         double* rel_res, const MaskHint& mh = MaskHint(),
+                         HybridCache* cache = nullptr) {
     const int N = A.nr;
     o.isnsp = isnsp;
     o.fnode = fnode;
@@ -389,32 +402,53 @@ static void class_amg_on(ipd_ctx* ctx, const Csr& A, const double* f, AmgOpts o,
     for (double& v : g) v = gscale * v;
     double* dg = ctx->scratch->alloc<double>((size_t)N);
     ctx->upload(dg, g.data(), (size_t)N);
-    std::unique_ptr<ipd_amg, void (*)(ipd_amg*)> h(nullptr, ipd_amg_destroy);
-    {
+    std::unique_ptr<ipd_amg, void (*)(ipd_amg*)> own(nullptr, ipd_amg_destroy);
+    ipd_amg* h = nullptr;
+    if (cache && cache->valid && cache->next < cache->hier.size()) {
+        h = cache->hier[cache->next++].get();          // second right-hand side: same operator
+    } else {
         ProfScope ps(ctx, PROF_AMG_SETUP);
-        h.reset(amg_setup(ctx, A, o, rng));
-        if (mh.p && o.bigph) amg_attach_maskop(h.get(), mh.p, mh.q, mh.m, mh.n, mh.tk);
+        own.reset(amg_setup(ctx, A, o, rng));
+        h = own.get();
+        if (mh.p && o.bigph) amg_attach_maskop(h, mh.p, mh.q, mh.m, mh.n, mh.tk);
+        if (cache) cache->hier.push_back(std::move(own));
     }
     int32_t its = 0;
     double rr = 0.0;
     {
         ProfScope ps(ctx, PROF_AMG_SOLVE);
-        amg_solve_dev(h.get(), f, dg, u_out, &its, &rr, nullptr, nullptr);
+        amg_solve_dev(h, f, dg, u_out, &its, &rr, nullptr, nullptr);
     }
     *it = its;
     *rel_res = rr;
 }
 
+static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
+                              const double* q, int m, int n, double bk1, double tk, const double* z,
+                              const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out,
+                              HybridCache* cache);
+
 void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
-                           const double* q, int m, int n, double bk1, double tk, const double* z,
-                           const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out) {
+                    const double* q, int m, int n, double bk1, double tk, const double* z,
+                    const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out) {
+    hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, z, opts, rng, zeta, out, nullptr);
+}
+
+static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
+                              const double* q, int m, int n, double bk1, double tk, const double* z,
+                              const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out,
+                              HybridCache* cache) {
     IPD_REQUIRE(rng, IPD_E_ARG, "Hybrid_AMG needs a rand stream");
     IPD_REQUIRE(tk != 0.0, IPD_E_ARG, "tk must be nonzero");
     const int M = m + n;
     const int N0 = 100;                                                   // Hybrid_AMG.m:51
     Arena& tmp = *ctx->scratch;
+    const bool reuse = cache && cache->valid;
+    if (cache) cache->next = 0;
     Csr Ae;
-    {
+    if (reuse) {
+        Ae = cache->Ae;
+    } else {
         ProfScope ps(ctx, PROF_BUILD_AE);
         build_Ae(ctx, tmp, H0, tdiag, p, q, m, n, bk1, tk, &Ae);        // :17-24
     }
@@ -427,11 +461,16 @@ void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const doub
     IPD_KERNEL_CHECK();
     IPD_HIP(hipMemsetAsync(u, 0, sizeof(double) * (size_t)M, ctx->stream));
     // components of A0 = Q0*H0*Q0: same pattern as H0 (qp has no zeros)     :27
-    Components cc;
-    {
+    Components cc_local;
+    if (!reuse) {
         ProfScope ps(ctx, PROF_COMPONENTS);
-        find_components(ctx, H0, &cc);
+        find_components(ctx, H0, &cc_local);
+        if (cache) {
+            cache->cc = cc_local;
+            cache->Ae = Ae;
+        }
     }
+    const Components& cc = reuse ? cache->cc : cc_local;
     out->num_comp = cc.ncomp;
     std::vector<double> hdK;
     if (tdiag) {
@@ -455,7 +494,7 @@ void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const doub
         mh.m = m;
         mh.n = n;
         mh.tk = tk;
-        class_amg_on(ctx, Ae, f, opts, isnsp, n, gscale, rng, u, &it, &rr, mh);
+        class_amg_on(ctx, Ae, f, opts, isnsp, n, gscale, rng, u, &it, &rr, mh, cache);
         out->itamg = it;
         out->resamg = rr;
         out->it_num = 1;
@@ -501,7 +540,7 @@ void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const doub
                         "Hybrid_AMG: a large component lies on one side of the bigraph");
             int it = 0;
             double rr = 0.0;
-            class_amg_on(ctx, Ak, fk, opts, isnsp, fnode, gscale, rng, dk, &it, &rr);
+            class_amg_on(ctx, Ak, fk, opts, isnsp, fnode, gscale, rng, dk, &it, &rr, MaskHint(), cache);
             hipLaunchKernelGGL(k_scatter, dim3(elems_grid(nk)), dim3(256), 0, ctx->stream, nk, d_pk,
                                dk, u);                                    // :77 u(pk) = dk
             IPD_KERNEL_CHECK();
@@ -549,6 +588,7 @@ void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const doub
     hipLaunchKernelGGL(k_scale_qp, dim3(g), dim3(256), 0, ctx->stream, M, n, p, q,
                        (const double*)u, zeta);                           // :113 zeta = Q0*u
     IPD_KERNEL_CHECK();
+    if (cache) cache->valid = true;
 }
 
 // ---------------------------------------------------------------------------
@@ -633,10 +673,15 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
                  const double* q, int m, int n, double bk1, double tk, const double* z,
                  const uint8_t* s, const double* phi, const AmgOpts& opts, ipd_rng* rng,
                  double* zeta, HybridOut* out) {
+    const char* re = getenv("IPD_REUSE_HIERARCHY");
+    const bool reuse_env = re && re[0] == '1';
+    HybridCache cache;
     auto solve = [&](const double* rhs, double* x, HybridOut* o) {
-        hybrid_amg_dev(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o);
+        hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o,
+                          reuse_env ? &cache : nullptr);
     };
     pot_reduce(ctx, H0, p, q, m, n, bk1, tk, z, s, phi, zeta, out, solve);
+    ctx->sync();   // the cached hierarchies are released on return
 }
 
 // ---------------------------------------------------------------------------
