@@ -273,7 +273,12 @@ def main():
             try:
                 pm = json.load(open(pf))
                 for kname, d in pm.items():
-                    if "k_smooth" in kname and "hbm_traffic_bytes_per_launch" in d:
+                    if "hbm_traffic_bytes_per_launch" not in d:
+                        continue
+                    if "k_smooth_mask" in kname:
+                        if "level1_mask_operator" in result:
+                            result["level1_mask_operator"]["traffic"] = d["hbm_traffic_bytes_per_launch"]
+                    elif "k_smooth" in kname:
                         traffic = d["hbm_traffic_bytes_per_launch"]
             except Exception:
                 traffic = None
