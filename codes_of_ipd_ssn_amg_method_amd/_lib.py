@@ -46,7 +46,7 @@ class ipd_amg_opts(Structure):
 
 
 class ipd_pcg_opts(Structure):
-    _fields_ = [("retol", c_double), ("maxit", c_int64), ("precd", c_int32)]
+    _fields_ = [("retol", c_double), ("maxit", c_int64), ("precd", c_int32), ("nf", c_int64)]
 
 
 class ipd_prob(Structure):

@@ -306,8 +306,12 @@ def PCG(H, e, pcg_options: dict | None = None):
             o.maxit = int(pcg_options["maxit"])
         if pcg_options.get("precd") is not None:
             o.precd = int(pcg_options["precd"])
+        if pcg_options.get("nf") is not None:
+            o.nf = int(pcg_options["nf"])
         if pcg_options.get("guess") is not None:
             guess = f64(pcg_options["guess"])
+        if o.precd == 5 and "nf" not in pcg_options:
+            raise ValueError("SSOR for bigraph requires pcg_options.nf!!!")   # PCG.m:64
     maxit = int(o.maxit) if o.maxit >= 0 else 10000
     d = np.empty(e.size)
     it = c_int64()

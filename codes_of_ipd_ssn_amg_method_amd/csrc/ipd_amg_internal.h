@@ -80,7 +80,8 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
 void amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev, double* x_dev,
                    int32_t* it, double* rel_res, double* rel_resk, double* rhok);
 void pcg_dev(ipd_ctx* ctx, const Csr& H, const double* e, const double* guess, double tol,
-             long long maxit, int precd, double* d, long long* it, double* res, double* resk_host);
+             long long maxit, int precd, double* d, long long* it, double* res, double* resk_host,
+             long long nf = 0);
 
 // ipd_hybrid.hip: problem-level solvers on device-resident data
 struct HybridOut {

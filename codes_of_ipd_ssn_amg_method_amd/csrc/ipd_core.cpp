@@ -214,6 +214,7 @@ extern "C" void ipd_pcg_opts_init(ipd_pcg_opts* o) {
     o->retol = -1;
     o->maxit = -1;
     o->precd = -1;
+    o->nf = 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -270,6 +270,149 @@ __global__ __launch_bounds__(BT) void k_pcg(PcgArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// PCG with the triangular preconditioners of PCG.m: precd 3 (SSOR, w = 1.5, :40-44,96-99) and
+// precd 5 (SSOR on the bigraph blocks, :52-62).  Cold paths (the drivers use precd 2): one
+// workgroup, correctness first.  The two triangular solves of precd 3 are sequential in the row
+// index: wave 0 walks the rows in order (lanes over a row's entries); the unknowns live in LDS.
+// precd 5 is applied matrix-free: with y_C = T^-1 (r_C - w U' V^-1 r_F),
+//     P r = w(2-w) [ V^-1 (r_F - w U y_C) ; y_C ]      (the block product of :59-60 expanded)
+// ---------------------------------------------------------------------------
+struct PcgGenArgs {
+    PcgArgs a;
+    int nf;          // precd 5: size of the F block
+    double* tmp;     // 2*N doubles
+};
+
+__device__ __forceinline__ void pcg_gen_prec(const PcgGenArgs& g, const double* r, double* w,
+                                             double* sol /*LDS, N*/, double* red) {
+    const PcgArgs& a = g.a;
+    const int tid = threadIdx.x, N = a.N;
+    const double* dg = a.work + 3 * (size_t)N;
+    const double om = 1.5, c = om * (2.0 - om);
+    if (a.precd == 5) {
+        const int nf = g.nf;
+        double* t1 = g.tmp;   // V^-1 r_F
+        for (int i = tid; i < nf; i += BT) t1[i] = r[i] / dg[i];
+        __syncthreads();
+        for (int i = nf + tid; i < N; i += BT) {   // y_C
+            double sdot = 0.0;
+            for (int t = a.rp[i]; t < a.rp[i + 1]; ++t)
+                if (a.ci[t] < nf) sdot += a.va[t] * t1[a.ci[t]];
+            w[i] = (r[i] - om * sdot) / dg[i];
+        }
+        __syncthreads();
+        for (int i = tid; i < nf; i += BT) {
+            double sdot = 0.0;
+            for (int t = a.rp[i]; t < a.rp[i + 1]; ++t)
+                if (a.ci[t] >= nf) sdot += a.va[t] * w[a.ci[t]];
+            w[i] = c * ((r[i] - om * sdot) / dg[i]);
+        }
+        __syncthreads();
+        for (int i = nf + tid; i < N; i += BT) w[i] = c * w[i];
+        __syncthreads();
+        return;
+    }
+    // precd 3: p1 = (D + wL) \ r ; p2 = D*p1 ; p = (c*(D + wU)) \ p2
+    if (tid < 64) {
+        for (int i = 0; i < N; ++i) {   // forward
+            double sdot = 0.0;
+            for (int t = a.rp[i] + tid; t < a.rp[i + 1]; t += 64) {
+                const int j = a.ci[t];
+                if (j < i) sdot += a.va[t] * sol[j];
+            }
+            sdot = wave_sum(sdot);
+            if (tid == 0) sol[i] = (r[i] - om * sdot) / dg[i];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int i = tid; i < N; i += 64) sol[i] = dg[i] * sol[i];   // p2
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = N - 1; i >= 0; --i) {   // backward, in place: rows > i already hold p
+            double sdot = 0.0;
+            for (int t = a.rp[i] + tid; t < a.rp[i + 1]; t += 64) {
+                const int j = a.ci[t];
+                if (j > i) sdot += (c * om * a.va[t]) * sol[j];
+            }
+            sdot = wave_sum(sdot);
+            if (tid == 0) sol[i] = (sol[i] - sdot) / (c * dg[i]);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += BT) w[i] = sol[i];
+    __syncthreads();
+    (void)red;
+}
+
+__global__ __launch_bounds__(BT) void k_pcg_gen(const PcgGenArgs g) {
+    __shared__ double red[16];
+    extern __shared__ __attribute__((aligned(16))) double sol[];
+    const PcgArgs& a = g.a;
+    const int tid = threadIdx.x, N = a.N;
+    double* r = a.work;
+    double* p = a.work + N;
+    double* q = a.work + 2 * (size_t)N;
+    double* dg = a.work + 3 * (size_t)N;
+    double* w = g.tmp + N;
+    // r = e - H*d0 ; diag                                                    PCG.m:68
+    for (int row = tid; row < N; row += BT) {
+        double sdot = 0.0, dd = 0.0;
+        for (int t = a.rp[row]; t < a.rp[row + 1]; ++t) {
+            const int j = a.ci[t];
+            if (a.guess) sdot += a.va[t] * a.guess[j];
+            if (j == row) dd = a.va[t];
+        }
+        r[row] = a.rhs[row] - sdot;
+        dg[row] = dd;
+        a.d[row] = a.guess ? a.guess[row] : 0.0;
+    }
+    __syncthreads();
+    pcg_gen_prec(g, r, w, sol, red);                                            // :69
+    double acc = 0.0;
+    for (int row = tid; row < N; row += BT) {
+        p[row] = w[row];
+        acc += r[row] * w[row];
+    }
+    double delta_new = block_sum(acc, red);
+    const double delta_0 = delta_new;
+    const double thresh = a.tol * a.tol * delta_0;
+    long long it_count = 0;
+    while (it_count < a.maxit && delta_new > thresh) {                          // :76
+        const double delta_old = delta_new;
+        __syncthreads();
+        acc = 0.0;
+        for (int row = tid; row < N; row += BT) {
+            double sdot = 0.0;
+            for (int t = a.rp[row]; t < a.rp[row + 1]; ++t) sdot += a.va[t] * p[a.ci[t]];
+            q[row] = sdot;
+            acc += sdot * p[row];
+        }
+        const double qp = block_sum(acc, red);
+        const double alpha = delta_old / qp;
+        for (int row = tid; row < N; row += BT) {
+            a.d[row] += alpha * p[row];
+            r[row] = r[row] - alpha * q[row];
+        }
+        __syncthreads();
+        pcg_gen_prec(g, r, w, sol, red);                                        // :80
+        acc = 0.0;
+        for (int row = tid; row < N; row += BT) acc += r[row] * w[row];
+        delta_new = block_sum(acc, red);
+        const double beta = delta_new / delta_old;
+        for (int row = tid; row < N; row += BT) p[row] = w[row] + beta * p[row];
+        ++it_count;
+        if (tid == 0 && a.out && it_count <= a.nresk)
+            a.out[1 + it_count] = sqrt(fabs(delta_new / delta_0));
+    }
+    if (tid == 0 && a.out) {
+        a.out[0] = (double)it_count;
+        a.out[1] = sqrt(fabs(delta_new / delta_0));
+    }
+}
+
+// ---------------------------------------------------------------------------
 // fused single-workgroup program
 // ---------------------------------------------------------------------------
 // Phases whose row range fits one workgroup (a few thousand nonzeros) cost far more as
@@ -366,10 +509,15 @@ static int pick_lanes(long long nnz, int nrows, int blocks_target) {
 
 void pcg_dev(ipd_ctx* ctx, const Csr& H, const double* e, const double* guess, double tol,
              long long maxit, int precd, double* d, long long* it, double* res,
-             double* resk_host) {
+             double* resk_host, long long nf) {
     IPD_REQUIRE(H.nr == H.nc, IPD_E_ARG, "PCG: H must be square");
-    IPD_REQUIRE(precd == 1 || precd == 2, IPD_E_UNSUPPORTED,
-                "PCG: only precd 1 (none) and 2 (Jacobi) run on the device; 3,4,5 are cold paths");
+    IPD_REQUIRE(precd != 4, IPD_E_UNSUPPORTED,
+                "PCG: precd 4 (MATLAB's ichol) is not built; use 1, 2, 3 or 5");
+    IPD_REQUIRE(precd == 1 || precd == 2 || precd == 3 || precd == 5, IPD_E_ARG,
+                "PCG: precd must be 1..5");
+    if (precd == 5)
+        IPD_REQUIRE(nf > 0 && nf < H.nr, IPD_E_ARG,
+                    "SSOR for bigraph requires pcg_options.nf!!!");              // PCG.m:64
     Arena& tmp = *ctx->scratch;
     const long long nresk = resk_host ? std::min<long long>(maxit, 1 << 20) : 0;
     PcgArgs a;
@@ -387,7 +535,22 @@ void pcg_dev(ipd_ctx* ctx, const Csr& H, const double* e, const double* guess, d
     a.precd = precd;
     a.out = tmp.alloc<double>((size_t)(2 + nresk));
     a.nresk = nresk;
-    hipLaunchKernelGGL(k_pcg, dim3(1), dim3(BT), 0, ctx->stream, a);
+    if (precd == 3 || precd == 5) {
+        IPD_REQUIRE(H.nr <= 7000, IPD_E_LIMIT, "PCG precd 3/5: at most 7000 rows (LDS-resident solve)");
+        PcgGenArgs g;
+        g.a = a;
+        g.nf = (int)nf;
+        g.tmp = tmp.alloc<double>(2 * (size_t)H.nr);
+        static bool attr_set = false;
+        if (!attr_set) {
+            IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_gen),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_pcg_gen, dim3(1), dim3(BT), sizeof(double) * (size_t)H.nr, ctx->stream, g);
+    } else {
+        hipLaunchKernelGGL(k_pcg, dim3(1), dim3(BT), 0, ctx->stream, a);
+    }
     IPD_KERNEL_CHECK();
     if (it || res || resk_host) {
         double head[2];

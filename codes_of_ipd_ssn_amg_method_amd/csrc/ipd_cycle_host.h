@@ -1098,10 +1098,12 @@ extern "C" int ipd_pcg(ipd_ctx* ctx, const ipd_csc* H, const double* e, const do
         double tol = 1e-11;
         long long maxit = 10000;
         int precd = 2;  // PCG.m:24-27 defaults
+        long long nf = 0;
         if (o) {
             if (o->retol >= 0) tol = o->retol;
             if (o->maxit >= 0) maxit = o->maxit;
             if (o->precd >= 0) precd = o->precd;
+            nf = o->nf;
         }
         Csr hm;
         csr_upload_from_csc(ctx, tmp, H, false, &hm);  // true rows of H
@@ -1115,7 +1117,7 @@ extern "C" int ipd_pcg(ipd_ctx* ctx, const ipd_csc* H, const double* e, const do
             ctx->upload(dg, guess, N);
         }
         long long its = 0;
-        pcg_dev(ctx, hm, de, dg, tol, maxit, precd, dd, &its, res, resk);
+        pcg_dev(ctx, hm, de, dg, tol, maxit, precd, dd, &its, res, resk, nf);
         if (it) *it = its;
         ctx->fetch(dd, d, N);
     });

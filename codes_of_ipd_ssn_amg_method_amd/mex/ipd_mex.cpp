@@ -158,7 +158,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         else chk(ipd_amg_wcycle(g_h, mxGetDoubles(a[0]), isnsp, k, nrhs > 4 ? mxGetDoubles(a[3]) : nullptr, mxGetDoubles(plhs[0])));
     } else if (fn == "PCG") {                    // [d,it,res,resk] = PCG(H,e,pcg_options)
         ipd_csc H = csc_of(a[0]); ipd_pcg_opts o; ipd_pcg_opts_init(&o); const mxArray* so = nrhs > 3 ? a[2] : nullptr;
-        if (so) { o.retol = field(so, "retol", -1); o.maxit = (int64_t)field(so, "maxit", -1); o.precd = (int32_t)field(so, "precd", -1); }
+        if (so) { o.retol = field(so, "retol", -1); o.maxit = (int64_t)field(so, "maxit", -1); o.precd = (int32_t)field(so, "precd", -1); o.nf = (int64_t)field(so, "nf", 0); }
         const int64_t maxit = o.maxit >= 0 ? o.maxit : 10000;
         plhs[0] = col((size_t)H.nrows); int64_t it = 0; double res = 0; std::vector<double> rk((size_t)maxit + 1);
         chk(ipd_pcg(g_ctx, &H, mxGetDoubles(a[1]), opt_vec(so, "guess"), &o, mxGetDoubles(plhs[0]), &it, &res, rk.data()));

@@ -89,7 +89,9 @@ typedef struct ipd_amg_opts {
 typedef struct ipd_pcg_opts {
     double retol;   /* default 1e-11 */
     int64_t maxit;  /* default 10000 */
-    int32_t precd;  /* 1 none, 2 Jacobi (device); 3,4,5 -> IPD_E_UNSUPPORTED */
+    int32_t precd;  /* 1 none, 2 Jacobi, 3 SSOR (w = 1.5), 5 SSOR on the bigraph blocks;
+                       4 (MATLAB's ichol) -> IPD_E_UNSUPPORTED                     */
+    int64_t nf;     /* precd 5: size of the F block (pcg_options.nf, PCG.m:55)      */
 } ipd_pcg_opts;
 
 /* prob_data struct (Class1/APD_SsN_Class1.m:154-156, Class2/APD_SsN_Class2.m:163-166). */

@@ -36,7 +36,35 @@ def test_pcg(ipd):
     d, it, res, _ = ipd.PCG(A, np.zeros(200))
     assert it == 0 and np.isnan(res) and not d.any()
     with pytest.raises(ipd.IpdError):
-        ipd.PCG(A, b, dict(precd=4))
+        ipd.PCG(A, b, dict(precd=4))        # MATLAB's ichol: not built
+
+
+def test_pcg_ssor_preconditioners(ipd):
+    """precd 3 (SSOR, w = 1.5, PCG.m:40-44,96-99) on a general SPD matrix and precd 5 (SSOR on the
+    bigraph blocks, :52-62, needs pcg_options.nf) on a rescaled Newton operator."""
+    A = PR.random_sym_graph_laplacian(300, seed=10, eps=0.5)
+    b = np.random.RandomState(11).randn(300)
+    o = dict(guess=0.1 * np.random.RandomState(3).randn(300), retol=1e-11, maxit=1000, precd=3)
+    d, it, res, resk = ipd.PCG(A, b, o)
+    do, ito, reso, resko = O.PCG(A, b, o)
+    assert abs(it - ito) <= 1
+    assert np.linalg.norm(A @ d - b) <= 1e-9 * np.linalg.norm(b)
+    assert np.allclose(d, do, rtol=1e-8, atol=1e-10)
+    k = min(it, ito) - 2
+    assert np.allclose(resk[:k], resko[:k], rtol=1e-6)
+    m, n = 60, 50
+    s = PR.mask_bernoulli(m, n, 0.2, seed=3)
+    pd = PR.make_prob(m, n, s, pq_random=True)
+    Ae = O.build_Ae(O.ASAt(s, pd["p"], pd["q"]), pd["T"], pd["p"], pd["q"], pd["bk1"], pd["tk"])[0]
+    f = np.random.RandomState(5).randn(m + n)
+    o5 = dict(guess=None, retol=1e-11, maxit=5000, precd=5, nf=n)
+    d, it, res, resk = ipd.PCG(Ae, f, o5)
+    do, ito, reso, resko = O.PCG(Ae, f, o5)
+    assert abs(it - ito) <= 2
+    assert np.linalg.norm(Ae @ d - f) <= 1e-8 * np.linalg.norm(f)
+    assert np.linalg.norm(d - do) <= 1e-7 * np.linalg.norm(do)
+    with pytest.raises(ValueError, match="requires pcg_options.nf"):
+        ipd.PCG(Ae, f, dict(precd=5))
 
 
 CASES = [
