@@ -107,5 +107,5 @@ def test_amg4pot(ipd, m, n, rho):
     z, it, res, info = ipd.AMG4POT(pd, O.amg_options_class2("w"), "amg", ipd.MatlabRand())
     assert np.array_equal(info, infoo) and abs(it - ito) <= 1
     assert np.linalg.norm(z - zo) <= 1e-6 * np.linalg.norm(zo)
-    with pytest.raises(ipd.IpdError):
-        ipd.AMG4POT(pd, O.amg_options_class2("w"), "twogrid")
+    with pytest.raises(ValueError):
+        ipd.AMG4POT(pd, O.amg_options_class2("w"), "direct")   # str is 'amg' or 'twogrid' (:44-51)
