@@ -1079,13 +1079,13 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
                     const int Lt = tiny_lanes(L.N), i = t / Lt, sub = t % Lt;
                     const bool valid = i < L.N;
                     const double sd = lds_densedot_split(L.dA, L.N, L.N, i, sub, Lt, valid, L.e);
-                    if (valid && sub == 0) L.rr[i] = L.r[i] - sd;
+                    if (valid && sub == 0) L.e2[i] = L.r[i] - sd;   // e2 is free between the sweeps
                 }
                 tiny_sync();
                 {
                     const int Lt = tiny_lanes(L.Nc), i = t / Lt, sub = t % Lt;
                     const bool cv = i < L.Nc;
-                    const double rc = lds_densedot_split(L.dPt, L.Nc, L.N, i, sub, Lt, cv, L.rr);
+                    const double rc = lds_densedot_split(L.dPt, L.Nc, L.N, i, sub, Lt, cv, L.e2);
                     if (cv && sub == 0) L.rc[i] = rc;
                 }
                 tiny_sync();
@@ -1231,13 +1231,13 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
                     const int Lr = lanes_per_row(L.N), row = i / Lr, sub = i % Lr;
                     const bool rvld = row < L.N;
                     const double sd = lds_rowdot_split(L.rp, L.ci, L.va, row, sub, Lr, rvld, L.e);
-                    if (rvld && sub == 0) L.rr[row] = L.r[row] - sd;
+                    if (rvld && sub == 0) L.e2[row] = L.r[row] - sd;   // e2 is free between the sweeps
                 }
                 __syncthreads();
                 {
                     const int Lr = lanes_per_row(L.Nc), row = i / Lr, sub = i % Lr;
                     const bool cv = row < L.Nc;
-                    const double rc = lds_rowdot_split(L.Rrp, L.Rci, L.Rva, row, sub, Lr, cv, L.rr);
+                    const double rc = lds_rowdot_split(L.Rrp, L.Rci, L.Rva, row, sub, Lr, cv, L.e2);
                     if (cv && sub == 0) L.rc[row] = rc;
                 }
                 __syncthreads();

@@ -308,6 +308,13 @@ void amg_prepare_levels(ipd_amg* h) {
                 tiny_lo = k;
             }
     }
+    // the thread-per-row / wave sub-cycles keep the residual in the free iterate buffer and never
+    // use the Gauss-Seidel scratch vector: 5 vectors per cached level instead of 7
+    bool lean_vectors = true;
+    {
+        const char* nb = std::getenv("IPD_NO_BLK");
+        if (nb && nb[0] == '1') lean_vectors = false;
+    }
     // LDS cache plan: deepest levels first, while they fit; returns the first cached level
     auto plan_lds = [&](size_t stage, size_t* used_out) {
         size_t used = stage + SOL_HEAD + 256;
@@ -317,7 +324,7 @@ void amg_prepare_levels(ipd_amg* h) {
             const Level& lv = h->L[k];
             const size_t N = (size_t)lv.A.nr;
             size_t bytes = r16(4 * (N + 1)) + r16(4 * (size_t)lv.A.nnz) + r16(8 * (size_t)lv.A.nnz) +
-                           7 * r16(8 * N) + 16;
+                           ((lean_vectors && k >= 2) ? 5 : 7) * r16(8 * N) + 16;
             if (k < h->J) {
                 const size_t Nc = (size_t)h->L[k + 1].A.nr, np = (size_t)h->L[k + 1].P.nnz;
                 bytes += r16(4 * (Nc + 1)) + r16(4 * (N + 1)) + 2 * (r16(4 * np) + r16(8 * np));
@@ -345,6 +352,7 @@ void amg_prepare_levels(ipd_amg* h) {
     // Lays levels k_from..J out behind the staging area, packs the image on the device and
     // returns it (the descriptor the kernels take); *lds_total = dynamic LDS bytes to request.
     auto build_image = [&](SolveDesc* sd, int k_from, size_t stage, size_t* lds_total) {
+        const bool lean = lean_vectors && sd->k_blk <= std::max(2, k_from);
         std::vector<PackEntry> packs;
         std::vector<unsigned> relocs;
         size_t off = stage + SOL_HEAD;   // LDS offset (from dyn_raw) of the next carve
@@ -406,10 +414,17 @@ void amg_prepare_levels(ipd_amg* h) {
             SolveLevel& T = sd->L[k];
             const size_t N = (size_t)T.lv.N;
             set_off(T.lv.r, carve(N * 8));
-            set_off(T.lv.rr, carve(N * 8));
             set_off(T.e, carve(N * 8));
             set_off(T.e2, carve(N * 8));
-            set_off(T.w, carve(N * 8));
+            if (lean && k >= 2) {   // never dereferenced on these levels (see lean_vectors)
+                T.lv.rr = T.e2;
+                relocs.push_back((unsigned)(reinterpret_cast<char*>(&T.lv.rr) - reinterpret_cast<char*>(sd)));
+                T.w = T.e2;
+                relocs.push_back((unsigned)(reinterpret_cast<char*>(&T.w) - reinterpret_cast<char*>(sd)));
+            } else {
+                set_off(T.lv.rr, carve(N * 8));
+                set_off(T.w, carve(N * 8));
+            }
         }
         for (int k = std::max(1, k_from - 1); k < h->J; ++k) {   // vectors that cross levels
             SolveLevel& T = sd->L[k];
@@ -510,7 +525,8 @@ void amg_prepare_levels(ipd_amg* h) {
             if (k_small < h->J) {
                 // ... and everything below it fits in LDS (the stage area holds N_root doubles)
                 for (int kroot = k_small; kroot < h->J; ++kroot) {
-                    const size_t stage = r16(sizeof(double) * (size_t)h->L[kroot].A.nr);
+                    // the generic phases (and their staging vector) only run when IPD_NO_BLK is set
+                    const size_t stage = lean_vectors ? 16 : r16(sizeof(double) * (size_t)h->L[kroot].A.nr);
                     size_t used = 0;
                     const int k_lds = plan_lds(stage, &used);
                     if (k_lds > kroot) continue;
