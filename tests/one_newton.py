@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One ASAt + Hybrid_AMG call (after a warm-up call) for rocprofv3 kernel traces:
-  tools/one_newton.py [tree|hub|golden40]"""
+  tests/one_newton.py [tree|hub|golden40]"""
 import os
 import sys
 import time

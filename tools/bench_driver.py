@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Whole-solve timing of the device drivers (rows f1/f2) and the bandwidth of the fused
-evaluation pass.  `--oracle` also times the CPU restatement (bounded: small sizes only).
+evaluation pass.  (The CPU restatement is timed by tests/time_oracle_drivers.py: only tests/ may
+import oracle/.)
 
-  python tools/bench_driver.py [--sizes 500,1024] [--oracle]
+  python tools/bench_driver.py [--sizes 500,1024] [--classes 1,2]
 """
 import argparse
 import json
@@ -69,30 +70,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="500,1024")
     ap.add_argument("--classes", default="1,2")
-    ap.add_argument("--oracle", action="store_true")
     a = ap.parse_args()
     for N in [int(x) for x in a.sizes.split(",")]:
         for cls in [int(x) for x in a.classes.split(",")]:
             pr = problem(cls, N)
             rec = run(cls, N, pr)
-            if a.oracle and N <= 500:
-                from oracle import drivers as D
-                one = np.ones(N)
-                t0 = time.perf_counter()
-                if cls == 1:
-                    st = D.warmup_class1(pr["c"], pr["r"], pr["l"], one, one, np.inf, 100)
-                    t1 = time.perf_counter()
-                    ref = D.apd_ssn_class1(pr["c"], pr["r"], pr["l"], one, one, np.inf, inner="amg",
-                                           start=st)
-                else:
-                    st = D.warmup_class2(pr["c"], pr["r"], pr["l"], one, one, pr["mu"],
-                                         np.ones(N * N), 100)
-                    t1 = time.perf_counter()
-                    ref = D.apd_ssn_class2(pr["c"], pr["r"], pr["l"], one, one, pr["mu"],
-                                           np.ones(N * N), inner="amg", start=st)
-                t2 = time.perf_counter()
-                rec.update(oracle_warmup_s=t1 - t0, oracle_apd_s=t2 - t1, oracle_k=ref["k"],
-                           oracle_fval=ref["fval"])
             print(json.dumps(rec), flush=True)
 
 

@@ -10,8 +10,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import codes_of_ipd_ssn_amg_method_amd as ipd          # noqa: E402
 from codes_of_ipd_ssn_amg_method_amd import _lib as L  # noqa: E402
-from oracle import ipd_oracle as O                     # noqa: E402
-from tests import problems as PR                       # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 kcap = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -28,9 +26,10 @@ lam = ws.state()[2]
 sc = ws.begin(kcap + 1)
 ev = ws.eval(lam)
 print("captured k=%d E=%d bk1=%.3e tk=%.3e" % (kcap + 1, ev["E"], sc["bk1"], sc["tk"]))
-H0 = O.ASAt(ev["s"], one, one)
 import scipy.sparse as sp
-Ae = O.build_Ae(H0, sp.csr_matrix((2 * N, 2 * N)), one, one, sc["bk1"], sc["tk"])[0]
+H0 = ipd.ASAt(ev["s"], one, one)                       # Hybrid_AMG.m:17-24 with p = q = 1, T = 0
+Q0 = sp.diags(np.concatenate([one, -one]))
+Ae = sp.csr_matrix(sc["bk1"] * (Q0 @ Q0) + (1.0 / sc["tk"]) * ((Q0 @ H0) @ Q0))
 ws.close()
 opts = dict(retol=1e-11, bigph=1, maxit=30, theta=1 / 4, smoth=5, cycle="w", isnsp=1, inter=1,
             fnode=N)
