@@ -510,7 +510,10 @@ class APDWorkspace:
     SsN_itnum``, ``records()`` -> what the scripts print per Newton step.
     """
 
-    def __init__(self, cls, c, r, l, p, q, gama=np.inf, mu=0.0, phi=None):
+    def __init__(self, cls, c, r, l, p, q, gama=np.inf, mu=0.0, phi=None, ctx=None):
+        # ctx: an own L.Context (own HIP stream and arenas) lets several workspaces run
+        # concurrently from several host threads; default = the process-wide context
+        self._ctx = ctx
         self.cls = int(cls)
         self._keep = [f64(c), f64(r), f64(l), f64(p), f64(q)]
         c_, r_, l_, p_, q_ = self._keep
@@ -545,7 +548,7 @@ class APDWorkspace:
         self.L = self.M + (1 if self.cls == 2 else 0)
         self.U = m * n + (self.M if self.cls == 2 else 0)
         self.handle = c_void_p()
-        check(lib.ipd_apd_create(_h(), byref(d), byref(self.handle)))
+        check(lib.ipd_apd_create((ctx or get_ctx()).handle, byref(d), byref(self.handle)))
 
     def close(self):
         if getattr(self, "handle", None):
