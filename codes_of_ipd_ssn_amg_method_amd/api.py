@@ -180,13 +180,15 @@ def transfer(A, amg_options: dict, level: int = 2, rng: MatlabRand | None = None
 class AMGHierarchy:
     """Device-resident ``Ack/Prok/Rk/J`` (``AMG/Class_AMG.m:42-85``)."""
 
-    def __init__(self, A, amg_options: dict, rng: MatlabRand | None = None):
+    def __init__(self, A, amg_options: dict, rng: MatlabRand | None = None, ctx=None):
+        self.ctx = ctx or get_ctx()      # an own L.Context = an own HIP stream (concurrent use)
         self.rng = rng or MatlabRand()
         self._a = CscIn(A)
         self.opts = dict(amg_options) if amg_options is not None else None
         o = _opts_struct(amg_options)
         self.handle = c_void_p()
-        check(lib.ipd_amg_setup(_h(), self._a.ref(), byref(o), self.rng.handle, byref(self.handle)))
+        check(lib.ipd_amg_setup(self.ctx.handle, self._a.ref(), byref(o), self.rng.handle,
+                                byref(self.handle)))
         self.maxit = int(o.maxit) if o.maxit >= 0 else 50
         self.N = int(self._a.struct.nrows)
 
@@ -199,13 +201,12 @@ class AMGHierarchy:
         Hybrid_AMG's rescaled operator for these ``p, q, tk`` and the 1-bit-per-entry sweeps are
         now in use; False leaves the CSR kernels in place."""
         p_, q_ = f64(p), f64(q)
-        dp = L.DeviceBuffer.from_array(p_)
-        dq = L.DeviceBuffer.from_array(q_)
+        dp = L.DeviceBuffer.from_array(p_, self.ctx)
+        dq = L.DeviceBuffer.from_array(q_, self.ctx)
         got = c_int32(0)
         check(lib.ipd_amg_attach_mask_operator(self.handle, dp.ptr, dq.ptr, c_int64(p_.size),
                                                c_int64(q_.size), c_double(float(tk)), byref(got)))
-        _h_sync = get_ctx()
-        _h_sync.sync()
+        self.ctx.sync()
         return bool(got.value)
 
     def level_dims(self, k: int):
