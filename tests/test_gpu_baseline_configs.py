@@ -89,3 +89,59 @@ def test_residual_history_monotone_full_size(ipd):
     o.update(fnode=n, guess=np.zeros(m + n))
     x, it, rel, rk, rho = ipd.Class_AMG(Ae, qp * pd["z"], o, ipd.MatlabRand())
     assert np.all(np.diff(rk) < 0) and np.all(rho[1:] < 1) and rel <= 1e-11 and it < 30
+
+
+# ---------------------------------------------------------------------------
+# the drivers (rows f1/f2) at full size: size-independent optimality properties
+# ---------------------------------------------------------------------------
+def _ot_problem(cls, N, seed=1):
+    rs = np.random.RandomState(seed)
+    c, r, l = rs.random_sample(N * N), rs.random_sample(N), rs.random_sample(N)
+    if cls == 1:
+        return c, r, l * r.sum() / l.sum(), None
+    return c, r, l, 0.65 * min(r.sum(), l.sum())
+
+
+def test_class1_driver_full_size_optimality(ipd):
+    """m = n = 1024: the iterate the device driver stops at satisfies the LP's optimality system
+    (APD_SsN_Class1.m:1-7): primal feasibility, x >= 0, and dual feasibility / complementarity
+    through the reduced costs c + A'lk (the scripts' KKT(xk) residual, recomputed on the host)."""
+    N = 1024
+    c, r, l, _ = _ot_problem(1, N)
+    one = np.ones(N)
+    out = ipd.APD_SsN_Class1(c, r, l, one, one, np.inf, rng=ipd.MatlabRand(5489))
+    assert out["converged"] and out["k"] <= 100 and out["FailAMG"] == 0
+    x, lam = out["xk"], out["lk"]
+    assert x.min() >= 0.0
+    X = x.reshape((N, N), order="F")
+    b = np.concatenate([r, l])
+    Ax = np.concatenate([X.sum(axis=0), X.sum(axis=1)])
+    assert np.linalg.norm(Ax - b) <= 1e-6 * (1 + out["KKT_lk"][0])
+    red = c.reshape((N, N), order="F") + lam[:N][None, :] + lam[N:][:, None]    # c + A'lk
+    kx = np.linalg.norm(X - np.maximum(X - red, 0.0))
+    assert kx <= 1e-6 * (1 + out["KKT_xk"][0])
+    assert abs(kx - out["KKT_xk"][-1]) <= 1e-9 * (1 + kx)
+    assert abs(c @ x - out["fval"]) <= 1e-12 * abs(out["fval"])
+    # monotone enough: the relative KKT residual fell by six orders of magnitude
+    rr0 = max(out["KKT_xk"][0], out["KKT_lk"][0])
+    assert max(out["KKT_xk"][-1], out["KKT_lk"][-1]) <= 1e-5 * rr0
+
+
+def test_class2_driver_full_size_optimality(ipd):
+    """m = n = 512 (BASELINE config 3): partial optimal transport, phi = 1."""
+    N = 512
+    c, r, l, mu = _ot_problem(2, N)
+    one, phi = np.ones(N), np.ones(N * N)
+    out = ipd.APD_SsN_Class2(c, r, l, one, one, mu, phi, rng=ipd.MatlabRand(5489))
+    assert out["converged"] and out["k"] <= 100
+    u, lam = out["uk"], out["lk"]
+    mn = N * N
+    x, y, z = u[:mn], u[mn:mn + N], u[mn + N:]
+    assert min(x.min(), y.min(), z.min()) >= 0.0
+    X = x.reshape((N, N), order="F")
+    assert abs(x.sum() - mu) <= 1e-6 * (1 + mu)                       # phi'x = mu
+    assert np.linalg.norm(X.sum(axis=0) + y - r) <= 1e-6 * (1 + np.linalg.norm(r))
+    assert np.linalg.norm(X.sum(axis=1) + z - l) <= 1e-6 * (1 + np.linalg.norm(l))
+    red = c.reshape((N, N), order="F") + lam[:N][None, :] + lam[N:2 * N][:, None] + lam[2 * N]
+    kx = np.linalg.norm(X - np.maximum(X - red, 0.0))
+    assert kx <= 1e-6 * (1 + out["KKT_xk"][0])
