@@ -119,7 +119,9 @@ static void build_padded(ipd_ctx* ctx, Arena& ar, const Csr& A, int rows_per_lau
     const int nvec = S / 4;
     int L = 4;
     while (L < BT && L * (ROW_U / 4) < nvec) L <<= 1;
-    while (L < BT && (long long)rows_per_launch * L < (long long)cu * BT / 2 && L < nvec) L <<= 1;
+    double fill = 1.0;   // one workgroup per CU (0.5 left half the chip idle on a 1024-row level: 6.16 -> 5.79 us)
+    if (const char* e = std::getenv("IPD_PAD_FILL")) fill = std::atof(e);
+    while (L < BT && (double)rows_per_launch * L < fill * cu * BT && L < nvec) L <<= 1;
     dev->L = L;
     dev->G = pick_blocks(rows_per_launch, L, cu);
 }
