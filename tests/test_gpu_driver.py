@@ -238,3 +238,44 @@ def test_script_entry_points_converge():
                            inner="direct")
     assert out["converged"] and out["k"] == ref["k"]
     assert abs(out["fval"] - ref["fval"]) <= 1e-7
+
+
+def test_driver_argument_errors():
+    """Error behaviour of the workspace API: bad sizes and options fail loudly, with the library's
+    message, and leave the workspace usable."""
+    I = ipd()
+    pr = problem(1, 6, 5)
+    with pytest.raises(ValueError):
+        I.APDWorkspace(1, pr["c"][:-1], pr["r"], pr["l"], pr["p"], pr["q"])          # length(c) != m*n
+    with pytest.raises(ValueError):
+        I.APDWorkspace(2, pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], mu=1.0)       # class 2 needs phi
+    with pytest.raises(ValueError):
+        I.APDWorkspace(1, pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], gama=np.ones(7))
+    ws = ws_of(1, pr)
+    with pytest.raises(ValueError):
+        ws.set_state(u=np.zeros(3))
+    with pytest.raises(I.IpdError, match="bk must be positive"):
+        ws.set_state(bk=0.0)
+    with pytest.raises(I.IpdError, match="ipd_apd_begin must run first"):
+        ws.eval(np.zeros(ws.L))
+    with pytest.raises(I.IpdError, match="bad driver options"):
+        ws.run(dict(retol=1e-11, bigph=1, maxit=30, smoth=5, cycle="w", isnsp=1), I.MatlabRand(5489),
+               delta=1.5)
+    with pytest.raises(I.IpdError, match="res = 0 and maxit = inf"):
+        ws.warmup(0.0, np.inf)
+    # still usable
+    ws.warmup(0.0, 10)
+    out = ws.run(dict(retol=1e-11, bigph=1, maxit=30, theta=0.25, smoth=5, cycle="w", isnsp=1,
+                      inter=1), I.MatlabRand(5489), iters=3)
+    assert out["k"] == 3 and len(ws.history()["fxk"]) == 4
+    ws.close()
+    # p or q containing a zero is the reference's error (Hybrid_AMG.m:19-21)
+    pz = problem(1, 6, 5)
+    pz["p"] = pz["p"].copy()
+    pz["p"][2] = 0.0
+    wz = ws_of(1, pz)
+    wz.warmup(0.0, 5)
+    with pytest.raises(I.IpdError, match="p or q contains 0"):
+        wz.run(dict(retol=1e-11, bigph=1, maxit=30, theta=0.25, smoth=5, cycle="w", isnsp=1,
+                    inter=1), I.MatlabRand(5489), iters=2)
+    wz.close()
