@@ -733,6 +733,8 @@ struct SolveDesc {
     int k_lds;        // levels k_lds..J (and the transfers between them) are cached in LDS
     int k_tiny;       // levels k_tiny..J have <= 32 rows: their whole sub-cycle runs in ONE wave
     int k_blk;        // cached Jacobi levels k_blk..k_tiny-1: one thread per row (blk_cycle)
+    int k_semi;       // 0, or a sub-cycle root whose vectors sit in LDS while its matrix, its
+                      // transfers and its constant vectors are read from global memory (L2)
     // LDS image: this descriptor, a relocation table and the constant arrays of the cached
     // levels are laid out in global memory exactly as they will sit in LDS (behind the staging
     // area); pointers into the image are stored as LDS byte offsets and relocated on arrival
@@ -848,7 +850,23 @@ struct LdsLevel {
     AS3 const double* dP;
     AS3 const double* dPt;
     double xx;
+    // semi-cached level: a 1024-row level does not fit in LDS beside the deeper ones, but its
+    // rows are short (3-7 entries) and L2-resident; only r, e, e2 live in LDS
+    bool semi;
+    const int* grp;
+    const int* gci;
+    const double* gva;
+    const double* gdinv;
+    const double* gAxi;
+    const int* gRrp;
+    const int* gRci;
+    const double* gRva;
+    const int* gPrp;
+    const int* gPci;
+    const double* gPva;
 };
+__device__ __forceinline__ double lvl_dinv(const LdsLevel& L, int i) { return L.semi ? L.gdinv[i] : L.dinv[i]; }
+__device__ __forceinline__ double lvl_axi(const LdsLevel& L, int i) { return L.semi ? L.gAxi[i] : L.Axi[i]; }
 
 __device__ __forceinline__ LdsLevel lds_level(const SolveCtx& c, int k) {
     const AS3 SolveDesc* D = (const AS3 SolveDesc*)c.D;
@@ -876,7 +894,19 @@ __device__ __forceinline__ LdsLevel lds_level(const SolveCtx& c, int k) {
     L.dA = as_lds(G.dA);
     L.dP = as_lds(G.dP);
     L.dPt = as_lds(G.dPt);
-    L.xx = as_lds(G.lv.xx)[0];
+    L.semi = (k == D->k_semi);
+    L.grp = G.lv.rp;
+    L.gci = G.lv.ci;
+    L.gva = G.lv.va;
+    L.gdinv = G.lv.dinv;
+    L.gAxi = G.lv.Axi;
+    L.gRrp = G.rest.rp;
+    L.gRci = G.rest.ci;
+    L.gRva = G.rest.va;
+    L.gPrp = G.prol.rp;
+    L.gPci = G.prol.ci;
+    L.gPva = G.prol.va;
+    L.xx = L.semi ? G.lv.xx[0] : as_lds(G.lv.xx)[0];
     return L;
 }
 __device__ __forceinline__ AS3 double* lds_e(const SolveCtx& c, int k) {
@@ -943,6 +973,60 @@ __device__ __forceinline__ double lds_rowdot_split(AS3 const int* rp, AS3 const 
         for (; t < end; t += Lr) s += va[t] * x[ci[t]];
     }
     return subwave_sum(s, Lr);
+}
+
+// the same walk with the matrix in global memory (semi-cached level); x is in LDS
+__device__ __forceinline__ double glb_rowdot_split(const int* __restrict__ rp,
+                                                   const int* __restrict__ ci,
+                                                   const double* __restrict__ va, int row, int sub,
+                                                   int Lr, bool valid, AS3 const double* x) {
+    double s = 0.0;
+    if (valid) {
+        int t = rp[row] + sub;
+        const int end = rp[row + 1];
+        for (; t + 3 * Lr < end; t += 4 * Lr) {
+            const int c0 = ci[t], c1 = ci[t + Lr], c2 = ci[t + 2 * Lr], c3 = ci[t + 3 * Lr];
+            const double v0 = va[t], v1 = va[t + Lr], v2 = va[t + 2 * Lr], v3 = va[t + 3 * Lr];
+            s += v0 * x[c0];
+            s += v1 * x[c1];
+            s += v2 * x[c2];
+            s += v3 * x[c3];
+        }
+        for (; t < end; t += Lr) s += va[t] * x[ci[t]];
+    }
+    return subwave_sum(s, Lr);
+}
+// A semi-cached level walks its rows thread-per-row; the first SEMI_RC entries of the row stay in
+// registers for all sweeps of a visit (a global round trip per sweep would cost more than the
+// launch the kernel replaces), longer rows read the rest from global memory.
+static constexpr int SEMI_RC = 6;
+struct SemiRow {
+    int c[SEMI_RC];
+    double v[SEMI_RC];
+    int t0, len;
+};
+__device__ __forceinline__ SemiRow semi_row_load(const LdsLevel& L, int row, bool valid) {
+    SemiRow R;
+    R.t0 = valid ? L.grp[row] : 0;
+    R.len = valid ? L.grp[row + 1] - R.t0 : 0;
+#pragma unroll
+    for (int u = 0; u < SEMI_RC; ++u) {
+        const bool in = u < R.len;
+        R.c[u] = in ? L.gci[R.t0 + u] : 0;
+        R.v[u] = in ? L.gva[R.t0 + u] : 0.0;
+    }
+    return R;
+}
+__device__ __forceinline__ double semi_row_dot(const LdsLevel& L, const SemiRow& R,
+                                               AS3 const double* x) {
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < SEMI_RC; ++u) {
+        const double term = R.v[u] * x[R.c[u]];
+        s = (u < R.len) ? s + term : s;
+    }
+    for (int t = R.t0 + SEMI_RC; t < R.t0 + R.len; ++t) s += L.gva[t] * x[L.gci[t]];
+    return s;
 }
 
 // y_i = sum_j M[i + j*rows] * x[j]: ascending j like the sorted CSR walk, and the explicit
@@ -1137,20 +1221,25 @@ __device__ __forceinline__ void blk_publish(double v, AS3 double* part) {
 // cur: index (0/1) of the partial-sum buffer that describes the current iterate
 __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int nu, int isnsp,
                                            int& cur) {
-    const int N = L.N, Lr = lanes_per_row(N);
+    const int N = L.N, Lr = L.semi ? 1 : lanes_per_row(N);
     const int i = threadIdx.x / Lr, sub = threadIdx.x % Lr;
     const bool valid = i < N, owner = valid && sub == 0;
     AS3 double* part = as_lds(c.part);
     const double rv = valid ? L.r[i] : 0.0;
-    const double ax = valid ? L.Axi[i] : 0.0;
-    const double dv = valid ? L.dinv[i] : 0.0;
+    const double ax = valid ? lvl_axi(L, i) : 0.0;
+    const double dv = valid ? lvl_dinv(L, i) : 0.0;
     const double sumr = isnsp ? as_lds(c.sumr)[k] : 0.0;
+    SemiRow R;
+    if (L.semi) R = semi_row_load(L, i, valid);
     for (int s = 0; s < nu; ++s) {
         const bool ez = (c.zeromask >> k) & 1u;
         const double eo = (valid && !ez) ? L.e[i] : 0.0;
         double cc = 0.0;
         if (isnsp) cc = (sumr - (ez ? 0.0 : blk_total(part + 16 * cur))) / L.xx;
-        const double sd = ez ? 0.0 : lds_rowdot_split(L.rp, L.ci, L.va, i, sub, Lr, valid, L.e);
+        double sd = 0.0;
+        if (!ez)
+            sd = L.semi ? semi_row_dot(L, R, L.e)
+                        : lds_rowdot_split(L.rp, L.ci, L.va, i, sub, Lr, valid, L.e);
         const double v = eo + dv * (rv - sd - ax * cc) + cc;
         if (owner) L.e2[i] = v;
         if (isnsp) blk_publish(owner ? ax * v : 0.0, part + 16 * (cur ^ 1));
@@ -1213,7 +1302,7 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
             if (isnsp) {   // 1'r of this visit, and (A1)'e when the visit starts from an iterate
                 const bool ez = (c.zeromask >> k) & 1u;
                 blk_publish(valid ? L.r[i] : 0.0, part + 32);
-                blk_publish((valid && !ez) ? L.Axi[i] * L.e[i] : 0.0, part + 16 * cur);
+                blk_publish((valid && !ez) ? lvl_axi(L, i) * L.e[i] : 0.0, part + 16 * cur);
                 __syncthreads();
                 if (i == 0) as_lds(c.sumr)[k] = blk_total(part + 32);
                 __syncthreads();
@@ -1230,14 +1319,18 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
                 {
                     const int Lr = lanes_per_row(L.N), row = i / Lr, sub = i % Lr;
                     const bool rvld = row < L.N;
-                    const double sd = lds_rowdot_split(L.rp, L.ci, L.va, row, sub, Lr, rvld, L.e);
+                    const double sd =
+                        L.semi ? glb_rowdot_split(L.grp, L.gci, L.gva, row, sub, Lr, rvld, L.e)
+                               : lds_rowdot_split(L.rp, L.ci, L.va, row, sub, Lr, rvld, L.e);
                     if (rvld && sub == 0) L.e2[row] = L.r[row] - sd;   // e2 is free between the sweeps
                 }
                 __syncthreads();
                 {
                     const int Lr = lanes_per_row(L.Nc), row = i / Lr, sub = i % Lr;
                     const bool cv = row < L.Nc;
-                    const double rc = lds_rowdot_split(L.Rrp, L.Rci, L.Rva, row, sub, Lr, cv, L.e2);
+                    const double rc =
+                        L.semi ? glb_rowdot_split(L.gRrp, L.gRci, L.gRva, row, sub, Lr, cv, L.e2)
+                               : lds_rowdot_split(L.Rrp, L.Rci, L.Rva, row, sub, Lr, cv, L.e2);
                     if (cv && sub == 0) L.rc[row] = rc;
                 }
                 __syncthreads();
@@ -1260,14 +1353,16 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
             {
                 const int Lr = lanes_per_row(L.N), row = i / Lr, sub = i % Lr;
                 const bool own = row < L.N && sub == 0;
-                const double sd = lds_rowdot_split(L.Prp, L.Pci, L.Pva, row, sub, Lr, row < L.N,
-                                                   lds_e(c, k + 1));
+                AS3 const double* ec = lds_e(c, k + 1);
+                const double sd =
+                    L.semi ? glb_rowdot_split(L.gPrp, L.gPci, L.gPva, row, sub, Lr, row < L.N, ec)
+                           : lds_rowdot_split(L.Prp, L.Pci, L.Pva, row, sub, Lr, row < L.N, ec);
                 double v = 0.0;
                 if (own) {
                     v = L.e[row] + sd;
                     L.e[row] = v;
                 }
-                if (isnsp) blk_publish(own ? L.Axi[row] * v : 0.0, part + 16 * cur);
+                if (isnsp) blk_publish(own ? lvl_axi(L, row) * v : 0.0, part + 16 * cur);
                 __syncthreads();
             }
             SOL_DBG_ADD(c, 7);

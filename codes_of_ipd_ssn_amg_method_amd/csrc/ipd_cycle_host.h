@@ -378,6 +378,7 @@ void amg_prepare_levels(ipd_amg* h) {
         for (int k = k_from; k <= h->J; ++k) {     // constants first: they form the image
             SolveLevel& T = sd->L[k];
             const size_t N = (size_t)T.lv.N;
+            if (k == sd->k_semi) continue;         // matrix, transfers, dinv, Axi stay in global memory
             put(T.lv.rp, N + 1);
             put(T.lv.ci, (size_t)T.nnzA);
             put(T.lv.va, (size_t)T.nnzA);
@@ -520,7 +521,42 @@ void amg_prepare_levels(ipd_amg* h) {
         const char* ns = std::getenv("IPD_NO_SUBCYCLE");
         const bool want = !(ns && ns[0] == '1') && !st->small_ok && h->J <= SOLVE_ML && h->J >= 3 &&
                           (h->opts.cycle == 'w' || h->opts.cycle == 'v');
-        if (want) {
+        bool semi_done = false;
+        {   // (b1) root at level 2 with only r, e, e2 in LDS; levels 3..J fully cached
+            const char* nse = std::getenv("IPD_NO_SEMI");
+            bool ok = want && lean_vectors && !(nse && nse[0] == '1') && h->L[2].A.nr <= BT &&
+                      h->L[2].A.nr > 64 && (double)h->L[2].A.nnz <= 12.0 * h->L[2].A.nr &&
+                      (double)h->L[3].P.nnz <= 12.0 * h->L[2].A.nr;
+            for (int k = 3; k <= h->J && ok; ++k) ok = small_level(k);
+            if (ok) {
+                const size_t stage = 16;
+                size_t used = 0;
+                const int k_lds = plan_lds(stage, &used);     // which levels fit fully cached
+                const size_t n2 = (size_t)h->L[2].A.nr;
+                // plan_lds may stop anywhere: levels 3..J must all be in, plus level 2's 3 vectors
+                size_t need = used + 3 * r16(8 * n2);
+                if (k_lds <= 2) {   // level 2 itself fitted fully: nothing to gain from "semi"
+                    ok = false;
+                } else if (k_lds > 3 || need > 150 * 1024) {
+                    ok = false;
+                }
+                if (ok) {
+                    std::unique_ptr<SolveDesc> sd(new SolveDesc());
+                    fill_desc(sd.get());
+                    sd->k_lds = 2;
+                    sd->k_semi = 2;
+                    sd->k_tiny = tiny_from(3);
+                    sd->k_blk = blk_from(2);
+                    sd->stage_bytes = (int)stage;
+                    sd->root_r = h->L[2].r;
+                    sd->root_e = h->L[2].e;
+                    st->k_sub = 2;
+                    st->d_sub = build_image(sd.get(), 2, stage, &st->sub_lds);
+                    semi_done = true;
+                }
+            }
+        }
+        if (want && !semi_done) {
             // first level from which every level is small ...
             int k_small = h->J + 1;
             for (int k = h->J; k >= 2 && small_level(k); --k) k_small = k;
