@@ -953,24 +953,26 @@ __device__ __forceinline__ int lanes_per_row(int rows) {
     while (L < 16 && rows * (L * 2) <= BT) L <<= 1;
     return L;
 }
-// every lane of the group returns the full sum
+// every lane of the group returns the full sum.  Entries go four at a time with the last batch
+// masked instead of a one-by-one remainder loop: most rows of these levels hold fewer than
+// 4*Lr entries, and the remainder loop paid two dependent LDS round trips per entry.
 __device__ __forceinline__ double lds_rowdot_split(AS3 const int* rp, AS3 const int* ci,
                                                    AS3 const double* va, int row, int sub, int Lr,
                                                    bool valid, AS3 const double* x) {
     double s = 0.0;
     if (valid) {
-        int t = rp[row] + sub;
-        const int end = rp[row + 1];
-        for (; t + 3 * Lr < end; t += 4 * Lr) {
-            const int c0 = ci[t], c1 = ci[t + Lr], c2 = ci[t + 2 * Lr], c3 = ci[t + 3 * Lr];
-            const double v0 = va[t], v1 = va[t + Lr], v2 = va[t + 2 * Lr], v3 = va[t + 3 * Lr];
+        const int beg = rp[row], end = rp[row + 1];
+        for (int t = beg + sub; t < end; t += 4 * Lr) {
+            const int t1 = t + Lr, t2 = t + 2 * Lr, t3 = t + 3 * Lr;
+            const bool k1 = t1 < end, k2 = t2 < end, k3 = t3 < end;
+            const int c0 = ci[t], c1 = ci[k1 ? t1 : t], c2 = ci[k2 ? t2 : t], c3 = ci[k3 ? t3 : t];
+            const double v0 = va[t], v1 = va[k1 ? t1 : t], v2 = va[k2 ? t2 : t], v3 = va[k3 ? t3 : t];
             const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
             s += v0 * x0;
-            s += v1 * x1;
-            s += v2 * x2;
-            s += v3 * x3;
+            if (k1) s += v1 * x1;
+            if (k2) s += v2 * x2;
+            if (k3) s += v3 * x3;
         }
-        for (; t < end; t += Lr) s += va[t] * x[ci[t]];
     }
     return subwave_sum(s, Lr);
 }
@@ -982,17 +984,17 @@ __device__ __forceinline__ double glb_rowdot_split(const int* __restrict__ rp,
                                                    int Lr, bool valid, AS3 const double* x) {
     double s = 0.0;
     if (valid) {
-        int t = rp[row] + sub;
-        const int end = rp[row + 1];
-        for (; t + 3 * Lr < end; t += 4 * Lr) {
-            const int c0 = ci[t], c1 = ci[t + Lr], c2 = ci[t + 2 * Lr], c3 = ci[t + 3 * Lr];
-            const double v0 = va[t], v1 = va[t + Lr], v2 = va[t + 2 * Lr], v3 = va[t + 3 * Lr];
+        const int beg = rp[row], end = rp[row + 1];
+        for (int t = beg + sub; t < end; t += 4 * Lr) {
+            const int t1 = t + Lr, t2 = t + 2 * Lr, t3 = t + 3 * Lr;
+            const bool k1 = t1 < end, k2 = t2 < end, k3 = t3 < end;
+            const int c0 = ci[t], c1 = ci[k1 ? t1 : t], c2 = ci[k2 ? t2 : t], c3 = ci[k3 ? t3 : t];
+            const double v0 = va[t], v1 = va[k1 ? t1 : t], v2 = va[k2 ? t2 : t], v3 = va[k3 ? t3 : t];
             s += v0 * x[c0];
-            s += v1 * x[c1];
-            s += v2 * x[c2];
-            s += v3 * x[c3];
+            if (k1) s += v1 * x[c1];
+            if (k2) s += v2 * x[c2];
+            if (k3) s += v3 * x[c3];
         }
-        for (; t < end; t += Lr) s += va[t] * x[ci[t]];
     }
     return subwave_sum(s, Lr);
 }
@@ -1233,17 +1235,28 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
     if (L.semi) R = semi_row_load(L, i, valid);
     for (int s = 0; s < nu; ++s) {
         const bool ez = (c.zeromask >> k) & 1u;
+        const long long q0 = c.dbg ? wall_clock64() : 0;
         const double eo = (valid && !ez) ? L.e[i] : 0.0;
         double cc = 0.0;
         if (isnsp) cc = (sumr - (ez ? 0.0 : blk_total(part + 16 * cur))) / L.xx;
+        const long long q1 = c.dbg ? wall_clock64() : 0;
         double sd = 0.0;
         if (!ez)
             sd = L.semi ? semi_row_dot(L, R, L.e)
                         : lds_rowdot_split(L.rp, L.ci, L.va, i, sub, Lr, valid, L.e);
         const double v = eo + dv * (rv - sd - ax * cc) + cc;
         if (owner) L.e2[i] = v;
+        const long long q2 = c.dbg ? wall_clock64() : 0;
         if (isnsp) blk_publish(owner ? ax * v : 0.0, part + 16 * (cur ^ 1));
+        const long long q3 = c.dbg ? wall_clock64() : 0;
         __syncthreads();
+        if (c.dbg && threadIdx.x == 0) {
+            c.dbg[9] += q1 - q0;
+            c.dbg[10] += q2 - q1;
+            c.dbg[11] += q3 - q2;
+            c.dbg[12] += wall_clock64() - q3;
+            c.dbg[13] += 1;
+        }
         cur ^= 1;
         AS3 double* t = L.e;
         L.e = L.e2;
@@ -1667,7 +1680,7 @@ __global__ __launch_bounds__(BT) void k_subcycle(const SolveDesc* __restrict__ D
     c.dbg = dbg;
     if (dbg && threadIdx.x == 0) {
         dbg[4] = dbg[5] = dbg[6] = dbg[7] = 0;
-        dbg[9] = dbg[10] = dbg[11] = dbg[12] = 0;
+        dbg[9] = dbg[10] = dbg[11] = dbg[12] = dbg[13] = 0;
         dbg[2] = wall_clock64();
         dbg[8] = clock64();
     }

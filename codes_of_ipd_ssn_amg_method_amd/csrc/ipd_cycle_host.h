@@ -1363,8 +1363,8 @@ extern "C" int ipd_amg_bench_subcycle(ipd_amg* h, int reps, double* total_ms, in
         if (stamps)
             for (int i = 0; i < 8; ++i) stamps[i] = hs[i];
         if (const char* e = std::getenv("IPD_DEBUG_SWEEP"); e && e[0] == '1')
-            std::fprintf(stderr, "[ipd] blk sweep parts (us): total+div %.2f rowdot %.2f publish %.2f barrier %.2f\n",
-                         hs[9] / 100.0, hs[10] / 100.0, hs[11] / 100.0, hs[12] / 100.0);
+            std::fprintf(stderr, "[ipd] %lld blk sweeps, parts (us): total+div %.2f rowdot %.2f publish %.2f barrier %.2f\n",
+                         hs[13], hs[9] / 100.0, hs[10] / 100.0, hs[11] / 100.0, hs[12] / 100.0);
         long long* none = nullptr;
         ctx->upload_bytes(reinterpret_cast<char*>(st->d_sub) + off, &none, sizeof(none));
     });
