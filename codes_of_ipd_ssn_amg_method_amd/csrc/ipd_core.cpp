@@ -166,8 +166,23 @@ extern "C" int ipd_ctx_create(int device, ipd_ctx** out) {
     });
 }
 
+// lazily created companion context (same device, own stream/arenas/pinned buffer)
+ipd_ctx* ipd_ctx_aux(ipd_ctx* ctx) {
+    if (!ctx->aux) {
+        ipd_ctx* a = nullptr;
+        const int rc = ipd_ctx_create(ctx->device, &a);
+        if (rc != IPD_OK) throw IpdError(rc, "cannot create the auxiliary context");
+        ctx->aux = a;
+    }
+    return ctx->aux;
+}
+
 extern "C" void ipd_ctx_destroy(ipd_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->aux) {
+        ipd_ctx_destroy(ctx->aux);
+        ctx->aux = nullptr;
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ipd_comm_cleanup(ctx);

@@ -9,6 +9,9 @@
 // labels into blocks/sizes/p/r and routes components is host logic.
 #pragma clang fp contract(off)
 
+#include <functional>
+#include <thread>
+
 #include "ipd_amg_internal.h"
 
 #include <algorithm>
@@ -390,10 +393,15 @@ struct HybridCache {
     size_t next = 0;
 };
 
-static void class_amg_on(ipd_ctx* ctx, const Csr& A, const double* f, AmgOpts o, int isnsp,
-                         long long fnode, double gscale, ipd_rng* rng, double* u_out, int* it,
-                         double* rel_res, const MaskHint& mh = MaskHint(),
-                         HybridCache* cache = nullptr) {
+// Work postponed to the solve phase of a Hybrid_AMG call: AMG4POT's two calls set their
+// hierarchies up one after the other (that keeps the order in which the reference consumes
+// rand) and then run their solve phases concurrently on two streams.
+using Deferred = std::vector<std::function<void()>>;
+
+// Guess + setup now (consumes rand); returns the solve phase, which fills *it / *rel_res.
+static std::function<void(int*, double*)> class_amg_prepare(
+    ipd_ctx* ctx, const Csr& A, const double* f, AmgOpts o, int isnsp, long long fnode, double gscale,
+    ipd_rng* rng, double* u_out, const MaskHint& mh = MaskHint(), HybridCache* cache = nullptr) {
     const int N = A.nr;
     o.isnsp = isnsp;
     o.fnode = fnode;
@@ -402,31 +410,36 @@ static void class_amg_on(ipd_ctx* ctx, const Csr& A, const double* f, AmgOpts o,
     for (double& v : g) v = gscale * v;
     double* dg = ctx->scratch->alloc<double>((size_t)N);
     ctx->upload(dg, g.data(), (size_t)N);
-    std::unique_ptr<ipd_amg, void (*)(ipd_amg*)> own(nullptr, ipd_amg_destroy);
+    std::shared_ptr<ipd_amg> own;
     ipd_amg* h = nullptr;
     if (cache && cache->valid && cache->next < cache->hier.size()) {
         h = cache->hier[cache->next++].get();          // second right-hand side: same operator
     } else {
         ProfScope ps(ctx, PROF_AMG_SETUP);
-        own.reset(amg_setup(ctx, A, o, rng));
-        h = own.get();
+        std::unique_ptr<ipd_amg, void (*)(ipd_amg*)> fresh(amg_setup(ctx, A, o, rng), ipd_amg_destroy);
+        h = fresh.get();
         if (mh.p && o.bigph) amg_attach_maskop(h, mh.p, mh.q, mh.m, mh.n, mh.tk);
-        if (cache) cache->hier.push_back(std::move(own));
+        if (cache)
+            cache->hier.push_back(std::move(fresh));
+        else
+            own = std::shared_ptr<ipd_amg>(fresh.release(), ipd_amg_destroy);
     }
-    int32_t its = 0;
-    double rr = 0.0;
-    {
-        ProfScope ps(ctx, PROF_AMG_SOLVE);
-        amg_solve_dev(h, f, dg, u_out, &its, &rr, nullptr, nullptr);
-    }
-    *it = its;
-    *rel_res = rr;
+    return [ctx, h, own, f, dg, u_out](int* it, double* rel_res) {
+        int32_t its = 0;
+        double rr = 0.0;
+        {
+            ProfScope ps(ctx, PROF_AMG_SOLVE);
+            amg_solve_dev(h, f, dg, u_out, &its, &rr, nullptr, nullptr);
+        }
+        *it = its;
+        *rel_res = rr;
+    };
 }
 
 static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
                               const double* q, int m, int n, double bk1, double tk, const double* z,
                               const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out,
-                              HybridCache* cache);
+                              HybridCache* cache, Deferred* later = nullptr);
 
 void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
                     const double* q, int m, int n, double bk1, double tk, const double* z,
@@ -437,8 +450,14 @@ void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const doub
 static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
                               const double* q, int m, int n, double bk1, double tk, const double* z,
                               const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out,
-                              HybridCache* cache) {
+                              HybridCache* cache, Deferred* later) {
     IPD_REQUIRE(rng, IPD_E_ARG, "Hybrid_AMG needs a rand stream");
+    auto defer = [&](std::function<void()> fn) {   // run now, or in the caller's solve phase
+        if (later)
+            later->push_back(std::move(fn));
+        else
+            fn();
+    };
     IPD_REQUIRE(tk != 0.0, IPD_E_ARG, "tk must be nonzero");
     const int M = m + n;
     const int N0 = 100;                                                   // Hybrid_AMG.m:51
@@ -486,28 +505,31 @@ static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, 
     const double gscale = bk1 * tk;
     if (cc.ncomp == 1) {                                                  // :30-48
         const int isnsp = sum_dk(nullptr, M) != 0.0 ? 0 : 1;
-        int it = 0;
-        double rr = 0.0;
         MaskHint mh;
         mh.p = p;
         mh.q = q;
         mh.m = m;
         mh.n = n;
         mh.tk = tk;
-        class_amg_on(ctx, Ae, f, opts, isnsp, n, gscale, rng, u, &it, &rr, mh, cache);
-        out->itamg = it;
-        out->resamg = rr;
-        out->it_num = 1;
+        auto run = class_amg_prepare(ctx, Ae, f, opts, isnsp, n, gscale, rng, u, mh, cache);
+        defer([run, out] {
+            int it = 0;
+            double rr = 0.0;
+            run(&it, &rr);
+            out->itamg = it;
+            out->resamg = rr;
+            out->it_num = 1;
+        });
     } else {                                                              // :50-107
         out->itamg = 0;
         out->resamg = 0.0;
         out->it_num = 0;
         std::vector<int> newidx((size_t)M);
-        int* d_pk = tmp.alloc<int>((size_t)M);
         int* d_new = tmp.alloc<int>((size_t)M);
         for (int k = 0; k < cc.ncomp; ++k) {                              // :55 large components
             if (cc.sizes[k] <= N0) continue;
             const int nk = cc.sizes[k];
+            int* d_pk = tmp.alloc<int>((size_t)nk);   // per component: the scatter may run later
             const int* pk = cc.p.data() + cc.r[k];  // ascending: F side first (quirk A-9)
             std::fill(newidx.begin(), newidx.end(), -1);
             int fnode = 0;
@@ -538,15 +560,18 @@ static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, 
             const int isnsp = sum_dk(pk, nk) != 0.0 ? 0 : 1;              // :60-66
             IPD_REQUIRE(fnode > 0 && fnode < nk, IPD_E_NUMERIC,
                         "Hybrid_AMG: a large component lies on one side of the bigraph");
-            int it = 0;
-            double rr = 0.0;
-            class_amg_on(ctx, Ak, fk, opts, isnsp, fnode, gscale, rng, dk, &it, &rr, MaskHint(), cache);
-            hipLaunchKernelGGL(k_scatter, dim3(elems_grid(nk)), dim3(256), 0, ctx->stream, nk, d_pk,
-                               dk, u);                                    // :77 u(pk) = dk
-            IPD_KERNEL_CHECK();
-            out->itamg = std::max(out->itamg, it);
-            out->resamg = std::max(out->resamg, rr);
-            out->it_num = k + 1;                                          // :80 (1-based)
+            auto run = class_amg_prepare(ctx, Ak, fk, opts, isnsp, fnode, gscale, rng, dk, MaskHint(), cache);
+            defer([run, out, ctx, nk, d_pk, dk, u, k] {
+                int it = 0;
+                double rr = 0.0;
+                run(&it, &rr);
+                hipLaunchKernelGGL(k_scatter, dim3(elems_grid(nk)), dim3(256), 0, ctx->stream, nk,
+                                   (const int*)d_pk, (const double*)dk, u);  // :77 u(pk) = dk
+                IPD_KERNEL_CHECK();
+                out->itamg = std::max(out->itamg, it);
+                out->resamg = std::max(out->resamg, rr);
+                out->it_num = k + 1;                                      // :80 (1-based)
+            });
         }
         // small components, all together                                   :85-91
         std::vector<int> nodes, boff(1, 0), local((size_t)M, 0);
@@ -585,9 +610,11 @@ static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, 
                         "Hybrid_AMG: a small diagonal block is not positive definite");
         }
     }
-    hipLaunchKernelGGL(k_scale_qp, dim3(g), dim3(256), 0, ctx->stream, M, n, p, q,
-                       (const double*)u, zeta);                           // :113 zeta = Q0*u
-    IPD_KERNEL_CHECK();
+    defer([ctx, g, M, n, p, q, u, zeta] {
+        hipLaunchKernelGGL(k_scale_qp, dim3(g), dim3(256), 0, ctx->stream, M, n, p, q,
+                           (const double*)u, zeta);                       // :113 zeta = Q0*u
+        IPD_KERNEL_CHECK();
+    });
     if (cache) cache->valid = true;
 }
 
@@ -675,13 +702,61 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
                  double* zeta, HybridOut* out) {
     const char* re = getenv("IPD_REUSE_HIERARCHY");
     const bool reuse_env = re && re[0] == '1';
+    const char* nc = getenv("IPD_NO_POT_CONCURRENT");
+    const bool concurrent = !reuse_env && !(nc && nc[0] == '1');
     HybridCache cache;
+    if (!concurrent) {
+        auto solve = [&](const double* rhs, double* x, HybridOut* o) {
+            hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o,
+                              reuse_env ? &cache : nullptr);
+        };
+        pot_reduce(ctx, H0, p, q, m, n, bk1, tk, z, s, phi, zeta, out, solve);
+        ctx->sync();   // the cached hierarchies are released on return
+        return;
+    }
+    // The two systems Ae*vv = v and Ae*ww = w are independent (Class2/AMG4POT.m:46-47).  Their
+    // guesses and hierarchies are drawn/built one after the other -- the rand stream is consumed
+    // in the reference's order -- and their solve phases then run at the same time on two
+    // streams: each is a chain of latency-bound launches that leaves the device mostly idle.
+    ipd_ctx* aux = ipd_ctx_aux(ctx);
+    Deferred first, second;
+    bool have_first = false;
     auto solve = [&](const double* rhs, double* x, HybridOut* o) {
-        hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o,
-                          reuse_env ? &cache : nullptr);
+        if (!have_first) {
+            hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o, nullptr, &first);
+            have_first = true;
+            return;
+        }
+        ctx->sync();   // rhs, H0, ... were produced on ctx's stream
+        // (Letting the second setup overlap with the first solve phase as well was measured: no
+        // gain -- the setup is bound by its host round trips -- so both setups stay on this
+        // thread and only the solve phases, which consume no random numbers, run concurrently.)
+        CallScope aux_scope(aux);
+        hybrid_amg_cached(aux, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o, nullptr, &second);
+        std::exception_ptr err;
+        std::thread other([&] {
+            try {
+                aux->set_device();
+                for (auto& fn : second) fn();
+                aux->sync();
+            } catch (...) {
+                err = std::current_exception();
+            }
+        });
+        std::exception_ptr err0;
+        try {
+            for (auto& fn : first) fn();
+            ctx->sync();
+        } catch (...) {
+            err0 = std::current_exception();
+        }
+        other.join();
+        first.clear();    // releases the hierarchies
+        second.clear();
+        if (err0) std::rethrow_exception(err0);
+        if (err) std::rethrow_exception(err);
     };
     pot_reduce(ctx, H0, p, q, m, n, bk1, tk, z, s, phi, zeta, out, solve);
-    ctx->sync();   // the cached hierarchies are released on return
 }
 
 // ---------------------------------------------------------------------------

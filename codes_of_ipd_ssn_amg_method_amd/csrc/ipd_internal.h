@@ -140,6 +140,7 @@ struct ipd_ctx {
     size_t pinned_bytes = 0;
     int num_cu = 256;
     RcclState* comm = nullptr;
+    ipd_ctx* aux = nullptr;   // second stream/arena for work that overlaps with this context's
 
     // read back `n` elements synchronously through the pinned staging buffer
     template <class T>
@@ -174,6 +175,8 @@ struct CallScope {
         ctx->scratch->off = off;
     }
 };
+
+ipd_ctx* ipd_ctx_aux(ipd_ctx* ctx);   // ipd_core.cpp
 
 // ipd_dist.cpp: RCCL communicator of the context (one rank per GPU)
 void ipd_comm_cleanup(ipd_ctx* ctx);
