@@ -53,7 +53,7 @@ def warmup_class1(c, r, l, p, q, gama, maxit=100):
 
 
 def apd_ssn_class1(c, r, l, p, q, gama, capture=(), inner="direct", maxit=100, rng=None,
-                   amg_cycle="w", verbose=False, start=None, prob=2):
+                   amg_cycle="w", verbose=False, start=None, prob=2, bk0=1.0, vk0=None):
     """`APD_SsN_Class1.m:30-275`.  `capture` = iterable of (k, ssn_it) pairs (1-based) whose
     Newton systems are recorded as dicts(s, bk1, tk, z, k, ssn).  inner = "direct"
     (inner_solver 1, `:146-148`) or "amg" (inner_solver 4, `:160-161`, oracle Hybrid_AMG)."""
@@ -64,7 +64,8 @@ def apd_ssn_class1(c, r, l, p, q, gama, capture=(), inner="direct", maxit=100, r
     KKT_Tol, bk = 1e-6, 1.0
     SsN_IT, SsN_Tol1, nu, delta, ll_max = 50, 1e-11, 0.2, 0.9, 500
     xk, lk = start if start is not None else warmup_class1(c, r, l, p, q, gama, 100)
-    vk = xk.copy()
+    vk = xk.copy() if vk0 is None else np.asarray(vk0, float).copy()
+    bk = bk0
     hist = dict(fxk=[float(c @ xk)], KKT_xk=[], KKT_lk=[], SsN_itnum=[])
     kkt_l0 = np.linalg.norm(O.Ax(xk, p, q) - b)
     kkt_x0 = np.linalg.norm(xk - prox(xk - c - O.Aty(lk, p, q)))
@@ -152,7 +153,7 @@ def apd_ssn_class1(c, r, l, p, q, gama, capture=(), inner="direct", maxit=100, r
             return dict(converged=True, k=k, fval=float(c @ xk), captured=captured, log=log,
                         xk=xk, lk=lk, bk=bk, **hist)
     return dict(converged=False, k=maxit, fval=float(c @ xk), captured=captured, log=log,
-                xk=xk, lk=lk, bk=bk, **hist)
+                xk=xk, lk=lk, bk=bk, vk=vk, **hist)
 
 
 # ---------------------------------------------------------------------------

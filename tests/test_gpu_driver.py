@@ -279,3 +279,28 @@ def test_driver_argument_errors():
         wz.run(dict(retol=1e-11, bigph=1, maxit=30, theta=0.25, smoth=5, cycle="w", isnsp=1,
                     inter=1), I.MatlabRand(5489), iters=2)
     wz.close()
+
+
+def test_restart_rule_matches_oracle():
+    """`APD_SsN_Class1.m:245-249`: bk1 < 1e-8 and a worse iterate -> xk1 = xk, lk1 = lk, vk1 = xk,
+    bk1 = rand.  The rand value proves that the device path consumed exactly as many random
+    numbers (guesses, mis_set) as the restatement before it."""
+    pr = problem(1, 20, 18, seed=3)
+    base = D.apd_ssn_class1(pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], np.inf, inner="amg",
+                            rng=O.matlab_rng())
+    xs, ls = base["xk"], base["lk"]
+    v0 = xs + 0.5 * np.random.RandomState(5).standard_normal(xs.size)
+    ref = D.apd_ssn_class1(pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], np.inf, inner="amg",
+                           start=(xs, ls), rng=O.matlab_rng(), maxit=1, bk0=1e-9, vk0=v0)
+    assert np.array_equal(ref["xk"], xs) and ref["bk"] > 1e-3      # the oracle did restart
+    ws = ws_of(1, pr)
+    ws.set_state(xs, v0, ls, 1e-9)
+    out = ws.run(dict(retol=1e-11, bigph=1, maxit=30, theta=1 / 4, smoth=5, cycle="w", isnsp=1,
+                      inter=1), ipd().MatlabRand(5489), iters=1)
+    u, v, lam, bk = ws.state()
+    assert out["restarts"] == 1 and out["k"] == 1
+    assert np.array_equal(u, xs) and np.array_equal(v, xs) and np.array_equal(lam, ls)
+    assert bk == ref["bk"]
+    hist = ws.history()
+    assert abs(hist["KKT_xk"][1] - ref["KKT_xk"][1]) <= 1e-12 * (1 + ref["KKT_xk"][1])
+    ws.close()
