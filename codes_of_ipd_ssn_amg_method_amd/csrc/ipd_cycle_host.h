@@ -480,7 +480,51 @@ void amg_prepare_levels(ipd_amg* h) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr_set = true;
     }
+    // Level 2 as a semi-cached level (r, e, e2 in LDS; matrix rows from L2) with levels 3..J fully
+    // cached: returns the dynamic LDS needed behind a staging area of `stage` bytes, 0 = no
+    auto semi_plan = [&](size_t stage) -> size_t {
+        const char* nse = std::getenv("IPD_NO_SEMI");
+        if ((nse && nse[0] == '1') || !lean_vectors || h->J < 3 || h->J > SOLVE_ML) return 0;
+        const Level& l2 = h->L[2];
+        if (l2.A.nr > BT || l2.A.nr <= 64 || (double)l2.A.nnz > 12.0 * l2.A.nr ||
+            (double)h->L[3].P.nnz > 12.0 * l2.A.nr)
+            return 0;
+        for (int k = 3; k <= h->J; ++k)
+            if (!small_level(k)) return 0;
+        size_t used = 0;
+        const int k_lds = plan_lds(stage, &used);
+        if (k_lds != 3) return 0;   // <= 2: level 2 fits entirely; > 3: a deeper level does not
+        const size_t need = used + 3 * r16(8 * (size_t)l2.A.nr);
+        return need <= 150 * 1024 ? need : 0;
+    };
+    // (a') whole solve in one workgroup for a 2048-row system: level 1 through the generic
+    // phases (global memory), level 2 semi-cached, the rest out of LDS.  Opt-in
+    // (IPD_WHOLE_SEMI=1): measured 1.86 s against 1.82 s for multi-launch level 1 + sub-cycle on
+    // the m=n=1024 Class 1 run -- level 1's 25 phases per cycle cost one workgroup what they cost
+    // as launches.
     {
+        const char* ns = std::getenv("IPD_NO_SMALL");
+        const char* nw = std::getenv("IPD_WHOLE_SEMI");
+        const Level& l1 = h->L[1];
+        const size_t stage = r16(sizeof(double) * (size_t)l1.A.nr);
+        const bool cyc = h->opts.cycle == 'w' || h->opts.cycle == 'v';
+        if (!(ns && ns[0] == '1') && (nw && nw[0] == '1') && cyc && l1.A.nr > 1024 &&
+            l1.A.nr <= 2048 && l1.A.nnz <= 40000 && h->L.size() > 2 && h->L[2].P.nnz <= 40000 &&
+            semi_plan(stage) != 0) {
+            std::unique_ptr<SolveDesc> sd(new SolveDesc());
+            fill_desc(sd.get());
+            sd->k_lds = 2;
+            sd->k_semi = 2;
+            sd->k_tiny = tiny_from(3);
+            sd->k_blk = blk_from(2);
+            sd->stage_bytes = (int)stage;
+            st->solve_cached = true;
+            st->d_solve = build_image(sd.get(), 2, stage, &st->solve_lds);
+            st->solve_out = ar.alloc<double>(4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2));
+            st->small_ok = true;
+        }
+    }
+    if (!st->small_ok) {
         const char* ns = std::getenv("IPD_NO_SMALL");
         bool ok = !(ns && ns[0] == '1') && h->J <= SOLVE_ML;
         size_t maxlen = 1;
@@ -522,39 +566,20 @@ void amg_prepare_levels(ipd_amg* h) {
         const bool want = !(ns && ns[0] == '1') && !st->small_ok && h->J <= SOLVE_ML && h->J >= 3 &&
                           (h->opts.cycle == 'w' || h->opts.cycle == 'v');
         bool semi_done = false;
-        {   // (b1) root at level 2 with only r, e, e2 in LDS; levels 3..J fully cached
-            const char* nse = std::getenv("IPD_NO_SEMI");
-            bool ok = want && lean_vectors && !(nse && nse[0] == '1') && h->L[2].A.nr <= BT &&
-                      h->L[2].A.nr > 64 && (double)h->L[2].A.nnz <= 12.0 * h->L[2].A.nr &&
-                      (double)h->L[3].P.nnz <= 12.0 * h->L[2].A.nr;
-            for (int k = 3; k <= h->J && ok; ++k) ok = small_level(k);
-            if (ok) {
-                const size_t stage = 16;
-                size_t used = 0;
-                const int k_lds = plan_lds(stage, &used);     // which levels fit fully cached
-                const size_t n2 = (size_t)h->L[2].A.nr;
-                // plan_lds may stop anywhere: levels 3..J must all be in, plus level 2's 3 vectors
-                size_t need = used + 3 * r16(8 * n2);
-                if (k_lds <= 2) {   // level 2 itself fitted fully: nothing to gain from "semi"
-                    ok = false;
-                } else if (k_lds > 3 || need > 150 * 1024) {
-                    ok = false;
-                }
-                if (ok) {
-                    std::unique_ptr<SolveDesc> sd(new SolveDesc());
-                    fill_desc(sd.get());
-                    sd->k_lds = 2;
-                    sd->k_semi = 2;
-                    sd->k_tiny = tiny_from(3);
-                    sd->k_blk = blk_from(2);
-                    sd->stage_bytes = (int)stage;
-                    sd->root_r = h->L[2].r;
-                    sd->root_e = h->L[2].e;
-                    st->k_sub = 2;
-                    st->d_sub = build_image(sd.get(), 2, stage, &st->sub_lds);
-                    semi_done = true;
-                }
-            }
+        if (want && semi_plan(16) != 0) {   // (b1) the sub-cycle is rooted at the semi-cached level 2
+            const size_t stage = 16;
+            std::unique_ptr<SolveDesc> sd(new SolveDesc());
+            fill_desc(sd.get());
+            sd->k_lds = 2;
+            sd->k_semi = 2;
+            sd->k_tiny = tiny_from(3);
+            sd->k_blk = blk_from(2);
+            sd->stage_bytes = (int)stage;
+            sd->root_r = h->L[2].r;
+            sd->root_e = h->L[2].e;
+            st->k_sub = 2;
+            st->d_sub = build_image(sd.get(), 2, stage, &st->sub_lds);
+            semi_done = true;
         }
         if (want && !semi_done) {
             // first level from which every level is small ...
