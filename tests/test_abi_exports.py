@@ -54,3 +54,21 @@ def test_rng_matches_matlab_stream():
     assert list(rp.rand(2)) == [0.25, 0.5]
     with pytest.raises(Exception):
         rp.rand(1)
+
+
+def test_header_is_plain_c_and_links_from_gcc(tmp_path):
+    """The boundary is a C ABI: include/ipd_amg.h must compile as C11 with gcc (no C++, no HIP
+    types) and a plain-C program must link against libipdamg.so (examples/class1_demo.c)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "codes_of_ipd_ssn_amg_method_amd")
+    if shutil.which("gcc") is None or not os.path.exists(os.path.join(lib_dir, "libipdamg.so")):
+        import pytest
+        pytest.skip("gcc or libipdamg.so not available")
+    out = tmp_path / "demo"
+    cmd = ["gcc", "-O1", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+           os.path.join(root, "examples", "class1_demo.c"), "-o", str(out), "-L", lib_dir,
+           "-lipdamg", "-lm", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr

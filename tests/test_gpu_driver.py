@@ -304,3 +304,21 @@ def test_restart_rule_matches_oracle():
     hist = ws.history()
     assert abs(hist["KKT_xk"][1] - ref["KKT_xk"][1]) <= 1e-12 * (1 + ref["KKT_xk"][1])
     ws.close()
+
+
+def test_plain_c_consumer_of_the_abi():
+    """examples/class1_demo.c: the whole Class 1 solve through the C ABI from a gcc-built program."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "class1_demo")
+    if not os.path.exists(exe):
+        res = subprocess.run(["make", "-C", os.path.join(root, "codes_of_ipd_ssn_amg_method_amd", "csrc"),
+                              "example"], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+    res = subprocess.run([exe, "96"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    fields = dict(tok.split("=") for tok in res.stdout.split() if "=" in tok)
+    assert fields["converged"] == "1" and int(fields["k"]) <= 100
+    assert float(fields["rr"]) <= 1e-6 and float(fields["feas"]) <= 1e-5 and float(fields["xmin"]) >= 0.0
+    assert int(fields["FailAMG"]) == 0
