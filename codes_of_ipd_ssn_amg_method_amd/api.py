@@ -29,7 +29,7 @@ __all__ = [
     "Class_AMG", "AMGHierarchy", "MG_Vcycle", "MG_Wcycle", "PCG", "components", "Hybrid_AMG",
     "AMG4POT", "MatlabRand", "IpdError", "amg_options", "APDWorkspace", "warmup_class1",
     "warmup_class2", "APD_SsN_Class1", "APD_SsN_Class2", "twogrid_bigph", "twogrid", "Hybrid_twogrid",
-    "aug_PCG", "PCG4POT",
+    "aug_PCG", "PCG4POT", "load_input",
 ]
 
 
@@ -713,3 +713,31 @@ def APD_SsN_Class2(c, r, l, p, q, mu, phi, rng: MatlabRand | None = None,
                                 isnsp=1, inter=1, guess=None)
     ws = APDWorkspace(2, c, r, l, p, q, mu=mu, phi=phi)
     return _run_script(ws, amg_opts, rng, (0.0, 100), opts)
+
+
+def load_input(path: str) -> dict:
+    """``load('./InputData/data1-*.mat')`` / ``data4-*.mat`` (``APD_SsN_Class1.m:27``,
+    ``APD_SsN_Class2.m``): the reference's MAT-v5 workspaces as float64 arrays.
+
+    The bundled files store ``p``, ``q`` (and ``phi``) as ``uint8`` and ``m``, ``n`` as ``uint16``;
+    MATLAB promotes them silently in mixed arithmetic, here they are cast once (SURVEY A-12).
+    Returns ``dict(cls, m, n, c, r, l, p, q, gama)`` for Class 1 and
+    ``dict(cls, m, n, c, r, l, p, q, mu, phi)`` for Class 2 (``c = C(:)``, column-major)."""
+    import scipy.io
+    d = scipy.io.loadmat(path)
+    vec = lambda k: np.asarray(d[k], dtype=np.float64).reshape(-1, order="F")
+    out = dict(r=vec("r"), l=vec("l"), p=vec("p"), q=vec("q"))
+    out["m"], out["n"] = out["l"].size, out["r"].size
+    if "mu" in d:                                           # Class 2
+        out["cls"] = 2
+        out["c"] = vec("c") if "c" in d else vec("C")
+        out["mu"] = float(np.asarray(d["mu"]).reshape(-1)[0])
+        out["phi"] = vec("phi")
+    else:
+        out["cls"] = 1
+        out["c"] = vec("c")
+        g = vec("gama")
+        out["gama"] = float(g[0]) if g.size == 1 or np.all(g == g[0]) else g
+    if out["c"].size != out["m"] * out["n"]:
+        raise ValueError("load_input: length(c) != m*n")
+    return out
