@@ -21,7 +21,7 @@ def system(m, n, rho, seed, pq_random):
 
 
 @pytest.mark.parametrize("m,n,rho,pq", [(64, 64, 1.0, False), (100, 70, 0.5, True),
-                                        (130, 257, 0.08, True), (33, 40, 0.9, True)])
+                                        (130, 257, 0.15, True), (33, 40, 0.9, True)])
 @pytest.mark.parametrize("cycle", ["v", "w"])
 def test_mask_operator_matches_csr_sweeps(m, n, rho, pq, cycle):
     import codes_of_ipd_ssn_amg_method_amd as ipd
@@ -53,10 +53,12 @@ def test_mask_operator_matches_csr_sweeps(m, n, rho, pq, cycle):
 def test_mask_operator_rejects_other_matrices():
     import codes_of_ipd_ssn_amg_method_amd as ipd
     m, n = 48, 40
-    pd, Ae = system(m, n, 0.3, 7, True)
+    pd, Ae = system(m, n, 0.6, 7, True)
     opts = dict(retol=1e-11, bigph=1, maxit=30, theta=0.25, smoth=5, cycle="v", isnsp=1, inter=1,
                 fnode=n)
-    # (a) wrong scale vectors
+    # the operator itself is fine for this matrix ...
+    assert ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand(5489)).attach_mask_operator(pd["p"], pd["q"], pd["tk"])
+    # ... (a) but not with wrong scale vectors
     h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand(5489))
     assert not h.attach_mask_operator(pd["p"] * 1.001, pd["q"], pd["tk"])
     assert not h.attach_mask_operator(pd["p"], pd["q"], pd["tk"] * 1.5)
@@ -69,6 +71,9 @@ def test_mask_operator_rejects_other_matrices():
     hb = ipd.AMGHierarchy(sp.csc_matrix(B), opts, ipd.MatlabRand(5489))
     assert not hb.attach_mask_operator(pd["p"], pd["q"], pd["tk"])
     # (a non-bipartite level 1 cannot get this far: bigph setup refuses it, transfer.m:20-21)
+    # (c) sparse masks (fewer than 16 entries per row) keep the padded CSR sweeps: they are faster
+    pds, Aes = system(m, n, 0.05, 7, True)
+    assert not ipd.AMGHierarchy(Aes, opts, ipd.MatlabRand(5489)).attach_mask_operator(pds["p"], pds["q"], pds["tk"])
     # the rejected hierarchies still solve with the CSR kernels
     r = np.random.RandomState(2).standard_normal(m + n)
     x, it, rr, _, _ = hb.solve(r - r.mean(), np.zeros(m + n))
