@@ -215,6 +215,8 @@ void fill_f64(ipd_ctx* ctx, double* p, double v, size_t n);
 void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n);
 // C = X*Y with MATLAB ordering (ascending inner index, no FMA, exact zeros dropped)
 void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C);
+void csr_expand_dense(ipd_ctx* ctx, const Csr& A, double* dense, int ld);  // dense pre-zeroed
+void dense_rowcount(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, int* rowcnt);
 void csr_copy(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out);
 void csr_drop_zeros(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out);  // ipd_kkt.hip
 

@@ -13,6 +13,8 @@
 #include "ipd_amg_internal.h"
 
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 static inline int rows_grid(int nr) { return std::max(1, std::min(cdiv(nr, 4), 4096)); }
 static inline int elems_grid(long long n) {
@@ -521,6 +523,100 @@ __global__ __launch_bounds__(256) void k_build_W(int N, int Nc, const int* __res
     }
 }
 
+// The same rows through the ordered product of ipd_sparse.hip, for levels whose rows are long
+// (filled-in level 2 under dense masks): W1 and X are written as CSR matrices over all N rows
+// (C rows empty), W2 = X*W1 is one csr_spgemm (which switches to register tiles when that is
+// faster), and the rows of W are put together in a dense scratch.  Every W2(i,c) still receives
+// x(i,k)*w1(k,c) one term at a time in ascending k, so the bits equal k_build_W's.
+__global__ __launch_bounds__(256) void k_w_split_count(int N, const int* __restrict__ rp,
+                                                      const int* __restrict__ ci,
+                                                      const uint8_t* __restrict__ strong,
+                                                      const uint8_t* __restrict__ isC,
+                                                      const uint8_t* __restrict__ isF,
+                                                      int* __restrict__ cnt1,
+                                                      int* __restrict__ cntx) {
+    WAVE_ROWS(i, N) {
+        int n1 = 0, nx = 0;
+        if (!isC[i])
+            for (int t = rp[i] + lane; t < rp[i + 1]; t += 64) {
+                const int j = ci[t];
+                n1 += isC[j] != 0;
+                nx += isF[j] && (j == i || strong[t]);
+            }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            n1 += __shfl_xor(n1, d);
+            nx += __shfl_xor(nx, d);
+        }
+        if (lane == 0) {
+            cnt1[i] = n1;
+            cntx[i] = nx;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_w_split_fill(int N, const int* __restrict__ rp,
+                                                     const int* __restrict__ ci,
+                                                     const double* __restrict__ va,
+                                                     const double* __restrict__ diag,
+                                                     const uint8_t* __restrict__ strong,
+                                                     const uint8_t* __restrict__ isC,
+                                                     const uint8_t* __restrict__ isF,
+                                                     const int* __restrict__ cidx,
+                                                     const int* __restrict__ rp1,
+                                                     int* __restrict__ ci1, double* __restrict__ va1,
+                                                     const int* __restrict__ rpx,
+                                                     int* __restrict__ cix, double* __restrict__ vax) {
+    WAVE_ROWS(i, N) {
+        if (isC[i]) continue;
+        const double ndi = -diag[i];
+        int b1 = rp1[i], bx = rpx[i];
+        const int b = rp[i], e = rp[i + 1];
+        for (int t0 = b; t0 < e; t0 += 64) {
+            const int t = t0 + lane;
+            const int j = t < e ? ci[t] : 0;
+            const bool f1 = t < e && isC[j];
+            const bool fx = t < e && isF[j] && (j == i || strong[t]);
+            const double v = t < e ? va[t] / ndi : 0.0;
+            const unsigned long long m1 = __ballot(f1), mx = __ballot(fx);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (f1) {
+                const int pos = b1 + __popcll(m1 & below);
+                ci1[pos] = cidx[j];
+                va1[pos] = v;
+            }
+            if (fx) {
+                const int pos = bx + __popcll(mx & below);
+                cix[pos] = j;
+                vax[pos] = v;
+            }
+            b1 += __popcll(m1);
+            bx += __popcll(mx);
+        }
+    }
+}
+
+// dense rows hold W1; add half of W2 on the F rows, write the identity entry on the C rows
+__global__ __launch_bounds__(256) void k_w_combine(int N, int Nc, const uint8_t* __restrict__ isC,
+                                                  const int* __restrict__ cidx,
+                                                  const int* __restrict__ rp2,
+                                                  const int* __restrict__ ci2,
+                                                  const double* __restrict__ va2,
+                                                  double* __restrict__ dense) {
+    WAVE_ROWS(i, N) {
+        double* drow = dense + (size_t)i * Nc;
+        if (isC[i]) {
+            if (lane == 0) drow[cidx[i]] = 1.0;
+            continue;
+        }
+        for (int t = rp2[i] + lane; t < rp2[i + 1]; t += 64) {
+            const int c = ci2[t];
+            const double half = 0.5 * va2[t];
+            drow[c] = drow[c] + half;
+        }
+    }
+}
+
 // D = diag(W*1); W = D\W on the F rows (transfer.m:60-62)
 __global__ __launch_bounds__(256) void k_row_normalize(int N, const uint8_t* __restrict__ isF,
                                                        const int* __restrict__ prp,
@@ -632,17 +728,54 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
                     "transfer: dense interpolation scratch above 2 GiB");
         double* dense = tmp.alloc<double>(dense_elems);
         int* rowcnt = tmp.alloc<int>((size_t)N + 1);
-        static bool attr_set = false;
-        if (!attr_set) {
-            IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_W),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_set = true;
+        // long rows: the product form (see k_w_split_count); short rows: one kernel
+        bool split = (double)A.nnz / std::max(N, 1) >= 64.0;
+        if (const char* e = getenv("IPD_INTERP")) split = !strcmp(e, "split");
+        if (split) {
+            int* cnt1 = tmp.alloc<int>((size_t)N + 1);
+            int* cntx = tmp.alloc<int>((size_t)N + 1);
+            hipLaunchKernelGGL(k_w_split_count, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp,
+                               A.ci, strong, isC, isF, cnt1, cntx);
+            IPD_KERNEL_CHECK();
+            Csr W1, X, W2;
+            W1.nr = N;
+            W1.nc = Nc;
+            X.nr = X.nc = N;
+            W1.rp = tmp.alloc<int>((size_t)N + 1);
+            X.rp = tmp.alloc<int>((size_t)N + 1);
+            exclusive_scan_i32(ctx, cnt1, W1.rp, N);
+            exclusive_scan_i32(ctx, cntx, X.rp, N);
+            W1.nnz = ctx->fetch1(W1.rp + N);
+            X.nnz = ctx->fetch1(X.rp + N);
+            W1.ci = tmp.alloc<int>((size_t)std::max(W1.nnz, 1));
+            W1.va = tmp.alloc<double>((size_t)std::max(W1.nnz, 1));
+            X.ci = tmp.alloc<int>((size_t)std::max(X.nnz, 1));
+            X.va = tmp.alloc<double>((size_t)std::max(X.nnz, 1));
+            hipLaunchKernelGGL(k_w_split_fill, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp,
+                               A.ci, A.va, diag, strong, isC, isF, cidx, W1.rp, W1.ci, W1.va, X.rp,
+                               X.ci, X.va);
+            IPD_KERNEL_CHECK();
+            csr_spgemm(ctx, tmp, X, W1, &W2);
+            IPD_HIP(hipMemsetAsync(dense, 0, dense_elems * 8, ctx->stream));
+            csr_expand_dense(ctx, W1, dense, Nc);
+            hipLaunchKernelGGL(k_w_combine, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, Nc, isC,
+                               cidx, W2.rp, W2.ci, W2.va, dense);
+            IPD_KERNEL_CHECK();
+            dense_rowcount(ctx, N, Nc, Nc, dense, rowcnt);
+        } else {
+            static bool attr_set = false;
+            if (!attr_set) {
+                IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_W),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            128 * 1024));
+                attr_set = true;
+            }
+            const int bw_threads = (double)A.nnz / std::max(N, 1) >= 96.0 ? 256 : 64;
+            hipLaunchKernelGGL(k_build_W, dim3(std::min(N, 16384)), dim3(bw_threads),
+                               (size_t)Nc * 16, ctx->stream, N, Nc, A.rp, A.ci, A.va, diag, strong,
+                               isC, isF, cidx, dense, rowcnt);
+            IPD_KERNEL_CHECK();
         }
-        const int bw_threads = (double)A.nnz / std::max(N, 1) >= 96.0 ? 256 : 64;
-        hipLaunchKernelGGL(k_build_W, dim3(std::min(N, 16384)), dim3(bw_threads), (size_t)Nc * 16,
-                           ctx->stream, N, Nc, A.rp, A.ci, A.va, diag, strong, isC, isF, cidx, dense,
-                           rowcnt);
-        IPD_KERNEL_CHECK();
         P.rp = dst.alloc<int>((size_t)N + 1);
         exclusive_scan_i32(ctx, rowcnt, P.rp, N);
         P.nnz = ctx->fetch1(P.rp + N);

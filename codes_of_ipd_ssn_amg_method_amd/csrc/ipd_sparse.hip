@@ -10,7 +10,9 @@
 
 #include "ipd_internal.h"
 
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 // ---------------------------------------------------------------------------
 // small kernels
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void k_spgemm_rows(int nr, int nc, const int* 
 }
 
 // one wave per row: ordered compaction of the dense row into CSR
-__global__ __launch_bounds__(256) void k_dense_compact(int nr, int nc,
+__global__ __launch_bounds__(256) void k_dense_compact(int nr, int nc, int ld,
                                                        const double* __restrict__ dense,
                                                        const int* __restrict__ rp,
                                                        int* __restrict__ ci,
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256) void k_dense_compact(int nr, int nc,
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int i = wave; i < nr; i += nwaves) {
         int base = rp[i];
-        const double* drow = dense + (size_t)i * nc;
+        const double* drow = dense + (size_t)i * ld;
         for (int j0 = 0; j0 < nc; j0 += 64) {
             const int j = j0 + lane;
             const double v = j < nc ? drow[j] : 0.0;
@@ -380,33 +382,198 @@ __global__ __launch_bounds__(256) void k_dense_compact(int nr, int nc,
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// dense-tile variant of the ordered product, for filled-in operands
+// ---------------------------------------------------------------------------
+// When the masks are dense (BASELINE regime D, early Newton iterations) the level-2 Galerkin
+// products are products of nearly full matrices and the row kernel above spends its time on LDS
+// read-modify-writes.  Here the operands are expanded to zero-padded dense arrays and a 64x64
+// output tile per workgroup accumulates in registers, 4x4 outputs per thread, with the inner
+// index still walked strictly in ascending order: every C(i,j) receives x(i,k)*y(k,j) one term
+// at a time for k = 0,1,2,...  The terms a structural zero contributes are +0.0, which leave a
+// partial sum unchanged, so the result is bit-identical to the row kernel's (this translation
+// unit is compiled with -ffp-contract=off: multiply, round, add, round).
+constexpr int GT = 64;   // output tile edge
+constexpr int GK = 16;   // inner-index tile
+
+__global__ __launch_bounds__(256) void k_csr_expand(int nr, int ld, const int* __restrict__ rp,
+                                                    const int* __restrict__ ci,
+                                                    const double* __restrict__ va,
+                                                    double* __restrict__ dense) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < nr; i += nwaves) {
+        double* drow = dense + (size_t)i * ld;
+        for (int t = rp[i] + lane; t < rp[i + 1]; t += 64) drow[ci[t]] = va[t];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_ordered(int nkp, int ncp,
+                                                      const double* __restrict__ X,
+                                                      const double* __restrict__ Y,
+                                                      double* __restrict__ C) {
+    // X: (rows padded to GT) x nkp, Y: nkp x ncp, C: rows x ncp; nkp % GK == 0, ncp % GT == 0
+    __shared__ __attribute__((aligned(16))) double xs[GK][GT];   // transposed: xs[k][row]
+    __shared__ __attribute__((aligned(16))) double ys[GK][GT];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int r0 = blockIdx.y * GT, c0 = blockIdx.x * GT;
+    double acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+    // fetch roles: X tile 64 rows x 16 k (4 consecutive k per thread), Y tile 16 k x 64 columns
+    const int xr = tid >> 2, xk = (tid & 3) * 4;
+    const int yk = tid >> 4, yc = (tid & 15) * 4;
+    const double* xp = X + (size_t)(r0 + xr) * nkp + xk;
+    const double* yp = Y + (size_t)yk * ncp + c0 + yc;
+    double xf[4], yf[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        xf[u] = xp[u];
+        yf[u] = yp[u];
+    }
+    for (int k0 = 0; k0 < nkp; k0 += GK) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xs[xk + u][xr] = xf[u];
+            ys[yk][yc + u] = yf[u];
+        }
+        __syncthreads();
+        if (k0 + GK < nkp) {   // next tile's fetch overlaps this tile's arithmetic
+            xp += GK;
+            yp += (size_t)GK * ncp;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xf[u] = xp[u];
+                yf[u] = yp[u];
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < GK; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = xs[kk][ty * 4 + u];
+                b[u] = ys[kk][tx * 4 + u];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double prod = a[r] * b[c];
+                    acc[r][c] = acc[r][c] + prod;
+                }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double* crow = C + (size_t)(r0 + ty * 4 + r) * ncp + c0 + tx * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) crow[c] = acc[r][c];
+    }
+}
+
+// one wave per row: number of nonzeros of a dense row
+__global__ __launch_bounds__(256) void k_dense_rowcount(int nr, int nc, int ld,
+                                                        const double* __restrict__ dense,
+                                                        int* __restrict__ rowcnt) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < nr; i += nwaves) {
+        const double* drow = dense + (size_t)i * ld;
+        int nz = 0;
+        for (int j = lane; j < nc; j += 64) nz += (drow[j] != 0.0);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d);
+        if (lane == 0) rowcnt[i] = nz;
+    }
+}
+
+static inline size_t round_up(size_t v, size_t q) { return (v + q - 1) / q * q; }
+
+// Which product kernel is expected to finish first.  The row kernel is a dependent chain per
+// output row: one step per entry of X's row, each step a pass over a row of Y plus a barrier
+// (about 0.35 us + 0.25 us per 256 entries, measured on MI355X), with rows spread over the CUs
+// as LDS allows.  The tile kernel walks the padded rows x inner x columns box at about 0.9 us
+// per 16 inner indices per wave of 256 tiles, plus the expansion of the operands.
+// IPD_PRODUCT=rows|tiles overrides the choice (tests compare the two bit for bit).
+static bool spgemm_prefers_tiles(const Csr& X, const Csr& Y, size_t* bytes) {
+    const size_t nrp = round_up((size_t)X.nr, GT), nkp = round_up((size_t)X.nc, GT),
+                 ncp = round_up((size_t)Y.nc, GT);
+    *bytes = 8 * (nrp * nkp + nkp * ncp + nrp * ncp);
+    if (X.nr == 0 || X.nc == 0 || Y.nc == 0 || X.nnz == 0) return false;
+    if (*bytes > (size_t(3) << 29)) return false;   // 1.5 GiB of dense scratch at most
+    if (const char* e = getenv("IPD_PRODUCT")) {
+        if (!strcmp(e, "tiles")) return true;
+        if (!strcmp(e, "rows")) return false;
+    }
+    const double xlen = (double)X.nnz / X.nr, ylen = (double)Y.nnz / Y.nr;
+    const double lds_rows = std::max(1.0, std::min(8.0, 160.0 * 1024 / (8.0 * Y.nc + 64)));
+    const double row_rounds = std::ceil(X.nr / (256.0 * lds_rows));
+    const double t_rows = row_rounds * xlen * (0.35 + 0.25 * std::ceil(ylen / 256.0));
+    const double tiles = (double)(nrp / GT) * (double)(ncp / GT);
+    const double t_tiles = 40.0 + std::ceil(tiles / 256.0) * (double)(nkp / GK) * 0.9 +
+                           (double)*bytes / 3.0e6;   // memset + expand + rowcount at ~3 TB/s
+    return t_tiles < t_rows;
+}
+
 void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
     IPD_REQUIRE(X.nc == Y.nr, IPD_E_ARG, "spgemm: inner dimensions differ");
     const int nr = X.nr, nc = Y.nc;
-    IPD_REQUIRE((size_t)nc * 8 <= 128 * 1024, IPD_E_LIMIT,
-                "spgemm: more than 16384 columns (LDS accumulator row limit)");
-    const size_t dense_elems = (size_t)(nr ? nr : 1) * (size_t)(nc ? nc : 1);
-    IPD_REQUIRE(dense_elems * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
-                "spgemm: dense scratch above 2 GiB");
     Arena& tmp = *ctx->scratch;
-    double* dense = tmp.alloc<double>(dense_elems);
     int* rowcnt = tmp.alloc<int>((size_t)nr + 1);
     Csr out;
     out.nr = nr;
     out.nc = nc;
     out.rp = dst.alloc<int>((size_t)nr + 1);
-    if (nr > 0) {
-        const size_t lds = std::max<size_t>((size_t)nc * 8, 16);
-        static bool attr_set = false;
-        if (!attr_set) {
-            IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_spgemm_rows),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_set = true;
-        }
-        const int threads = (Y.nr > 0 && (double)Y.nnz / Y.nr >= 96.0) ? 256 : 64;
-        hipLaunchKernelGGL(k_spgemm_rows, dim3(std::min(nr, 16384)), dim3(threads), lds, ctx->stream,
-                           nr, nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense, rowcnt);
+    double* dense = nullptr;
+    int ld = nc;
+    size_t tile_bytes = 0;
+    if (spgemm_prefers_tiles(X, Y, &tile_bytes)) {
+        const size_t nrp = round_up((size_t)nr, GT), nkp = round_up((size_t)X.nc, GT),
+                     ncp = round_up((size_t)nc, GT);
+        double* xd = tmp.alloc<double>(nrp * nkp);
+        double* yd = tmp.alloc<double>(nkp * ncp);
+        dense = tmp.alloc<double>(nrp * ncp);
+        ld = (int)ncp;
+        IPD_HIP(hipMemsetAsync(xd, 0, nrp * nkp * 8, ctx->stream));
+        IPD_HIP(hipMemsetAsync(yd, 0, nkp * ncp * 8, ctx->stream));
+        hipLaunchKernelGGL(k_csr_expand, dim3(std::min(cdiv(X.nr, 4), 4096)), dim3(256), 0,
+                           ctx->stream, X.nr, (int)nkp, X.rp, X.ci, X.va, xd);
+        hipLaunchKernelGGL(k_csr_expand, dim3(std::min(cdiv(Y.nr, 4), 4096)), dim3(256), 0,
+                           ctx->stream, Y.nr, (int)ncp, Y.rp, Y.ci, Y.va, yd);
+        hipLaunchKernelGGL(k_gemm_ordered, dim3((unsigned)(ncp / GT), (unsigned)(nrp / GT)),
+                           dim3(256), 0, ctx->stream, (int)nkp, (int)ncp, xd, yd, dense);
+        hipLaunchKernelGGL(k_dense_rowcount, dim3(std::min(cdiv(nr, 4), 4096)), dim3(256), 0,
+                           ctx->stream, nr, nc, ld, dense, rowcnt);
         IPD_KERNEL_CHECK();
+    } else {
+        IPD_REQUIRE((size_t)nc * 8 <= 128 * 1024, IPD_E_LIMIT,
+                    "spgemm: more than 16384 columns (LDS accumulator row limit)");
+        const size_t dense_elems = (size_t)(nr ? nr : 1) * (size_t)(nc ? nc : 1);
+        IPD_REQUIRE(dense_elems * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
+                    "spgemm: dense scratch above 2 GiB");
+        dense = tmp.alloc<double>(dense_elems);
+        if (nr > 0) {
+            const size_t lds = std::max<size_t>((size_t)nc * 8, 16);
+            static bool attr_set = false;
+            if (!attr_set) {
+                IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_spgemm_rows),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            128 * 1024));
+                attr_set = true;
+            }
+            const int threads = (Y.nr > 0 && (double)Y.nnz / Y.nr >= 96.0) ? 256 : 64;
+            hipLaunchKernelGGL(k_spgemm_rows, dim3(std::min(nr, 16384)), dim3(threads), lds,
+                               ctx->stream, nr, nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense,
+                               rowcnt);
+            IPD_KERNEL_CHECK();
+        }
     }
     exclusive_scan_i32(ctx, rowcnt, out.rp, nr);
     out.nnz = ctx->fetch1(out.rp + nr);
@@ -414,10 +581,25 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
     out.va = dst.alloc<double>((size_t)out.nnz);
     if (out.nnz) {
         hipLaunchKernelGGL(k_dense_compact, dim3(std::max(1, std::min(cdiv(nr, 4), 4096))), dim3(256),
-                           0, ctx->stream, nr, nc, dense, out.rp, out.ci, out.va);
+                           0, ctx->stream, nr, nc, ld, dense, out.rp, out.ci, out.va);
         IPD_KERNEL_CHECK();
     }
     *C = out;
+}
+
+// dense-row helpers shared with the interpolation build (ipd_setup.hip)
+void csr_expand_dense(ipd_ctx* ctx, const Csr& A, double* dense, int ld) {
+    if (A.nr == 0 || A.nnz == 0) return;
+    hipLaunchKernelGGL(k_csr_expand, dim3(std::min(cdiv(A.nr, 4), 4096)), dim3(256), 0, ctx->stream,
+                       A.nr, ld, A.rp, A.ci, A.va, dense);
+    IPD_KERNEL_CHECK();
+}
+
+void dense_rowcount(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, int* rowcnt) {
+    if (nr == 0) return;
+    hipLaunchKernelGGL(k_dense_rowcount, dim3(std::min(cdiv(nr, 4), 4096)), dim3(256), 0,
+                       ctx->stream, nr, nc, ld, dense, rowcnt);
+    IPD_KERNEL_CHECK();
 }
 
 // ---------------------------------------------------------------------------

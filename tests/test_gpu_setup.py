@@ -127,3 +127,63 @@ def test_setup_errors(ipd):
     with pytest.raises(ipd.IpdError) as ei:
         ipd.AMGHierarchy(A, dict(bigph=1, fnode=None, smoth=1))
     assert "requires Nf > 0" in str(ei.value)       # Class_AMG.m:36-40
+
+
+@pytest.mark.parametrize("name,m,n,mk,t", [c for c in CASES if c[0] in ("dense96", "half128")],
+                         ids=["dense96", "half128"])
+def test_hierarchy_bit_exact_tile_product(ipd, monkeypatch, name, m, n, mk, t):
+    """Galerkin products through the dense-tile kernel (csrc/ipd_sparse.hip k_gemm_ordered),
+    forced here at sizes the oracle can follow: same bits as the oracle's ordered product."""
+    monkeypatch.setenv("IPD_PRODUCT", "tiles")
+    monkeypatch.setenv("IPD_INTERP", "split")   # interpolation rows through the product too
+    Ae, pd = newton_matrix(m, n, mk())
+    o = O.amg_options_class1("v"); o.update(fnode=n, isnsp=1)
+    ho = O.amg_setup(Ae, o, O.matlab_rng())
+    h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+    assert h.level_sizes() == ho.level_sizes()
+    for k in range(1, ho.J + 1):
+        assert csc_equal(h.A(k), ho.Ack[k]), f"Ack{{{k}}} differs"
+    for k in range(2, ho.J + 1):
+        assert csc_equal(h.P(k), ho.Prok[k]), f"Prok{{{k}}} differs"
+    h.close()
+
+
+@pytest.mark.parametrize("name,m,n,mk,t", CASES, ids=[c[0] for c in CASES])
+def test_hierarchy_bit_exact_split_interpolation(ipd, monkeypatch, name, m, n, mk, t):
+    """The interpolation build in product form (csrc/ipd_setup.hip k_w_split_*; default only for
+    long rows) on every setup case, sparse ones included, with the row product kernel."""
+    monkeypatch.setenv("IPD_INTERP", "split")
+    monkeypatch.setenv("IPD_PRODUCT", "rows")
+    s = mk()
+    Ae, pd = newton_matrix(m, n, s)
+    lab = sp.csgraph.connected_components(Ae)[1]
+    pk = np.flatnonzero(lab == np.argmax(np.bincount(lab)))
+    Ae = sp.csr_matrix(Ae[pk, :][:, pk])
+    o = O.amg_options_class1("v"); o.update(fnode=int((pk < n).sum()), isnsp=1)
+    ho = O.amg_setup(Ae, o, O.matlab_rng())
+    h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+    assert h.level_sizes() == ho.level_sizes()
+    for k in range(2, ho.J + 1):
+        assert csc_equal(h.A(k), ho.Ack[k]), f"Ack{{{k}}} differs"
+        assert csc_equal(h.P(k), ho.Prok[k]), f"Prok{{{k}}} differs"
+    h.close()
+
+
+@pytest.mark.parametrize("rho", [1.0, 0.4])
+def test_tile_product_matches_row_product(ipd, monkeypatch, rho):
+    """At a size where the tile kernel is the default choice, both product kernels give the same
+    hierarchy bit for bit (ragged sizes: the zero padding of the dense operands is exercised)."""
+    m, n = 530, 470
+    Ae, pd = newton_matrix(m, n, PR.mask_bernoulli(m, n, rho, seed=4))
+    o = O.amg_options_class1("v"); o.update(fnode=n, isnsp=1)
+    hs = []
+    for kind in ("rows", "tiles"):
+        monkeypatch.setenv("IPD_PRODUCT", kind)
+        monkeypatch.setenv("IPD_INTERP", "single" if kind == "rows" else "split")
+        hs.append(ipd.AMGHierarchy(Ae, o, ipd.MatlabRand()))
+    a, b = hs
+    assert a.level_sizes() == b.level_sizes()
+    for k in range(2, a.J + 1):
+        assert csc_equal(a.A(k), b.A(k)), f"level {k}"
+        assert csc_equal(a.P(k), b.P(k)), f"level {k}"
+    a.close(); b.close()
