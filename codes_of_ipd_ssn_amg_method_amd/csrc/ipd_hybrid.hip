@@ -9,7 +9,11 @@
 // labels into blocks/sizes/p/r and routes components is host logic.
 #pragma clang fp contract(off)
 
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
+#include <string>
 #include <thread>
 
 #include "ipd_amg_internal.h"
@@ -454,6 +458,41 @@ static std::function<void(int*, double*)> class_amg_prepare(
     };
 }
 
+// Debugging aid: IPD_DUMP_SYSTEM=<prefix> IPD_DUMP_CALLS=<lo>-<hi> writes the rescaled Newton
+// systems Ae*u = f of those Hybrid_AMG calls (counted per process from 0) to
+// <prefix><call>.bin: int64 M, nf, nnz; int32 rp[M+1], ci[nnz]; double va[nnz], f[M].
+// tests/read_system_dump.py reads them back, so a system a driver run produced can be put
+// through the oracle.
+static void dump_system(ipd_ctx* ctx, const Csr& Ae, const double* f, int nf) {
+    static std::atomic<int> calls{0};
+    const int call = calls++;
+    const char* prefix = getenv("IPD_DUMP_SYSTEM");
+    if (!prefix) return;
+    int lo = 0, hi = 0;
+    if (const char* e = getenv("IPD_DUMP_CALLS")) {
+        if (sscanf(e, "%d-%d", &lo, &hi) < 2) hi = lo;
+    }
+    if (call < lo || call > hi) return;
+    std::vector<int> rp((size_t)Ae.nr + 1), ci((size_t)Ae.nnz);
+    std::vector<double> va((size_t)Ae.nnz), hf((size_t)Ae.nr);
+    ctx->fetch(Ae.rp, rp.data(), rp.size());
+    if (Ae.nnz) {
+        ctx->fetch(Ae.ci, ci.data(), ci.size());
+        ctx->fetch(Ae.va, va.data(), va.size());
+    }
+    ctx->fetch(f, hf.data(), hf.size());
+    const std::string path = std::string(prefix) + std::to_string(call) + ".bin";
+    FILE* fp = fopen(path.c_str(), "wb");
+    IPD_REQUIRE(fp, IPD_E_ARG, "IPD_DUMP_SYSTEM: cannot open the output file");
+    const int64_t head[3] = {Ae.nr, nf, Ae.nnz};
+    fwrite(head, sizeof(int64_t), 3, fp);
+    fwrite(rp.data(), sizeof(int), rp.size(), fp);
+    fwrite(ci.data(), sizeof(int), ci.size(), fp);
+    fwrite(va.data(), sizeof(double), va.size(), fp);
+    fwrite(hf.data(), sizeof(double), hf.size(), fp);
+    fclose(fp);
+}
+
 static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
                               const double* q, int m, int n, double bk1, double tk, const double* z,
                               const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out,
@@ -497,6 +536,7 @@ static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, 
     hipLaunchKernelGGL(k_dk, dim3(g), dim3(256), 0, ctx->stream, M, n, p, q, tdiag, dK);
     IPD_KERNEL_CHECK();
     IPD_HIP(hipMemsetAsync(u, 0, sizeof(double) * (size_t)M, ctx->stream));
+    dump_system(ctx, Ae, f, n);
     // components of A0 = Q0*H0*Q0: same pattern as H0 (qp has no zeros)     :27
     Components cc_local;
     if (!reuse) {

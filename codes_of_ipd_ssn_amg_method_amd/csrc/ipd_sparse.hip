@@ -507,7 +507,7 @@ static bool spgemm_prefers_tiles(const Csr& X, const Csr& Y, size_t* bytes) {
                  ncp = round_up((size_t)Y.nc, GT);
     *bytes = 8 * (nrp * nkp + nkp * ncp + nrp * ncp);
     if (X.nr == 0 || X.nc == 0 || Y.nc == 0 || X.nnz == 0) return false;
-    if (*bytes > (size_t(3) << 29)) return false;   // 1.5 GiB of dense scratch at most
+    if (*bytes > (size_t(12) << 30)) return false;   // 12 GiB of dense scratch at most
     if (const char* e = getenv("IPD_PRODUCT")) {
         if (!strcmp(e, "tiles")) return true;
         if (!strcmp(e, "rows")) return false;

@@ -27,15 +27,15 @@ def problem(cls, N, seed=1):
     return dict(c=c, r=r, l=l, mu=0.65 * min(r.sum(), l.sum()))
 
 
-def run(cls, N, pr):
+def run(cls, N, pr, cycle="w"):
     one = np.ones(N)
     t0 = time.perf_counter()
     if cls == 1:
         ws = ipd.APDWorkspace(1, pr["c"], pr["r"], pr["l"], one, one, gama=np.inf)
-        amg = dict(retol=1e-11, bigph=1, maxit=30, theta=1 / 4, smoth=5, cycle="w", isnsp=1, inter=1)
+        amg = dict(retol=1e-11, bigph=1, maxit=30, theta=1 / 4, smoth=5, cycle=cycle, isnsp=1, inter=1)
     else:
         ws = ipd.APDWorkspace(2, pr["c"], pr["r"], pr["l"], one, one, mu=pr["mu"], phi=np.ones(N * N))
-        amg = dict(retol=1e-11, bigph=1, maxit=40, theta=1 / 4, smoth=10, cycle="w", isnsp=1, inter=1)
+        amg = dict(retol=1e-11, bigph=1, maxit=40, theta=1 / 4, smoth=10, cycle=cycle, isnsp=1, inter=1)
     ipd.get_ctx().sync()
     t1 = time.perf_counter()
     ws.warmup(0.0, 100)
@@ -70,11 +70,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="500,1024")
     ap.add_argument("--classes", default="1,2")
+    ap.add_argument("--cycle", default="w", choices=["v", "w"],
+                    help="AMG cycle of the inner solver (the reference scripts use w)")
     a = ap.parse_args()
     for N in [int(x) for x in a.sizes.split(",")]:
         for cls in [int(x) for x in a.classes.split(",")]:
             pr = problem(cls, N)
-            rec = run(cls, N, pr)
+            rec = run(cls, N, pr, a.cycle)
+            rec["cycle"] = a.cycle
             print(json.dumps(rec), flush=True)
 
 
