@@ -138,6 +138,10 @@ struct ipd_ctx {
     std::unique_ptr<Arena> scratch;  // per-call temporaries (reset by CallScope)
     void* pinned = nullptr;          // host staging for small readbacks
     size_t pinned_bytes = 0;
+    // mailbox for scalar readbacks: host-coherent memory a one-wave kernel writes the words and
+    // then a ticket into, while the host spins on the ticket (no copy engine, no stream wait)
+    volatile unsigned* mailbox = nullptr;   // [0] ticket, [16..48) payload words
+    unsigned mailbox_ticket = 0;
     int num_cu = 256;
     RcclState* comm = nullptr;
     ipd_ctx* aux = nullptr;   // second stream/arena for work that overlaps with this context's
