@@ -116,7 +116,8 @@ EXPORTS = [
     "ipd_amg_level_dims", "ipd_amg_get_A", "ipd_amg_get_P", "ipd_amg_get_cmask", "ipd_amg_solve",
     "ipd_amg_vcycle", "ipd_amg_wcycle", "ipd_class_amg", "ipd_pcg", "ipd_components",
     "ipd_hybrid_amg", "ipd_amg4pot", "ipd_dmalloc", "ipd_dfree", "ipd_h2d", "ipd_d2h",
-    "ipd_dmat_upload", "ipd_dmat_download", "ipd_dmat_dims", "ipd_dmat_destroy", "ipd_spmv_dev",
+    "ipd_dmat_upload", "ipd_dmat_download", "ipd_dmat_dims", "ipd_dmat_destroy",
+    "ipd_dmat_multiply", "ipd_spmv_dev",
     "ipd_ax_dev", "ipd_aty_dev", "ipd_asat_dev", "ipd_amg_setup_dev", "ipd_amg_solve_dev",
     "ipd_hybrid_amg_dev", "ipd_amg_bench_cycles", "ipd_amg_bench_sweeps", "ipd_amg_cycle_bytes", "ipd_comm_get_unique_id",
     "ipd_comm_init", "ipd_comm_finalize", "ipd_amg_bench_cycles_sharded",

@@ -29,7 +29,7 @@ __all__ = [
     "Class_AMG", "AMGHierarchy", "MG_Vcycle", "MG_Wcycle", "PCG", "components", "Hybrid_AMG",
     "AMG4POT", "MatlabRand", "IpdError", "amg_options", "APDWorkspace", "warmup_class1",
     "warmup_class2", "APD_SsN_Class1", "APD_SsN_Class2", "twogrid_bigph", "twogrid", "Hybrid_twogrid",
-    "aug_PCG", "PCG4POT", "load_input",
+    "aug_PCG", "PCG4POT", "load_input", "sparse_multiply",
 ]
 
 
@@ -159,6 +159,27 @@ def mis_set(A, theta: float = 0.025, rng: MatlabRand | None = None):
     check(lib.ipd_mis_set(_h(), a.ref(), c_double(theta), rng.handle, bptr(isC), bptr(isF),
                           byref(out)))
     return isC.astype(bool), isF.astype(bool), csc_out_to_scipy(out)
+
+
+def sparse_multiply(A, B) -> sp.csc_matrix:
+    """``A*B`` for sparse operands with the summation order of MATLAB's sparse ``mtimes`` (every
+    entry accumulated in ascending inner index; ``transfer.m:66`` forms ``Pro'*A*Pro`` with it).
+    The device kernels are the ones the setup uses (row kernel or register tiles)."""
+    a, b = CscIn(A), CscIn(B)
+    if a.struct.ncols != b.struct.nrows:
+        raise ValueError("sparse_multiply: inner dimensions differ")
+    da, db, dc = c_void_p(), c_void_p(), c_void_p()
+    out = L.ipd_csc_out()
+    try:
+        check(lib.ipd_dmat_upload(_h(), a.ref(), c_int32(0), byref(da)))
+        check(lib.ipd_dmat_upload(_h(), b.ref(), c_int32(0), byref(db)))
+        check(lib.ipd_dmat_multiply(_h(), da, db, byref(dc)))
+        check(lib.ipd_dmat_download(_h(), dc, byref(out)))
+    finally:
+        for d in (da, db, dc):
+            if d:
+                lib.ipd_dmat_destroy(d)
+    return csc_out_to_scipy(out)
 
 
 def transfer(A, amg_options: dict, level: int = 2, rng: MatlabRand | None = None):

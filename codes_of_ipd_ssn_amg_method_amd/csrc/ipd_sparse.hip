@@ -626,6 +626,20 @@ extern "C" int ipd_dmat_download(ipd_ctx* ctx, const ipd_dmat* A, ipd_csc_out* o
     });
 }
 
+extern "C" int ipd_dmat_multiply(ipd_ctx* ctx, const ipd_dmat* A, const ipd_dmat* B,
+                                 ipd_dmat** out) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && A && B && out, IPD_E_ARG, "NULL argument");
+        CallScope scope(ctx);
+        std::unique_ptr<ipd_dmat> d(new ipd_dmat());
+        d->ctx = ctx;
+        d->arena.reset(new Arena(&ctx->pool));
+        csr_spgemm(ctx, *d->arena, A->m, B->m, &d->m);
+        ctx->sync();
+        *out = d.release();
+    });
+}
+
 extern "C" int ipd_dmat_dims(const ipd_dmat* A, int64_t* rows, int64_t* cols, int64_t* nnz) {
     if (!A) return IPD_E_ARG;
     if (rows) *rows = A->m.nr;

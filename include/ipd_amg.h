@@ -233,6 +233,10 @@ int ipd_dmat_upload(ipd_ctx*, const ipd_csc* A, int symmetric, ipd_dmat** out);
 int ipd_dmat_download(ipd_ctx*, const ipd_dmat* A, ipd_csc_out* out);
 int ipd_dmat_dims(const ipd_dmat* A, int64_t* rows, int64_t* cols, int64_t* nnz);
 void ipd_dmat_destroy(ipd_dmat* A);
+/* C = A*B for sparse operands, every C(i,j) summed in ascending inner index with separately
+ * rounded multiply and add -- the order of MATLAB's sparse mtimes as `Pro'*A*Pro`
+ * (AMG/transfer.m:66) uses it; exact zeros are dropped from the result                      */
+int ipd_dmat_multiply(ipd_ctx*, const ipd_dmat* A, const ipd_dmat* B, ipd_dmat** out);
 /* y = A*x on device vectors (CSR row walk)                                   */
 int ipd_spmv_dev(ipd_ctx*, const ipd_dmat* A, const double* x_dev, double* y_dev);
 int ipd_ax_dev(ipd_ctx*, const double* x_dev, const double* p_dev, const double* q_dev,
