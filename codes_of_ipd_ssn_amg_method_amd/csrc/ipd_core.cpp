@@ -93,29 +93,43 @@ __global__ void k_mailbox(const unsigned* __restrict__ src, int nwords, volatile
     if (i == 0) box[0] = ticket;
 }
 
+static bool mailbox_enabled() {
+    static const bool on = getenv("IPD_NO_MAILBOX") == nullptr;
+    return on;
+}
+
+bool ipd_ctx::mailbox_begin(unsigned* ticket) {
+    if (!mailbox || !mailbox_enabled()) return false;
+    *ticket = ++mailbox_ticket;
+    return true;
+}
+
+void ipd_ctx::mailbox_wait(unsigned ticket, void* hdst, size_t bytes) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1; mailbox[0] != ticket; ++spins) {
+        if ((spins & 0xffff) == 0 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            // the stream is stuck or faulted: let the runtime report it
+            IPD_HIP(hipStreamSynchronize(stream));
+            if (mailbox[0] != ticket)
+                throw IpdError(IPD_E_HIP, "readback mailbox: the ticket never arrived");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    unsigned words[MAILBOX_WORDS];
+    for (size_t w = 0; w < bytes / 4; ++w) words[w] = mailbox[16 + w];
+    std::memcpy(hdst, words, bytes);
+}
+
 void ipd_ctx::fetch_bytes(const void* dsrc, void* hdst, size_t bytes) {
     if (bytes == 0) return;
-    static const bool use_mailbox = getenv("IPD_NO_MAILBOX") == nullptr;
-    if (use_mailbox && mailbox && bytes <= MAILBOX_WORDS * 4 && bytes % 4 == 0 &&
-        (reinterpret_cast<uintptr_t>(dsrc) & 3) == 0) {
-        const unsigned ticket = ++mailbox_ticket;
+    unsigned ticket = 0;
+    if (bytes <= MAILBOX_WORDS * 4 && bytes % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(dsrc) & 3) == 0 && mailbox_begin(&ticket)) {
         hipLaunchKernelGGL(k_mailbox, dim3(1), dim3(64), 0, stream,
                            static_cast<const unsigned*>(dsrc), (int)(bytes / 4), mailbox, ticket);
         IPD_HIP(hipGetLastError());
-        const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 1; mailbox[0] != ticket; ++spins) {
-            if ((spins & 0xffff) == 0 &&
-                std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-                // the stream is stuck or faulted: let the runtime report it
-                IPD_HIP(hipStreamSynchronize(stream));
-                if (mailbox[0] != ticket)
-                    throw IpdError(IPD_E_HIP, "readback mailbox: the ticket never arrived");
-            }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        unsigned words[MAILBOX_WORDS];
-        for (size_t w = 0; w < bytes / 4; ++w) words[w] = mailbox[16 + w];
-        std::memcpy(hdst, words, bytes);
+        mailbox_wait(ticket, hdst, bytes);
         return;
     }
     if (bytes <= pinned_bytes) {

@@ -136,8 +136,7 @@ static void build_Ae(ipd_ctx* ctx, Arena& dst, const Csr& H0, const double* tdia
     Csr a;
     a.nr = a.nc = M;
     a.rp = dst.alloc<int>((size_t)M + 1);
-    exclusive_scan_i32(ctx, rowlen, a.rp, M);
-    a.nnz = ctx->fetch1(a.rp + M);
+    a.nnz = exclusive_scan_total(ctx, rowlen, a.rp, M);
     IPD_REQUIRE(ctx->fetch1(flag) == 0, IPD_E_ARG, "p or q contains 0 !!!!!");  // Hybrid_AMG.m:18-19
     a.ci = dst.alloc<int>((size_t)a.nnz);
     a.va = dst.alloc<double>((size_t)a.nnz);
@@ -604,8 +603,7 @@ static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, 
             hipLaunchKernelGGL(k_sub_count, dim3(elems_grid(nk)), dim3(256), 0, ctx->stream, nk,
                                d_pk, Ae.rp, rowlen);
             IPD_KERNEL_CHECK();
-            exclusive_scan_i32(ctx, rowlen, Ak.rp, nk);
-            Ak.nnz = ctx->fetch1(Ak.rp + nk);
+            Ak.nnz = exclusive_scan_total(ctx, rowlen, Ak.rp, nk);
             Ak.ci = tmp.alloc<int>((size_t)Ak.nnz);
             Ak.va = tmp.alloc<double>((size_t)Ak.nnz);
             hipLaunchKernelGGL(k_sub_fill, dim3(rows_grid(nk)), dim3(256), 0, ctx->stream, nk, d_pk,
@@ -922,8 +920,7 @@ void aug_pcg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
     hipLaunchKernelGGL(k_aug_rowlen, dim3(elems_grid(aug.nr)), dim3(256), 0, ctx->stream, nc, M,
                        (const int*)d_cr, (const int*)Ae.rp, len);
     IPD_KERNEL_CHECK();
-    exclusive_scan_i32(ctx, len, aug.rp, aug.nr);
-    aug.nnz = ctx->fetch1(aug.rp + aug.nr);
+    aug.nnz = exclusive_scan_total(ctx, len, aug.rp, aug.nr);
     aug.ci = tmp.alloc<int>((size_t)aug.nnz);
     aug.va = tmp.alloc<double>((size_t)aug.nnz);
     double* augf = tmp.alloc<double>((size_t)aug.nr);
@@ -1004,8 +1001,7 @@ void build_jk(ipd_ctx* ctx, Arena& dst, const Csr& H0, const double* tdiag, doub
     J->rp = dst.alloc<int>((size_t)M + 1);
     hipLaunchKernelGGL(k_jk_count, dim3(elems_grid(M)), dim3(256), 0, ctx->stream, M, H0.rp, H0.ci, len);
     IPD_KERNEL_CHECK();
-    exclusive_scan_i32(ctx, len, J->rp, M);
-    J->nnz = ctx->fetch1(J->rp + M);
+    J->nnz = exclusive_scan_total(ctx, len, J->rp, M);
     J->ci = dst.alloc<int>((size_t)J->nnz);
     J->va = dst.alloc<double>((size_t)J->nnz);
     hipLaunchKernelGGL(k_jk_fill, dim3(elems_grid(M)), dim3(256), 0, ctx->stream, M, H0.rp, H0.ci,

@@ -158,6 +158,11 @@ struct ipd_ctx {
         return v;
     }
     void fetch_bytes(const void* dsrc, void* hdst, size_t bytes);
+    // For kernels that post their own scalar results: take a ticket, pass `mailbox` and the
+    // ticket to the kernel (which stores <= 32 words at mailbox[16..] and then the ticket at
+    // mailbox[0], see k_mailbox), then wait.  Returns false when the mailbox is switched off.
+    bool mailbox_begin(unsigned* ticket);
+    void mailbox_wait(unsigned ticket, void* hdst, size_t bytes);
     void upload_bytes(void* ddst, const void* hsrc, size_t bytes);
     template <class T>
     void upload(T* ddst, const T* hsrc, size_t n) {
@@ -214,6 +219,7 @@ void csr_download_as_csc(ipd_ctx* ctx, const Csr& m, bool already_transposed, ip
 void csr_transpose(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* At);  // deterministic
 void csr_spmv(ipd_ctx* ctx, const Csr& A, const double* x, double* y);
 void exclusive_scan_i32(ipd_ctx* ctx, const int* in, int* out, int n);  // out has n+1 entries
+int exclusive_scan_total(ipd_ctx* ctx, const int* in, int* out, int n);  // same, returns out[n]
 void fill_i32(ipd_ctx* ctx, int* p, int v, size_t n);
 void fill_f64(ipd_ctx* ctx, double* p, double v, size_t n);
 void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n);

@@ -353,8 +353,7 @@ void csr_drop_zeros(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out) {
     hipLaunchKernelGGL(k_count_nz, dim3(cdiv(std::max(A.nr, 1), 256)), dim3(256), 0, ctx->stream,
                        A.nr, A.rp, A.va, cnt);
     IPD_KERNEL_CHECK();
-    exclusive_scan_i32(ctx, cnt, o.rp, A.nr);
-    o.nnz = ctx->fetch1(o.rp + A.nr);
+    o.nnz = exclusive_scan_total(ctx, cnt, o.rp, A.nr);
     o.ci = dst.alloc<int>((size_t)o.nnz);
     o.va = dst.alloc<double>((size_t)o.nnz);
     hipLaunchKernelGGL(k_copy_nz, dim3(cdiv(std::max(A.nr, 1), 256)), dim3(256), 0, ctx->stream,

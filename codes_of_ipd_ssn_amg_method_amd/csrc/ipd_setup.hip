@@ -135,7 +135,7 @@ __global__ void k_flag_pos(int n, const int* __restrict__ v, int* __restrict__ f
 __global__ void k_deg_init(int n, const int* __restrict__ degi, const int* __restrict__ rank,
                            const double* __restrict__ randv, double* __restrict__ deg,
                            uint8_t* __restrict__ isC, uint8_t* __restrict__ isF,
-                           uint8_t* __restrict__ isU) {
+                           uint8_t* __restrict__ isU, uint8_t* __restrict__ isS) {
     THREAD_ELEMS(i, n) {
         const int d = degi[i];
         double dv = 0.0;
@@ -147,11 +147,8 @@ __global__ void k_deg_init(int n, const int* __restrict__ degi, const int* __res
         isC[i] = 0;
         isF[i] = d == 0 ? 1 : 0;
         isU[i] = 1;
+        isS[i] = d > 0 ? 1 : 0;   // isS = deg > 0 of the first round (:47)
     }
-}
-
-__global__ void k_mis_sel_init(int n, const double* __restrict__ deg, uint8_t* __restrict__ isS) {
-    THREAD_ELEMS(i, n) isS[i] = deg[i] > 0.0 ? 1 : 0;
 }
 
 // edges (i,j), i<j, of triu(As(S,S),1): the smaller degree loses; ties keep the
@@ -160,7 +157,9 @@ __global__ __launch_bounds__(256) void k_mis_sel_kill(int nr, const int* __restr
                                                       const int* __restrict__ ci,
                                                       const uint8_t* __restrict__ strong,
                                                       const double* __restrict__ deg,
-                                                      uint8_t* __restrict__ isS) {
+                                                      uint8_t* __restrict__ isS,
+                                                      int* __restrict__ counts) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) counts[threadIdx.x] = 0;   // summed by k_mis_settle
     WAVE_ROWS(i, nr) {
         const double di = deg[i];
         if (di > 0.0) {
@@ -180,35 +179,46 @@ __global__ __launch_bounds__(256) void k_mis_sel_kill(int nr, const int* __restr
     }
 }
 
-__global__ void k_mis_commit(int n, const uint8_t* __restrict__ isS, uint8_t* __restrict__ isC) {
-    THREAD_ELEMS(i, n) if (isS[i]) isC[i] = 1;
-}
-
-// [i,~] = find(As(:,isC)); isF(i) = true   (:56-57)
-__global__ __launch_bounds__(256) void k_mis_markF(int nr, const int* __restrict__ rp,
-                                                   const int* __restrict__ ci,
-                                                   const uint8_t* __restrict__ strong,
-                                                   const uint8_t* __restrict__ isC,
-                                                   uint8_t* __restrict__ isF) {
+// The rest of a round in one launch, one wave per node (:53-59 and the loop test :42):
+//   isC(isS) = true;  [i,~] = find(As(:,isC)); isF(i) = true;  isU = ~(isF|isC);  deg(~isU) = 0
+// A neighbour is in C after this round iff it was before or survived the selection, and both
+// flags are final when this kernel starts, so no node waits for another one's commit.  The
+// selection of the next round, isS = deg > 0 = isU, goes to a second buffer because isS is still
+// being read here.
+__global__ __launch_bounds__(256) void k_mis_settle(int nr, const int* __restrict__ rp,
+                                                    const int* __restrict__ ci,
+                                                    const uint8_t* __restrict__ strong,
+                                                    const uint8_t* __restrict__ isS,
+                                                    uint8_t* __restrict__ isC,
+                                                    uint8_t* __restrict__ isF,
+                                                    uint8_t* __restrict__ isU,
+                                                    double* __restrict__ deg,
+                                                    uint8_t* __restrict__ isS_next,
+                                                    int* __restrict__ counts) {
+    int nc = 0, nu = 0;
     WAVE_ROWS(i, nr) {
         bool hit = false;
-        for (int t = rp[i] + lane; t < rp[i + 1]; t += 64)
-            if (strong[t] && isC[ci[t]]) hit = true;
-        if (__any(hit) && lane == 0) isF[i] = 1;
+        for (int t = rp[i] + lane; t < rp[i + 1]; t += 64) {
+            const int j = ci[t];
+            if (strong[t] && (isC[j] || isS[j])) hit = true;
+        }
+        hit = __any(hit);
+        if (lane == 0) {
+            const bool c = isC[i] || isS[i];
+            const bool f = isF[i] || hit;
+            const bool u = !(c || f);
+            if (c) isC[i] = 1;
+            if (f) isF[i] = 1;
+            isU[i] = u ? 1 : 0;
+            isS_next[i] = u ? 1 : 0;
+            if (!u) deg[i] = 0.0;
+            nc += c;
+            nu += u;
+        }
     }
-}
-
-// isU = ~(isF|isC); deg(~isU) = 0 (:58-59); counts for the loop test (:42)
-__global__ void k_mis_update(int n, const uint8_t* __restrict__ isC,
-                             const uint8_t* __restrict__ isF, uint8_t* __restrict__ isU,
-                             double* __restrict__ deg, int* __restrict__ counts) {
-    THREAD_ELEMS(i, n) {
-        const bool c = isC[i], f = isF[i];
-        const bool u = !(c || f);
-        isU[i] = u ? 1 : 0;
-        if (!u) deg[i] = 0.0;
-        if (c) atomicAdd(&counts[0], 1);
-        if (u) atomicAdd(&counts[1], 1);
+    if ((threadIdx.x & 63) == 0) {
+        if (nc) atomicAdd(&counts[0], nc);
+        if (nu) atomicAdd(&counts[1], nu);
     }
 }
 
@@ -248,8 +258,7 @@ void amg_mis_set(ipd_ctx* ctx, const Csr& A, double theta, ipd_rng* rng, uint8_t
     const int g = elems_grid(N);
     hipLaunchKernelGGL(k_flag_pos, dim3(g), dim3(256), 0, ctx->stream, N, degi, flag);
     IPD_KERNEL_CHECK();
-    exclusive_scan_i32(ctx, flag, rank, N);
-    const int nconn = ctx->fetch1(rank + N);
+    const int nconn = exclusive_scan_total(ctx, flag, rank, N);
     if ((double)nconn < 0.25 * std::sqrt((double)N)) {                       // :30-34
         std::vector<double> rv((size_t)N0);
         rng->fill(rv.data(), N0);
@@ -269,23 +278,21 @@ void amg_mis_set(ipd_ctx* ctx, const Csr& A, double theta, ipd_rng* rng, uint8_t
     rng->fill(rv.data(), nconn);                                             // :35
     double* drand = tmp.alloc<double>((size_t)nconn);
     ctx->upload(drand, rv.data(), (size_t)nconn);
+    uint8_t* isS2 = tmp.alloc<uint8_t>((size_t)N);
     hipLaunchKernelGGL(k_deg_init, dim3(g), dim3(256), 0, ctx->stream, N, degi, rank, drand, deg,
-                       isC, isF, isU);
+                       isC, isF, isU, isS);
     IPD_KERNEL_CHECK();
     int sumC = 0, sumU = N;
     int rounds = 0;
     while ((double)sumC < (double)N / 2.0 && sumU > N0) {                    // :42
         IPD_REQUIRE(++rounds <= N + 8, IPD_E_NUMERIC, "mis_set: no progress");
-        hipLaunchKernelGGL(k_mis_sel_init, dim3(g), dim3(256), 0, ctx->stream, N, deg, isS);
+        // two launches per round: the edge-wise selection, then everything that follows it
         hipLaunchKernelGGL(k_mis_sel_kill, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp,
-                           A.ci, strong, deg, isS);
-        hipLaunchKernelGGL(k_mis_commit, dim3(g), dim3(256), 0, ctx->stream, N, isS, isC);
-        hipLaunchKernelGGL(k_mis_markF, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp, A.ci,
-                           strong, isC, isF);
-        IPD_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(k_mis_update, dim3(g), dim3(256), 0, ctx->stream, N, isC, isF, isU, deg,
-                           counts);
+                           A.ci, strong, deg, isS, counts);
+        hipLaunchKernelGGL(k_mis_settle, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp, A.ci,
+                           strong, isS, isC, isF, isU, deg, isS2, counts);
         IPD_KERNEL_CHECK();
+        std::swap(isS, isS2);
         int hc[2];
         ctx->fetch(counts, hc, 2);
         sumC = hc[0];
@@ -684,8 +691,7 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
                            A.rp, A.ci, rowlen, bad);
         IPD_KERNEL_CHECK();
         P.rp = dst.alloc<int>((size_t)N + 1);
-        exclusive_scan_i32(ctx, rowlen, P.rp, N);
-        P.nnz = ctx->fetch1(P.rp + N);
+        P.nnz = exclusive_scan_total(ctx, rowlen, P.rp, N);
         IPD_REQUIRE(ctx->fetch1(bad) == 0, IPD_E_UNSUPPORTED,
                     "transfer: bigph level 1 needs a diagonal Aff block (transfer.m:20-21)");
         P.ci = dst.alloc<int>((size_t)P.nnz);
@@ -743,10 +749,8 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
             X.nr = X.nc = N;
             W1.rp = tmp.alloc<int>((size_t)N + 1);
             X.rp = tmp.alloc<int>((size_t)N + 1);
-            exclusive_scan_i32(ctx, cnt1, W1.rp, N);
-            exclusive_scan_i32(ctx, cntx, X.rp, N);
-            W1.nnz = ctx->fetch1(W1.rp + N);
-            X.nnz = ctx->fetch1(X.rp + N);
+            W1.nnz = exclusive_scan_total(ctx, cnt1, W1.rp, N);
+            X.nnz = exclusive_scan_total(ctx, cntx, X.rp, N);
             W1.ci = tmp.alloc<int>((size_t)std::max(W1.nnz, 1));
             W1.va = tmp.alloc<double>((size_t)std::max(W1.nnz, 1));
             X.ci = tmp.alloc<int>((size_t)std::max(X.nnz, 1));
@@ -777,8 +781,7 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
             IPD_KERNEL_CHECK();
         }
         P.rp = dst.alloc<int>((size_t)N + 1);
-        exclusive_scan_i32(ctx, rowcnt, P.rp, N);
-        P.nnz = ctx->fetch1(P.rp + N);
+        P.nnz = exclusive_scan_total(ctx, rowcnt, P.rp, N);
         P.ci = dst.alloc<int>((size_t)P.nnz);
         P.va = dst.alloc<double>((size_t)P.nnz);
         hipLaunchKernelGGL(k_dense_compact2, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, Nc,

@@ -37,7 +37,8 @@ void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n) { fill_t(ctx, p, v, 
 
 // Exclusive scan of n ints by ONE workgroup (n is a row/column count, at most a
 // few thousand on this path); out[n] receives the total.  in == out is allowed.
-__global__ __launch_bounds__(1024) void k_exscan(const int* __restrict__ in, int* out, int n) {
+__global__ __launch_bounds__(1024) void k_exscan(const int* __restrict__ in, int* out, int n,
+                                                 volatile unsigned* box, unsigned ticket) {
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int carry = 0;
@@ -63,12 +64,35 @@ __global__ __launch_bounds__(1024) void k_exscan(const int* __restrict__ in, int
         carry += total;
         __syncthreads();
     }
-    if (tid == 0) out[n] = carry;
+    if (tid == 0) {
+        out[n] = carry;
+        if (box) {   // post the total to the host mailbox (ipd_ctx::mailbox_wait)
+            box[16] = (unsigned)carry;
+            __threadfence_system();
+            box[0] = ticket;
+        }
+    }
 }
 
 void exclusive_scan_i32(ipd_ctx* ctx, const int* in, int* out, int n) {
-    hipLaunchKernelGGL(k_exscan, dim3(1), dim3(1024), 0, ctx->stream, in, out, n);
+    hipLaunchKernelGGL(k_exscan, dim3(1), dim3(1024), 0, ctx->stream, in, out, n,
+                       (volatile unsigned*)nullptr, 0u);
     IPD_KERNEL_CHECK();
+}
+
+// scan + total on the host in one launch (the total sizes the next allocation)
+int exclusive_scan_total(ipd_ctx* ctx, const int* in, int* out, int n) {
+    unsigned ticket = 0;
+    if (!ctx->mailbox_begin(&ticket)) {
+        exclusive_scan_i32(ctx, in, out, n);
+        return ctx->fetch1(out + n);
+    }
+    hipLaunchKernelGGL(k_exscan, dim3(1), dim3(1024), 0, ctx->stream, in, out, n, ctx->mailbox,
+                       ticket);
+    IPD_KERNEL_CHECK();
+    int total = 0;
+    ctx->mailbox_wait(ticket, &total, sizeof(int));
+    return total;
 }
 
 // ---------------------------------------------------------------------------
@@ -575,8 +599,7 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
             IPD_KERNEL_CHECK();
         }
     }
-    exclusive_scan_i32(ctx, rowcnt, out.rp, nr);
-    out.nnz = ctx->fetch1(out.rp + nr);
+    out.nnz = exclusive_scan_total(ctx, rowcnt, out.rp, nr);
     out.ci = dst.alloc<int>((size_t)out.nnz);
     out.va = dst.alloc<double>((size_t)out.nnz);
     if (out.nnz) {
