@@ -109,3 +109,27 @@ def test_amg4pot(ipd, m, n, rho):
     assert np.linalg.norm(z - zo) <= 1e-6 * np.linalg.norm(zo)
     with pytest.raises(ValueError):
         ipd.AMG4POT(pd, O.amg_options_class2("w"), "direct")   # str is 'amg' or 'twogrid' (:44-51)
+
+
+def test_system_dump_roundtrip(ipd, monkeypatch, tmp_path):
+    """IPD_DUMP_SYSTEM writes the rescaled Newton system a Hybrid_AMG call solves; the dump equals
+    the oracle's Ae and f = Q0*z (Hybrid_AMG.m:17-24) bit for bit."""
+    import glob
+    from tests.read_system_dump import read
+    m, n = 90, 70
+    s = PR.mask_tree(m, n, seed=8, connect=False)
+    pd = PR.make_prob(m, n, s, pq_random=True)
+    pd["H0"] = O.ASAt(s, pd["p"], pd["q"])
+    monkeypatch.setenv("IPD_DUMP_SYSTEM", str(tmp_path / "sys_"))
+    monkeypatch.setenv("IPD_DUMP_CALLS", "0-100000000")
+    ipd.Hybrid_AMG(pd, O.amg_options_class1("v"), ipd.MatlabRand())
+    files = glob.glob(str(tmp_path / "sys_*.bin"))
+    assert len(files) == 1
+    Ae, f, nf = read(files[0])
+    out = O.build_Ae(pd["H0"], pd["T"], pd["p"], pd["q"], pd["bk1"], pd["tk"])
+    ref, qp = sp.csr_matrix(out[0]), out[5]
+    ref.sort_indices()
+    assert nf == n and Ae.shape == ref.shape
+    assert np.array_equal(Ae.indptr, ref.indptr) and np.array_equal(Ae.indices, ref.indices)
+    assert np.array_equal(Ae.data, ref.data)
+    assert np.array_equal(f, qp * pd["z"])
