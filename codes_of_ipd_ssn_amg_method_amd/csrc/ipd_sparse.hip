@@ -324,13 +324,16 @@ void csr_spmv(ipd_ctx* ctx, const Csr& A, const double* x, double* y) {
 // ---------------------------------------------------------------------------
 // ordered SpGEMM  C = X*Y
 // ---------------------------------------------------------------------------
-// One single-wave workgroup per output row keeps a dense accumulator row in
-// LDS.  The inner-index loop is sequential (ascending k = ascending stored
-// order of X's row) and lanes only split the columns of Y's row k, which are
-// distinct, so every C(i,j) receives its terms one at a time in ascending k:
-// bit-identical to a sequential Gustavson product.  The dense row goes to a
-// scratch matrix; a second kernel compacts rows (exact zeros dropped, as
-// MATLAB's sparse mtimes does).
+// One workgroup per output row keeps a dense accumulator row in LDS.  The inner-index loop is
+// sequential (ascending k = ascending stored order of X's row) and lanes only split the columns
+// of Y's row k, which are distinct, so every C(i,j) receives its terms one at a time in
+// ascending k: bit-identical to a sequential Gustavson product.  The row goes to a dense scratch
+// matrix; a second kernel compacts rows (exact zeros dropped, as MATLAB's sparse mtimes does).
+//
+// Wide, sparse outputs (level 2 of an m = n = 8192 problem: 16384 columns, tens of entries per
+// row) would spend their time zeroing and scanning the accumulator, so the row keeps a bitmap of
+// the 64-column blocks it touched: only those are written out, re-zeroed and later compacted
+// (`rowbits`: one bit per block, ceil(nc/4096) words per row).
 __global__ __launch_bounds__(256) void k_spgemm_rows(int nr, int nc, const int* __restrict__ xrp,
                                                      const int* __restrict__ xci,
                                                      const double* __restrict__ xva,
@@ -338,15 +341,19 @@ __global__ __launch_bounds__(256) void k_spgemm_rows(int nr, int nc, const int* 
                                                      const int* __restrict__ yci,
                                                      const double* __restrict__ yva,
                                                      double* __restrict__ dense,
-                                                     int* __restrict__ rowcnt) {
+                                                     int* __restrict__ rowcnt,
+                                                     unsigned long long* __restrict__ rowbits) {
     // blockDim.x = 64 (short rows of Y) or 256 (long rows): more lanes per inner step
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ int wcnt[4];
+    __shared__ unsigned long long touched[4];   // nc <= 16384: at most 256 blocks
     double* acc = reinterpret_cast<double*>(smem_raw);
-    const int tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, W = T >> 6;
+    const int nb = (nc + 63) >> 6, nw = (nb + 63) >> 6;
+    for (int j = tid; j < nc; j += T) acc[j] = 0.0;
+    if (tid < 4) touched[tid] = 0ull;
+    __syncthreads();
     for (int i = blockIdx.x; i < nr; i += gridDim.x) {
-        for (int j = tid; j < nc; j += T) acc[j] = 0.0;
-        __syncthreads();
         const int xb = xrp[i], xe = xrp[i + 1];
         for (int e = xb; e < xe; ++e) {
             const int k = xci[e];
@@ -356,42 +363,65 @@ __global__ __launch_bounds__(256) void k_spgemm_rows(int nr, int nc, const int* 
                 const int j = yci[t];
                 const double prod = a * yva[t];
                 acc[j] = acc[j] + prod;
+                const unsigned long long bit = 1ull << ((j >> 6) & 63);
+                if (!(touched[j >> 12] & bit)) atomicOr(&touched[j >> 12], bit);
             }
             __syncthreads();
         }
+        if (xb == xe) __syncthreads();
+        // write out, count and re-zero the touched blocks: wave w takes every W-th of them
         int nz = 0;
         double* drow = dense + (size_t)i * nc;
-        for (int j = tid; j < nc; j += T) {
-            const double v = acc[j];
-            drow[j] = v;
-            nz += (v != 0.0);
+        int seen = 0;
+        for (int w = 0; w < nw; ++w) {
+            unsigned long long m = touched[w];
+            while (m) {
+                const int b = (w << 6) + __builtin_ctzll(m);
+                m &= m - 1;
+                if ((seen++ % W) != wave) continue;
+                const int j = (b << 6) + lane;
+                if (j < nc) {
+                    const double v = acc[j];
+                    drow[j] = v;
+                    nz += (v != 0.0);
+                    acc[j] = 0.0;
+                }
+            }
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d);
-        if ((tid & 63) == 0) wcnt[tid >> 6] = nz;
+        if (lane == 0) wcnt[wave] = nz;
         __syncthreads();
+        if (tid < nw) {
+            rowbits[(size_t)i * nw + tid] = touched[tid];
+            touched[tid] = 0ull;
+        }
         if (tid == 0) {
             int tot = 0;
-            for (int w = 0; w < (T >> 6); ++w) tot += wcnt[w];
+            for (int w = 0; w < W; ++w) tot += wcnt[w];
             rowcnt[i] = tot;
         }
         __syncthreads();
     }
 }
 
-// one wave per row: ordered compaction of the dense row into CSR
+// one wave per row: ordered compaction of the dense row into CSR; with `rowbits` only the
+// 64-column blocks flagged there hold data (ascending bit order = ascending columns)
 __global__ __launch_bounds__(256) void k_dense_compact(int nr, int nc, int ld,
                                                        const double* __restrict__ dense,
+                                                       const unsigned long long* __restrict__ rowbits,
                                                        const int* __restrict__ rp,
                                                        int* __restrict__ ci,
                                                        double* __restrict__ va) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nb = (nc + 63) >> 6, nw = (nb + 63) >> 6;
     for (int i = wave; i < nr; i += nwaves) {
         int base = rp[i];
+        if (base == rp[i + 1]) continue;
         const double* drow = dense + (size_t)i * ld;
-        for (int j0 = 0; j0 < nc; j0 += 64) {
+        auto block = [&](int j0) {
             const int j = j0 + lane;
             const double v = j < nc ? drow[j] : 0.0;
             const bool nzf = v != 0.0;
@@ -402,10 +432,20 @@ __global__ __launch_bounds__(256) void k_dense_compact(int nr, int nc, int ld,
                 va[pos] = v;
             }
             base += __popcll(mask);
+        };
+        if (rowbits) {
+            for (int w = 0; w < nw; ++w) {
+                unsigned long long m = rowbits[(size_t)i * nw + w];
+                while (m) {
+                    block(((w << 6) + __builtin_ctzll(m)) << 6);
+                    m &= m - 1;
+                }
+            }
+        } else {
+            for (int j0 = 0; j0 < nc; j0 += 64) block(j0);
         }
     }
 }
-
 
 // ---------------------------------------------------------------------------
 // dense-tile variant of the ordered product, for filled-in operands
@@ -556,6 +596,7 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
     out.nc = nc;
     out.rp = dst.alloc<int>((size_t)nr + 1);
     double* dense = nullptr;
+    unsigned long long* rowbits = nullptr;   // row kernel only: the 64-column blocks a row touched
     int ld = nc;
     size_t tile_bytes = 0;
     if (spgemm_prefers_tiles(X, Y, &tile_bytes)) {
@@ -583,6 +624,7 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
         IPD_REQUIRE(dense_elems * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
                     "spgemm: dense scratch above 2 GiB");
         dense = tmp.alloc<double>(dense_elems);
+        rowbits = tmp.alloc<unsigned long long>((size_t)(nr ? nr : 1) * (size_t)((nc + 4095) / 4096 + 1));
         if (nr > 0) {
             const size_t lds = std::max<size_t>((size_t)nc * 8, 16);
             static bool attr_set = false;
@@ -595,7 +637,7 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
             const int threads = (Y.nr > 0 && (double)Y.nnz / Y.nr >= 96.0) ? 256 : 64;
             hipLaunchKernelGGL(k_spgemm_rows, dim3(std::min(nr, 16384)), dim3(threads), lds,
                                ctx->stream, nr, nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense,
-                               rowcnt);
+                               rowcnt, rowbits);
             IPD_KERNEL_CHECK();
         }
     }
@@ -604,7 +646,8 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
     out.va = dst.alloc<double>((size_t)out.nnz);
     if (out.nnz) {
         hipLaunchKernelGGL(k_dense_compact, dim3(std::max(1, std::min(cdiv(nr, 4), 4096))), dim3(256),
-                           0, ctx->stream, nr, nc, ld, dense, out.rp, out.ci, out.va);
+                           0, ctx->stream, nr, nc, ld, dense, (const unsigned long long*)rowbits, out.rp, out.ci,
+                           out.va);
         IPD_KERNEL_CHECK();
     }
     *C = out;
