@@ -53,20 +53,6 @@ __global__ __launch_bounds__(BT) void k_top(TopArgs a) {
 }
 
 // padded off-diagonal copy of a CSR matrix: one wave per row
-__global__ __launch_bounds__(256) void k_offdiag_maxlen(int N, const int* __restrict__ rp,
-                                                        const int* __restrict__ ci,
-                                                        int* __restrict__ maxlen) {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int r = wave; r < N; r += nwaves) {
-        int hasd = 0;
-        for (int t = rp[r] + lane; t < rp[r + 1]; t += 64) hasd |= (ci[t] == r);
-        hasd = __any(hasd) ? 1 : 0;
-        if (lane == 0) atomicMax(maxlen, rp[r + 1] - rp[r] - hasd);
-    }
-}
-
 __global__ __launch_bounds__(256) void k_pad_build(int N, int S, const int* __restrict__ rp,
                                                    const int* __restrict__ ci,
                                                    const double* __restrict__ va,

@@ -56,25 +56,34 @@ static CycleState* state_of(ipd_amg* h) { return h->cyc.get(); }
 
 __global__ void k_level_prepare(int N, int nf, const int* __restrict__ rp,
                                 const int* __restrict__ ci, const double* __restrict__ va,
-                                double* __restrict__ dinv, double* __restrict__ Axi) {
-    // one wave per row: diagonal -> Rk, row sum -> A*1
+                                double* __restrict__ dinv, double* __restrict__ Axi,
+                                int* __restrict__ maxoff) {
+    // one wave per row: diagonal -> Rk, row sum -> A*1, longest off-diagonal row -> maxoff
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    int longest = 0;
     for (int r = wave; r < N; r += nwaves) {
         double s = 0.0, dg = 0.0;
+        int hasd = 0;
         for (int t = rp[r] + lane; t < rp[r + 1]; t += 64) {
             s += va[t];
-            if (ci[t] == r) dg = va[t];
+            if (ci[t] == r) {
+                dg = va[t];
+                hasd = 1;
+            }
         }
         s = wave_sum(s);
         dg = wave_sum(dg);
+        hasd = __any(hasd) ? 1 : 0;
+        longest = max(longest, rp[r + 1] - rp[r] - hasd);
         if (lane == 0) {
             Axi[r] = s;
             // Class_AMG.m:56-59 (1./diag) for the bigraph GS, :72/:84 (0.5*(1./diag)) otherwise
             dinv[r] = nf > 0 ? 1.0 / dg : 0.5 * (1.0 / dg);
         }
     }
+    if (lane == 0 && longest > 0) atomicMax(maxoff, longest);
 }
 
 static int pick_blocks(int nrows, int L, int cu);
@@ -82,6 +91,7 @@ static int pick_blocks(int nrows, int L, int cu);
 // Builds the padded off-diagonal copy when the level is big and regular enough
 // (see ipd_cycle_phases.h, item 2) and adapts the launch geometry to it.
 static void build_padded(ipd_ctx* ctx, Arena& ar, const Csr& A, int rows_per_launch, int cu,
+                         int maxlen /* longest off-diagonal row, from k_level_prepare */,
                          LevelDev* dev) {
     dev->S = 0;
     dev->pci = nullptr;
@@ -96,13 +106,7 @@ static void build_padded(ipd_ctx* ctx, Arena& ar, const Csr& A, int rows_per_lau
     double min_avg = 0.5;
     if (const char* e = std::getenv("IPD_PAD_MINAVG")) min_avg = std::atof(e);
     if (avg_off < min_avg) return;
-    int* dmax = ctx->scratch->alloc<int>(1);
-    IPD_HIP(hipMemsetAsync(dmax, 0, sizeof(int), ctx->stream));
     const int grid = std::max(1, std::min(cdiv(A.nr, 4), 4096));
-    hipLaunchKernelGGL(k_offdiag_maxlen, dim3(grid), dim3(256), 0, ctx->stream, A.nr, A.rp, A.ci,
-                       dmax);
-    IPD_KERNEL_CHECK();
-    const int maxlen = ctx->fetch1(dmax);
     const int S = (maxlen + 3) / 4 * 4;
     if (S == 0 || (double)S > 1.3 * avg_off + 16.0) return;
     unsigned short* pci = ar.alloc<unsigned short>((size_t)A.nr * S);
@@ -136,6 +140,10 @@ void amg_prepare_levels(ipd_amg* h) {
     std::unique_ptr<CycleState> st(new CycleState());
     st->run.resize((size_t)h->J + 1);
     const int cu = ctx->num_cu;
+    // first pass: per-level vectors and the longest off-diagonal row of every level (one
+    // readback for all levels), second pass: padded copies and launch geometry
+    int* maxoff = ctx->scratch->alloc<int>((size_t)h->J + 1);
+    IPD_HIP(hipMemsetAsync(maxoff, 0, sizeof(int) * ((size_t)h->J + 1), ctx->stream));
     for (int k = 1; k <= h->J; ++k) {
         Level& lv = h->L[k];
         const int N = lv.A.nr;
@@ -151,11 +159,18 @@ void amg_prepare_levels(ipd_amg* h) {
         lv.w = ar.alloc<double>((size_t)N);
         lv.rr = ar.alloc<double>((size_t)N);
         hipLaunchKernelGGL(k_level_prepare, dim3(std::max(1, std::min(cdiv(N, 4), 4096))), dim3(256),
-                           0, ctx->stream, N, lv.nf, lv.A.rp, lv.A.ci, lv.A.va, lv.dinv, lv.Axi);
+                           0, ctx->stream, N, lv.nf, lv.A.rp, lv.A.ci, lv.A.va, lv.dinv, lv.Axi,
+                           maxoff + k);
         IPD_KERNEL_CHECK();
         hipLaunchKernelGGL(k_vec_sum, dim3(1), dim3(BT), 0, ctx->stream, (const double*)lv.Axi, N,
                            lv.xx);
         IPD_KERNEL_CHECK();
+    }
+    std::vector<int> hmax((size_t)h->J + 1);
+    ctx->fetch(maxoff, hmax.data(), (size_t)h->J + 1);
+    for (int k = 1; k <= h->J; ++k) {
+        Level& lv = h->L[k];
+        const int N = lv.N;
         // launch geometry: for a GS level the work per launch is half the matrix
         const int rows_per_launch = lv.nf > 0 ? std::max(1, N / 2) : N;
         const long long nnz_per_launch = lv.nf > 0 ? std::max(1, lv.A.nnz / 2) : lv.A.nnz;
@@ -178,7 +193,7 @@ void amg_prepare_levels(ipd_amg* h) {
             const char* ns = std::getenv("IPD_NO_STAGE");
             if (ns && ns[0] == '1') rn.staged = 0;
         }
-        build_padded(ctx, ar, lv.A, rows_per_launch, cu, &rn.dev);
+        build_padded(ctx, ar, lv.A, rows_per_launch, cu, hmax[(size_t)k], &rn.dev);
     }
     for (int k = 1; k < h->J; ++k) {
         Level& fine = h->L[k];
