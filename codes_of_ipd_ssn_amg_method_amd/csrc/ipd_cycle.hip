@@ -483,7 +483,7 @@ static int pick_lanes(long long nnz, int nrows, int blocks_target) {
     if (nrows <= 0) return 1;
     const double avg = (double)nnz / (double)nrows;
     int L = 1;  // short rows: one lane walks the whole row in a single ROW_U batch
-    while (L < BT && (double)L * 6.0 < avg) L <<= 1;
+    while (L < BT && (double)L * (0.75 * ROW_U) < avg) L <<= 1;
     // widen while most of the chip would idle (tools/ubench_small.hip: a 1024-row launch of
     // short rows costs the same 6.5 us on 1, 4 or 16 workgroups, so spreading is free and
     // keeps one CU's load-issue rate from becoming the limit)

@@ -24,7 +24,10 @@
 //      launches, deterministic, and reduced in the same LDS exchange as the rows.
 #pragma once
 
-static constexpr int ROW_U = 8;          // matrix entries in flight per lane and batch
+// matrix entries in flight per lane and batch (one 4-entry vector of the padded format).
+// 8 was slower on every workload (m=n=1024 Class 1 run 1.58 -> 1.55 s, tree-mask W cycle
+// 0.532 -> 0.503 ms): short rows fill 3-6 of the slots and the rest are clamped dummy loads.
+static constexpr int ROW_U = 4;
 static constexpr int STAGE_MAX = 7680;   // vector entries staged in LDS (60 KiB)
 
 // LDS scratch of a phase
@@ -213,10 +216,16 @@ __device__ __forceinline__ void block_totals_to(double v0, double* dst0, double 
     }
 }
 
-// Visit j = tid, tid+BT, ... < N with the loads of VEC_U visits issued together
-// (a plain loop would wait for each iteration's loads before issuing the next:
-// one memory round trip per iteration).
-static constexpr int VEC_U = 4;
+// Visit j = tid, tid+BT, ... < N, VEC_U visits per trip with their loads issued together.
+// Measured on MI355X (m=n=1024 Class 1 run / regime-D V cycle / tree-mask W cycle):
+//   VEC_U = 8: 1.85 s / 0.239 ms / 0.648 ms     4: 1.70 / 0.222 / 0.572
+//           2: 1.60 / 0.214 / 0.540             1: 1.58 / 0.211 / 0.532
+// The plain loop wins: the clamped unconditional loads of a wide trip cost more issue slots and
+// registers than the overlap buys (the compiler already overlaps the loads of a simple loop).
+#ifndef IPD_VEC_U
+#define IPD_VEC_U 1
+#endif
+static constexpr int VEC_U = IPD_VEC_U;
 template <class LOAD, class USE>
 __device__ __forceinline__ void vec_pass(int N, LOAD load, USE use) {
     for (int j0 = threadIdx.x; j0 < N; j0 += BT * VEC_U) {
