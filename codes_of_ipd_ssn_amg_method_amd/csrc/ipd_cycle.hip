@@ -942,22 +942,32 @@ __device__ __forceinline__ int lanes_per_row(int rows) {
 // every lane of the group returns the full sum.  Entries go four at a time with the last batch
 // masked instead of a one-by-one remainder loop: most rows of these levels hold fewer than
 // 4*Lr entries, and the remainder loop paid two dependent LDS round trips per entry.
+#ifndef IPD_LDS_ROW_U
+#define IPD_LDS_ROW_U 2
+#endif
+static constexpr int LDS_ROW_U = IPD_LDS_ROW_U;   // entries per lane and trip of the LDS row walk
 __device__ __forceinline__ double lds_rowdot_split(AS3 const int* rp, AS3 const int* ci,
                                                    AS3 const double* va, int row, int sub, int Lr,
                                                    bool valid, AS3 const double* x) {
     double s = 0.0;
     if (valid) {
         const int beg = rp[row], end = rp[row + 1];
-        for (int t = beg + sub; t < end; t += 4 * Lr) {
-            const int t1 = t + Lr, t2 = t + 2 * Lr, t3 = t + 3 * Lr;
-            const bool k1 = t1 < end, k2 = t2 < end, k3 = t3 < end;
-            const int c0 = ci[t], c1 = ci[k1 ? t1 : t], c2 = ci[k2 ? t2 : t], c3 = ci[k3 ? t3 : t];
-            const double v0 = va[t], v1 = va[k1 ? t1 : t], v2 = va[k2 ? t2 : t], v3 = va[k3 ? t3 : t];
-            const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-            s += v0 * x0;
-            if (k1) s += v1 * x1;
-            if (k2) s += v2 * x2;
-            if (k3) s += v3 * x3;
+        for (int t = beg + sub; t < end; t += LDS_ROW_U * Lr) {
+            int c[LDS_ROW_U];
+            double v[LDS_ROW_U], xv[LDS_ROW_U];
+            bool k[LDS_ROW_U];
+#pragma unroll
+            for (int u = 0; u < LDS_ROW_U; ++u) {
+                const int tu = t + u * Lr;
+                k[u] = tu < end;
+                c[u] = ci[k[u] ? tu : t];
+                v[u] = va[k[u] ? tu : t];
+            }
+#pragma unroll
+            for (int u = 0; u < LDS_ROW_U; ++u) xv[u] = x[c[u]];
+#pragma unroll
+            for (int u = 0; u < LDS_ROW_U; ++u)
+                if (k[u]) s += v[u] * xv[u];
         }
     }
     return subwave_sum(s, Lr);

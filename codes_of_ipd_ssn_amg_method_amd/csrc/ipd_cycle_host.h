@@ -825,16 +825,28 @@ __global__ void k_maskop_scales(int nf, int nc, const double* __restrict__ p,
 
 // Derives the bit-mask form of level 1 from its CSR arrays; keeps the CSR kernels (returns
 // false) unless A_1 is exactly Hybrid_AMG's rescaled operator for these p, q, tk.
-bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int m, int n, double tk) {
+//
+// When it pays (`policy` true: the solvers' own call): the mask sweep moves 13x fewer bytes but is
+// the slower launch while the level is latency-bound -- regime D at m = n = 1024 (2.1 M entries):
+// 5.7 us against 5.2 us for the padded CSR sweep -- and the faster one once the CSR sweep is
+// bandwidth-bound -- m = n = 2048 (8.4 M entries): 8.3 us against 13.4 us.  The solvers therefore
+// attach it from 4 M entries on; IPD_MASKOP=1 lowers that to 16 entries per row, IPD_NO_MASKOP=1
+// switches it off.  An explicit ipd_amg_attach_mask_operator call is not subject to the policy.
+bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int m, int n, double tk,
+                       bool policy) {
     ipd_ctx* ctx = h->ctx;
     CycleState* st = state_of(h);
     if (!st) return false;
-    const char* env = std::getenv("IPD_NO_MASKOP");
-    if (env && env[0] == '1') return false;
     const Level& lv = h->L[1];
+    if (policy) {
+        const char* off = std::getenv("IPD_NO_MASKOP");
+        if (off && off[0] == '1') return false;
+        const char* on = std::getenv("IPD_MASKOP");
+        if (!(on && on[0] == '1') && (double)lv.A.nnz < 4.0e6) return false;
+    }
     if (h->J < 2 || lv.nf != n || lv.N != m + n || tk == 0.0) return false;
     // a row of the mask costs nw word walks whatever its population: with fewer than ~16 entries
-    // per row the padded CSR sweep (4.9 us) beats it (5.7 us)
+    // per row the padded CSR sweep always beats it
     if ((double)lv.A.nnz < 16.0 * lv.N) return false;
     if (std::max(m, n) > 4096) return false;   // a row's mask words must fit one wave (64 words)
     Arena& ar = *h->arena;
@@ -881,7 +893,7 @@ extern "C" int ipd_amg_attach_mask_operator(ipd_amg* h, const double* p_dev, con
         IPD_REQUIRE(h && p_dev && q_dev && m > 0 && n > 0, IPD_E_ARG, "bad argument");
         h->ctx->set_device();
         CallScope scope(h->ctx);
-        const bool ok = amg_attach_maskop(h, p_dev, q_dev, (int)m, (int)n, tk);
+        const bool ok = amg_attach_maskop(h, p_dev, q_dev, (int)m, (int)n, tk, false);
         if (attached) *attached = ok ? 1 : 0;
     });
 }

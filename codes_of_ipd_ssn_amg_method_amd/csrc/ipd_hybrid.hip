@@ -439,7 +439,8 @@ static std::function<void(int*, double*)> class_amg_prepare(
         ProfScope ps(ctx, PROF_AMG_SETUP);
         std::unique_ptr<ipd_amg, void (*)(ipd_amg*)> fresh(amg_setup(ctx, A, o, rng), ipd_amg_destroy);
         h = fresh.get();
-        if (mh.p && o.bigph) amg_attach_maskop(h, mh.p, mh.q, mh.m, mh.n, mh.tk);
+        // matrix-free level 1 where it pays (policy in amg_attach_maskop)
+        if (mh.p && o.bigph) amg_attach_maskop(h, mh.p, mh.q, mh.m, mh.n, mh.tk, true);
         if (cache)
             cache->hier.push_back(std::move(fresh));
         else

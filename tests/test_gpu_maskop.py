@@ -78,3 +78,21 @@ def test_mask_operator_rejects_other_matrices():
     r = np.random.RandomState(2).standard_normal(m + n)
     x, it, rr, _, _ = hb.solve(r - r.mean(), np.zeros(m + n))
     assert rr <= 1e-10
+
+
+def test_hybrid_amg_with_mask_operator(monkeypatch):
+    """IPD_MASKOP=1 lets Hybrid_AMG attach the operator itself (dense mask, multi-launch path):
+    same routing and cycle count as the CSR sweeps, solutions equal to solver tolerance."""
+    import codes_of_ipd_ssn_amg_method_amd as ipd
+    m = n = 96
+    s = PR.mask_bernoulli(m, n, 0.8, seed=3)
+    pd = PR.make_prob(m, n, s, pq_random=True)
+    pd["H0"] = O.ASAt(s, pd["p"], pd["q"])
+    opts = O.amg_options_class1("w")
+    monkeypatch.setenv("IPD_NO_SMALL", "1")
+    z0, it0, res0, info0 = ipd.Hybrid_AMG(pd, opts, ipd.MatlabRand())
+    monkeypatch.setenv("IPD_MASKOP", "1")
+    z1, it1, res1, info1 = ipd.Hybrid_AMG(pd, opts, ipd.MatlabRand())
+    assert np.array_equal(info0, info1) and abs(it0 - it1) <= 1
+    assert res1 <= 1e-10
+    assert np.linalg.norm(z1 - z0) <= 1e-8 * max(1.0, np.linalg.norm(z0))

@@ -21,7 +21,7 @@ python3 tools/summarize_pmc.py $OUT/${R}_pmc_summary.json FETCH_SIZE=$F WRITE_SI
 cp $OUT/${R}_pmc_summary.json profiles/${R}_pmc_summary.json
 cp $S $OUT/${R}_kernel_stats.csv
 timeout -k 10 400 python3 bench.py 2>/dev/null | tail -1 > $OUT/${R}_bench_n1.json || exit 1
-timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-maskop 2>/dev/null | tail -1 > $OUT/${R}_bench_n1_csr_level1.json
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --maskop 2>/dev/null | tail -1 > $OUT/${R}_bench_n1_maskop.json
 timeout -k 10 300 python3 bench.py --no-cpu-baseline --mask tree 2>/dev/null | tail -1 > $OUT/${R}_bench_tree_v.json
 timeout -k 10 300 python3 bench.py --no-cpu-baseline --mask tree --cycle w 2>/dev/null | tail -1 > $OUT/${R}_bench_tree_w.json
 timeout -k 10 300 python3 bench.py --no-cpu-baseline --mask hub --cycle w 2>/dev/null | tail -1 > $OUT/${R}_bench_hub_w.json
