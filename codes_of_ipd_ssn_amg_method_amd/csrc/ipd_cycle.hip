@@ -477,13 +477,19 @@ __global__ __launch_bounds__(BT) void k_fused(FusedProg prog) {
     }
 }
 
-// lanes per row: 3..6 entries per lane (one ROW_U batch), widened while the launch
+// lanes per row: about 2 entries per lane (half a ROW_U batch), widened while the launch
 // would leave most of the chip idle
 static int pick_lanes(long long nnz, int nrows, int blocks_target) {
     if (nrows <= 0) return 1;
     const double avg = (double)nnz / (double)nrows;
     int L = 1;  // short rows: one lane walks the whole row in a single ROW_U batch
-    while (L < BT && (double)L * (0.75 * ROW_U) < avg) L <<= 1;
+    static const double per_lane = [] {
+        // mean entries per lane aimed at.  m=n=1024 driver runs (Class 1 / Class 2):
+        // 1.5: 1.54 / 0.75 s, 2: 1.52 / 0.73, 3: 1.55 / 0.75, 4: 1.61 / 0.80, 6: 1.62 / 0.81
+        const char* e = std::getenv("IPD_LANE_ENTRIES");
+        return e ? std::atof(e) : 0.5 * ROW_U;
+    }();
+    while (L < BT && (double)L * per_lane < avg) L <<= 1;
     // widen while most of the chip would idle (tools/ubench_small.hip: a 1024-row launch of
     // short rows costs the same 6.5 us on 1, 4 or 16 workgroups, so spreading is free and
     // keeps one CU's load-issue rate from becoming the limit)
