@@ -172,7 +172,48 @@ struct PcgArgs {
     long long nresk;
 };
 
+// A 1x1 coarsest level (dense masks: levels 2048 / 1024 / 1) through the block-wide reductions
+// costs ~10 us per cycle for five multiplications; one thread runs the same recurrence in
+// registers.  Every block sum of the general path has a single nonzero term here, so the bits
+// are the same.
+__device__ __forceinline__ void pcg_single(const PcgArgs& a) {
+    if (threadIdx.x == 0) {
+        double h = 0.0;   // H(1,1); a structurally empty row leaves it 0 as the general path does
+        for (int t = a.rp[0]; t < a.rp[1]; ++t)
+            if (a.ci[t] == 0) h = a.va[t];
+        const double g0 = a.guess ? a.guess[0] : 0.0;
+        double r = a.rhs[0] - (a.guess ? h * g0 : 0.0);                         // :68
+        double p = a.precd == 2 ? r / h : r;
+        double d = g0;
+        double delta_new = r * p;
+        const double delta_0 = delta_new, thresh = a.tol * a.tol * delta_0;
+        long long it = 0;
+        while (it < a.maxit && delta_new > thresh) {                            // :76
+            const double delta_old = delta_new;
+            const double q = h * p;
+            const double alpha = delta_old / (q * p);                           // :78
+            d += alpha * p;
+            r = r - alpha * q;                                                  // :79
+            const double w = a.precd == 2 ? r / h : r;                          // :80
+            delta_new = r * w;                                                  // :81
+            p = w + (delta_new / delta_old) * p;                                // :82-83
+            ++it;
+            if (a.out && it <= a.nresk) a.out[1 + it] = sqrt(fabs(delta_new / delta_0));
+        }
+        a.d[0] = d;
+        if (a.out) {
+            a.out[0] = (double)it;
+            a.out[1] = sqrt(fabs(delta_new / delta_0));
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void pcg_block(const PcgArgs& a, double* red) {
+    if (a.N == 1) {
+        pcg_single(a);
+        return;
+    }
     const int tid = threadIdx.x;
     const int N = a.N, L = a.L, gpb = BT / L;
     const int g = tid / L, gl = tid - g * L;
