@@ -4,7 +4,13 @@
 
 #include <hip/hip_runtime.h>
 
-static constexpr int BT = 1024;  // threads per block of every phase kernel
+// threads per block of every phase kernel and of the single-workgroup kernels (their helpers
+// share the block reductions, so it is one constant).  Measured, 1024 -> 512: regime-D V cycle
+// 0.194 -> 0.190 ms, tree-mask W cycle 0.503 -> 0.431 ms, m=n=1024 Class 1 / Class 2 driver runs
+// 1.53 / 0.74 -> 1.47 / 0.70 s, m=n=4096 Class 1 5.33 -> 4.97 s (only the bandwidth-bound
+// m=n=2048 regime-D cycle loses: 0.328 -> 0.342 ms); 256: 0.234 ms and the sub-cycle kernel no
+// longer takes 300-1000-row roots (Class 1 run 20 s).
+static constexpr int BT = 512;
 
 // ---------------------------------------------------------------------------
 // device-side level descriptor
