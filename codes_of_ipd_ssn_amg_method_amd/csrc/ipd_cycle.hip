@@ -526,7 +526,7 @@ static int pick_lanes(long long nnz, int nrows, int blocks_target) {
     int L = 1;  // short rows: one lane walks the whole row in a single ROW_U batch
     // mean entries per lane aimed at.  Short rows (the realistic levels): 2 -- m=n=1024 driver
     // runs, Class 1 / Class 2: 1.5: 1.54 / 0.75 s, 2: 1.52 / 0.73, 3: 1.55 / 0.75, 4: 1.61 / 0.80,
-    // 6: 1.62 / 0.81.  Long rows (dense masks): 6 -- with 2 the 512..1024-entry rows of the
+    // 6: 1.62 / 0.81.  Long rows (dense masks): 12 -- with 2 the 512..1024-entry rows of the
     // regime-D transfers spread over 512-1024 lanes and the cross-wave reduction costs more than
     // the shorter walk saves (k_xfer 6.6 -> 10.0 us, V cycle 0.200 -> 0.206 ms).
     static const double forced = [] {
@@ -539,7 +539,8 @@ static int pick_lanes(long long nnz, int nrows, int blocks_target) {
     }();
     // regime D, m=n=1024 / 2048, ms per V cycle: 3: 0.2007 / 0.387, 4.5: 0.1968 / 0.378,
     // 6: 0.1960 / 0.376, 9: 0.1975 / 0.374, 17: 0.1969 / 0.370
-    const double long_rows = forced_long > 0.0 ? forced_long : 1.5 * ROW_U;
+    // (with 512-thread blocks: 6: 0.1903 / 0.337, 12: 0.1866 / 0.324, 24: 0.1891 / 0.320)
+    const double long_rows = forced_long > 0.0 ? forced_long : 3.0 * ROW_U;
     const double per_lane = forced > 0.0 ? forced : (avg >= 64.0 ? long_rows : 0.5 * ROW_U);
     while (L < BT && (double)L * per_lane < avg) L <<= 1;
     // widen while most of the chip would idle (tools/ubench_small.hip: a 1024-row launch of

@@ -125,7 +125,8 @@ static void build_padded(ipd_ctx* ctx, Arena& ar, const Csr& A, int rows_per_lau
     // batches per lane aimed at before the chip-filling rule below widens again.  Regime D at
     // m=n=2048 (2048-entry rows, bandwidth-bound): 1: 0.376 ms per V cycle, 2: 0.342, 4: 0.332,
     // 8/16: 0.332; m=n=1024 unchanged (0.197), m=n=4096 Class 1 run 5.37 -> 5.29 s
-    int batches = 4;
+    // (with 512-thread blocks: 4: 0.337, 8: 0.324-0.330, 16: 0.325)
+    int batches = 8;
     if (const char* e = std::getenv("IPD_PAD_BATCHES")) batches = std::max(1, std::atoi(e));
     while (L < BT && L * (ROW_U / 4) * batches < nvec) L <<= 1;
     double fill = 1.0;   // one workgroup per CU (0.5 left half the chip idle on a 1024-row level: 6.16 -> 5.79 us)
