@@ -220,10 +220,13 @@ __device__ __forceinline__ void block_totals_to(double v0, double* dst0, double 
 // Measured on MI355X (m=n=1024 Class 1 run / regime-D V cycle / tree-mask W cycle):
 //   VEC_U = 8: 1.85 s / 0.239 ms / 0.648 ms     4: 1.70 / 0.222 / 0.572
 //           2: 1.60 / 0.214 / 0.540             1: 1.58 / 0.211 / 0.532
-// The plain loop wins: the clamped unconditional loads of a wide trip cost more issue slots and
-// registers than the overlap buys (the compiler already overlaps the loads of a simple loop).
+// (1024-thread blocks: the narrower the better.)  With 512-thread blocks a thread visits twice
+// as many entries and two per trip is the best balance:
+//   VEC_U = 1: 1.52 s / 0.188 ms / 0.434 ms     2: 1.49 / 0.181 / 0.428     4: 1.50 / 0.185 / 0.448
+// Wide trips lose because their clamped unconditional loads cost more issue slots and registers
+// than the overlap buys.
 #ifndef IPD_VEC_U
-#define IPD_VEC_U 1
+#define IPD_VEC_U 2
 #endif
 static constexpr int VEC_U = IPD_VEC_U;
 template <class LOAD, class USE>
