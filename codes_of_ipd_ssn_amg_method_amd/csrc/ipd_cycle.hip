@@ -22,6 +22,7 @@
 #include "ipd_amg_internal.h"
 
 #include <cmath>
+#include <mutex>
 
 #include "ipd_cycle_dev.h"
 #include "ipd_cycle_phases.h"
@@ -1750,4 +1751,5 @@ __global__ __launch_bounds__(BT) void k_subcycle(const SolveDesc* __restrict__ D
     for (int i = threadIdx.x; i < N0; i += BT) ge[i] = res[i];
 }
 
+#include "ipd_resident.h"
 #include "ipd_cycle_host.h"

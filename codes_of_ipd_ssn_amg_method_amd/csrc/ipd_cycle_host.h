@@ -44,6 +44,16 @@ struct CycleState {
     int k_sub = 0;
     size_t sub_lds = 0;
     double* x2 = nullptr;
+    // level-resident solve kernel (ipd_resident.h): the whole Class_AMG loop in one launch of
+    // res_G co-resident workgroups that keep the matrices of levels 1-2 in registers
+    bool res_ok = false;
+    ResDesc res_desc{};
+    int res_G = 0;
+    int res_ke = 0;          // entries per lane of a padded row (template argument)
+    size_t res_lds = 0;
+    double* res_out = nullptr;
+    unsigned char* res_block = nullptr;   // [gran0 | gran1 | tmo]: zeroed before every launch
+    int res_timeouts = 0;    // launches whose bounded spins gave up (then: multi-launch path)
     hipGraphExec_t gexec[2] = {nullptr, nullptr};  // captured Class_AMG loop bodies (x->x2, x2->x)
     const double* gb = nullptr;                    // right-hand side the graphs were captured for
     ~CycleState() {
@@ -138,6 +148,142 @@ static void build_padded(ipd_ctx* ctx, Arena& ar, const Csr& A, int rows_per_lau
 
 static int pick_blocks(int nrows, int L, int cu) {
     return (int)std::max<long long>(1, std::min<long long>(cu, ((long long)nrows * L + BT - 1) / BT));
+}
+
+
+// ---- level-resident solve kernel: eligibility and launch ---------------------------------
+// Eligible: three levels -- a bigraph Gauss-Seidel level 1 and a Jacobi level 2 with padded
+// rows of at most 1024 entries, at most 2048 rows each, and a tail level of at most 64 rows --
+// i.e. the dense regimes (regime D), where each launch of the multi-launch path is
+// latency-bound.  IPD_NO_RESIDENT=1 switches it off, IPD_RESIDENT_G overrides the grid.
+static void plan_resident(ipd_amg* h, CycleState* st) {
+    st->res_ok = false;
+    if (const char* e = std::getenv("IPD_NO_RESIDENT"); e && e[0] == '1') return;
+    if (st->small_ok || h->J != 3 || h->opts.twogrid) return;
+    const Level& l1 = h->L[1];
+    const Level& l2 = h->L[2];
+    const Level& l3 = h->L[3];
+    const LevelDev& d1 = st->run[1].dev;
+    const LevelDev& d2 = st->run[2].dev;
+    const int N1 = l1.A.nr, N2 = l2.A.nr, Nt = l3.A.nr, nf = l1.nf, nc = N1 - nf;
+    if (nf <= 0 || nc <= 0 || d1.S <= 0 || d2.S <= 0) return;
+    if (N1 > 4 * BT || N2 > 4 * BT || nf > 2 * BT || nc > 2 * BT || Nt > RES_TAIL_MAX || Nt < 1) return;
+    const int smax = std::max(d1.S, d2.S);
+    int ke = 4;
+    while (64 * ke < smax) ke <<= 1;
+    if (ke > 16) return;
+    int G = std::max(cdiv(std::max(nf, nc), RES_WAVES), cdiv(N2, RES_WAVES));
+    if (const char* e = std::getenv("IPD_RESIDENT_G")) G = std::max(G, std::atoi(e));
+    // every workgroup owns at least one row of every block (the hand-off protocol needs it)
+    if (G > st->num_cu || G > std::min(std::min(nf, nc), N2)) return;
+    const size_t lds = RES_LDS_BYTES;
+    Arena& ar = *h->arena;
+    ResDesc D{};
+    auto lev = [](const LevelDev& d) {
+        ResLevelDesc L;
+        L.N = d.N;
+        L.nf = d.nf;
+        L.S = d.S;
+        L.pci = d.pci;
+        L.pva = d.pva;
+        L.diag = d.diag;
+        L.dinv = d.dinv;
+        L.Axi = d.Axi;
+        L.xx = d.xx;
+        return L;
+    };
+    auto csr = [](const Csr& m) {
+        ResCsr c;
+        c.rp = m.rp;
+        c.ci = m.ci;
+        c.va = m.va;
+        return c;
+    };
+    D.L1 = lev(d1);
+    D.L2 = lev(d2);
+    D.Pt2 = csr(l2.Pt);
+    D.P2 = csr(l2.P);
+    D.Pt3 = csr(l3.Pt);
+    D.P3 = csr(l3.P);
+    D.A3 = csr(l3.A);
+    D.Nt = Nt;
+    D.nu = h->opts.smoth;
+    D.isnsp = h->opts.isnsp;
+    D.wcycle = h->opts.cycle == 'w';
+    D.anycycle = (h->opts.cycle == 'w' || h->opts.cycle == 'v');
+    D.maxit = h->opts.maxit;
+    D.retol = h->opts.retol;
+    D.pcg_maxit = h->opts.pcg_maxit;
+    const size_t gbytes = (size_t)RES_GRAN_MAX * 16;
+    st->res_block = reinterpret_cast<unsigned char*>(ar.alloc_bytes(2 * gbytes + 16));
+    D.gran0 = st->res_block;
+    D.gran1 = st->res_block + gbytes;
+    D.tmo = reinterpret_cast<unsigned*>(st->res_block + 2 * gbytes);
+    D.dbg = nullptr;
+    st->res_desc = D;
+    st->res_G = G;
+    st->res_ke = ke;
+    st->res_lds = lds;
+    st->res_out = ar.alloc<double>(4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2));
+    st->res_ok = true;
+}
+
+// One resident kernel at a time per device: two of them would each hold part of the CUs and
+// wait for workgroups that cannot start (the spins are bounded, but the launch would be lost).
+static std::mutex& resident_mutex(int device) {
+    static std::mutex m[64];
+    return m[device & 63];
+}
+
+// Runs the whole solve (fixed_cycles == 0) or exactly fixed_cycles loop bodies on the
+// iterate in x (in: guess, out: result).  Returns false when the kernel could not be used
+// (another resident kernel is running, or a spin gave up): x is then unspecified and the
+// caller takes the multi-launch path.  `ms`: device time of the launch (HIP events), optional.
+static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double* x, int fixed_cycles,
+                         std::vector<double>* out_host, float* ms, long long* dbg_dev = nullptr) {
+    ipd_ctx* ctx = h->ctx;
+    std::unique_lock<std::mutex> lock(resident_mutex(ctx->device), std::try_to_lock);
+    if (!lock.owns_lock()) return false;
+    ResDesc D = st->res_desc;
+    D.dbg = dbg_dev;
+    IPD_HIP(hipMemsetAsync(st->res_block, 0, 2 * (size_t)RES_GRAN_MAX * 16 + 16, ctx->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ms) {
+        IPD_HIP(hipEventCreate(&e0));
+        IPD_HIP(hipEventCreate(&e1));
+        IPD_HIP(hipEventRecord(e0, ctx->stream));
+    }
+#define IPD_RES_LAUNCH(KE)                                                                          \
+    do {                                                                                            \
+        IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resident<KE, KE>),              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));       \
+        hipLaunchKernelGGL((k_resident<KE, KE>), dim3(st->res_G), dim3(BT), st->res_lds, ctx->stream, \
+                           D, b_dev, x, st->res_out, fixed_cycles);                                 \
+    } while (0)
+    if (st->res_ke == 4)
+        IPD_RES_LAUNCH(4);
+    else if (st->res_ke == 8)
+        IPD_RES_LAUNCH(8);
+    else
+        IPD_RES_LAUNCH(16);
+#undef IPD_RES_LAUNCH
+    IPD_KERNEL_CHECK();
+    if (ms) IPD_HIP(hipEventRecord(e1, ctx->stream));
+    const size_t nout = 4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2);
+    std::vector<double> out(nout);
+    ctx->fetch(st->res_out, out.data(), nout);   // synchronises the stream
+    if (ms) {
+        IPD_HIP(hipEventElapsedTime(ms, e0, e1));
+        IPD_HIP(hipEventDestroy(e0));
+        IPD_HIP(hipEventDestroy(e1));
+    }
+    if (out[3] != 0.0) {   // a bounded spin gave up: not every workgroup was resident
+        ++st->res_timeouts;
+        if (st->res_timeouts >= 2) st->res_ok = false;
+        return false;
+    }
+    if (out_host) *out_host = std::move(out);
+    return true;
 }
 
 void amg_prepare_levels(ipd_amg* h) {
@@ -629,8 +775,10 @@ void amg_prepare_levels(ipd_amg* h) {
             }
         }
     }
+    plan_resident(h, st.get());
     if (const char* dbg = std::getenv("IPD_DEBUG_LEVELS"); dbg && dbg[0] == '1') {
-        std::fprintf(stderr, "[ipd] J=%d small=%d k_sub=%d levels:", h->J, (int)st->small_ok, st->k_sub);
+        std::fprintf(stderr, "[ipd] J=%d small=%d k_sub=%d resident=%d(G=%d,KE=%d) levels:", h->J,
+                     (int)st->small_ok, st->k_sub, (int)st->res_ok, st->res_G, st->res_ke);
         for (int k = 1; k <= h->J; ++k) std::fprintf(stderr, " %d/%d", h->L[k].A.nr, h->L[k].A.nnz);
         std::fprintf(stderr, "\n");
     }
@@ -1083,6 +1231,28 @@ void amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev, dou
         ctx->sync();
         return;
     }
+    if (st->res_ok && st->shard_ranks == 1) {
+        // dense regime: the whole solve phase is one launch of co-resident workgroups
+        std::vector<double> out;
+        if (run_resident(h, st, b_dev, xa, 0, &out, nullptr)) {
+            const int its = (int)out[0];
+            if (rel_resk) std::memcpy(rel_resk, out.data() + 4, sizeof(double) * ((size_t)its + 1));
+            if (rhok) std::memcpy(rhok, out.data() + 4 + (o.maxit + 2), sizeof(double) * ((size_t)its + 1));
+            if (x_dev)
+                IPD_HIP(hipMemcpyAsync(x_dev, xa, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                                       ctx->stream));
+            if (it_out) *it_out = its;
+            if (rel_res_out) *rel_res_out = out[1];
+            ctx->sync();
+            return;
+        }
+        // not usable right now: restore the initial guess and take the multi-launch path
+        if (guess_dev)
+            IPD_HIP(hipMemcpyAsync(xa, guess_dev, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+        else
+            IPD_HIP(hipMemsetAsync(xa, 0, sizeof(double) * (size_t)N, ctx->stream));
+    }
     launch_top(h, st, b_dev, xa, nullptr, xb, true);                            // :89
     std::swap(xa, xb);
     double hh[5];
@@ -1274,6 +1444,41 @@ extern "C" int ipd_amg_cycle_bytes(const ipd_amg* h, double* bytes_per_cycle) {
     return IPD_OK;
 }
 
+extern "C" int ipd_amg_solve_mode(const ipd_amg* h, int32_t* mode, int32_t* grid, int32_t* timeouts) {
+    if (!h || !mode) return IPD_E_ARG;
+    const CycleState* st = h->cyc.get();
+    if (!st) return IPD_E_ARG;
+    *mode = st->small_ok ? 1 : (st->res_ok ? 2 : 0);
+    if (grid) *grid = st->res_ok ? st->res_G : (st->small_ok ? 1 : 0);
+    if (timeouts) *timeouts = st->res_timeouts;
+    return IPD_OK;
+}
+
+extern "C" int ipd_amg_bench_resident(ipd_amg* h, const double* b_dev, double* x_dev, int cycles,
+                                      double* total_ms, int64_t stamps[4]) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && b_dev && x_dev && cycles > 0 && total_ms && stamps, IPD_E_ARG, "bad argument");
+        ipd_ctx* ctx = h->ctx;
+        CallScope scope(ctx);
+        CycleState* st = state_of(h);
+        IPD_REQUIRE(st && st->res_ok, IPD_E_ARG, "hierarchy does not run in resident mode");
+        const int N = h->L[1].A.nr;
+        long long* dbg = ctx->scratch->alloc<long long>(16);
+        IPD_HIP(hipMemsetAsync(dbg, 0, 128, ctx->stream));
+        IPD_HIP(hipMemcpyAsync(h->x, x_dev, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+        float msf = 0.f;
+        IPD_REQUIRE(run_resident(h, st, b_dev, h->x, cycles, nullptr, &msf, dbg), IPD_E_HIP,
+                    "resident kernel gave up (not every workgroup was resident)");
+        IPD_HIP(hipMemcpyAsync(x_dev, h->x, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+        long long hs[4];
+        ctx->fetch(dbg, hs, 4);
+        for (int i = 0; i < 4; ++i) stamps[i] = hs[i];
+        *total_ms = msf;
+    });
+}
+
 // Captures the two loop bodies (x -> x2 and x2 -> x) as HIP graphs: one graph launch
 // per cycle instead of ~40 kernel launches, so the host never paces the device.
 static void ensure_graphs(ipd_amg* h, CycleState* st, const double* b_dev) {
@@ -1340,6 +1545,19 @@ extern "C" int ipd_amg_bench_cycles(ipd_amg* h, const double* b_dev, double* x_d
             *total_ms = msf;
             if (bytes_per_cycle) *bytes_per_cycle = cycle_bytes(h);
             return;
+        }
+        if (st->res_ok) {  // one launch of co-resident workgroups runs all the cycles
+            IPD_HIP(hipMemcpyAsync(h->x, x_dev, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+            float msf = 0.f;
+            if (run_resident(h, st, b_dev, h->x, cycles, nullptr, &msf)) {
+                IPD_HIP(hipMemcpyAsync(x_dev, h->x, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                                       ctx->stream));
+                ctx->sync();
+                *total_ms = msf;
+                if (bytes_per_cycle) *bytes_per_cycle = cycle_bytes(h);
+                return;
+            }
         }
         const char* ng = std::getenv("IPD_NO_GRAPH");
         const bool use_graph = !(ng && ng[0] == '1');

@@ -1,0 +1,611 @@
+// Level-resident solve kernel (included by ipd_cycle.hip only).
+//
+// The multi-launch path pays one kernel boundary plus 2-3 dependent memory round trips per
+// half sweep: 4.6-5.0 us per k_smooth launch at m=n=1024, rho=1, where the 12.7 MB a launch
+// streams would take 1.6 us at HBM peak (profiles/r1_kernel_stats.csv).  The whole hierarchy of
+// that regime (levels 2048 / 1024 / 1: 21 MB + 10.5 MB of padded rows) fits in the chip's
+// registers, so this kernel keeps it there for the WHOLE Class_AMG solve:
+//
+//   * G <= 256 workgroups of 512 threads, one per CU, all co-resident; a wave owns one row of
+//     each row block (level 1: F rows and C rows of the bigraph Gauss-Seidel, level 2: Jacobi),
+//     lane l holds entries l, l+64, ... of the padded row (16-bit column, fp64 value) in VGPRs;
+//   * every workgroup keeps the full vectors of both levels (x, e, r, r - A e, A*1) in LDS, so a
+//     row dot product is LDS gathers + one DPP wave sum, no memory traffic at all;
+//   * the only global traffic is the hand-off of each half sweep's result: a row's new value is
+//     published as ONE 16-byte write-through (sc1) store of two self-tagged 8-byte granules
+//     {lo, tag, hi, tag} (MI355X guide, Guideline 16 R2: the data is the flag) and every
+//     workgroup sweeps all granules of the step with sc1 loads until every tag carries the
+//     step number.  Two buffers by step parity: a workgroup writes step t+2 only after it has
+//     seen all of step t+1, which every workgroup publishes only after it has read all of t
+//     (every workgroup owns at least one row of every block, so "all of t+1" includes everyone).
+//     tools/ubench_exchange.hip prices the step at 1.9 us (G = 128) against 4.6-5.0 us for the
+//     launch it replaces (profiles/r2_ubench_exchange.txt);
+//   * the kernel-space scalar c = 1'(r - A e)/xx of the next sweep is reduced in the same sweep
+//     phase that stores the new iterate (no extra barrier), the transfers to and from level 2 walk
+//     the CSR rows of P'/P from L2 (twice per cycle), and the tail level (<= 64 rows, 1 row in
+//     the dense regime) is solved redundantly by every workgroup, so it needs no hand-off;
+//   * the stationary iteration and its stopping rules (Class_AMG.m:86-109) run in the kernel:
+//     every workgroup forms the same norm from the same LDS copy in the same order and so takes
+//     the same decision; one launch and one read-back per solve.
+//
+// Every spin is bounded: a workgroup that gives up raises `tmo`, every later sweep of every
+// workgroup gives up at once, and the host falls back to the multi-launch path.
+//
+// Arithmetic per row is the multi-launch kernels' (phase_smooth / phase_resid / phase_xfer /
+// phase_top), only the order inside a row's dot product differs (lane-strided entries).
+#pragma once
+
+typedef unsigned int res_v4u __attribute__((ext_vector_type(4)));
+
+static constexpr int RES_WAVES = BT / 64;     // row slots per block and workgroup (one wave per row)
+static constexpr int RES_TAIL_MAX = 64;       // rows of the redundantly solved tail level
+static constexpr int RES_NMAX = 4 * BT;        // rows per level (fixed LDS slots)
+static constexpr int RES_GRAN_MAX = RES_NMAX;  // granules per hand-off buffer
+static constexpr size_t RES_LDS_BYTES = sizeof(double) * ((size_t)9 * RES_NMAX + 3 * RES_TAIL_MAX + 10 * RES_WAVES + 6);
+static constexpr unsigned RES_SPIN_MAX = 1u << 18;
+
+struct ResLevelDesc {
+    int N, nf, S;
+    const unsigned short* pci;
+    const double* pva;
+    const double* diag;
+    const double* dinv;
+    const double* Axi;
+    const double* xx;
+};
+struct ResCsr {
+    const int* rp;
+    const int* ci;
+    const double* va;
+};
+struct ResDesc {
+    ResLevelDesc L1, L2;
+    ResCsr Pt2, P2;   // level 1 <-> 2: restriction rows (N2 x N1), prolongation rows (N1 x N2)
+    ResCsr Pt3, P3;   // level 2 <-> tail
+    ResCsr A3;        // tail operator (CSR)
+    int Nt;           // tail rows
+    int nu, isnsp, wcycle, anycycle, maxit;
+    double retol;
+    long long pcg_maxit;
+    unsigned char* gran0;
+    unsigned char* gran1;
+    unsigned* tmo;      // [0] != 0: a bounded spin gave up (value = step number)
+    long long* dbg;     // optional stamps (diagnostic build of the bench): see k_resident
+};
+
+// one fp64 value as two self-tagged 8-byte granules
+__device__ __forceinline__ res_v4u res_pack(double v, unsigned tag) {
+    res_v4u g;
+    g.x = (unsigned)__double2loint(v);
+    g.y = tag;
+    g.z = (unsigned)__double2hiint(v);
+    g.w = tag;
+    return g;
+}
+
+__device__ __forceinline__ void res_publish(__amdgpu_buffer_rsrc_t rs, unsigned seq, int gidx, double v) {
+    __builtin_amdgcn_raw_buffer_store_b128(res_pack(v, seq), rs,
+                                           (int)(seq & 1) * (RES_GRAN_MAX * 16) + gidx * 16, 0,
+                                           16 /* sc1: write-through */);
+}
+
+// Sweeps the n granules of hand-off `seq` (n <= NJ*BT); granule j goes to thread j % BT, pass
+// u = j / BT.  Returns the values in v[u] and true when the bounded spin gave up; the caller
+// stores the values after the barrier it places (all waves have then finished the step's
+// reads of the vectors that are about to change).
+template <int NJ>
+__device__ __forceinline__ bool res_sweep(__amdgpu_buffer_rsrc_t rs, unsigned seq, int n, bool dead,
+                                          unsigned* tmo, double (&v)[NJ]) {
+    const int base = (int)(seq & 1) * (RES_GRAN_MAX * 16);
+    const int j0 = threadIdx.x;
+    unsigned spins = 0;
+    bool bad = false;
+    if (!dead) {
+        for (;;) {
+            res_v4u gq[NJ];
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) {
+                const int j = j0 + u * BT;
+                gq[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (j < n ? j : 0) * 16, 0, 16 /* sc1 */);
+            }
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) {
+                const int j = j0 + u * BT;
+                ok &= (j >= n) | ((gq[u].y == seq) & (gq[u].w == seq));
+                v[u] = __hiloint2double((int)gq[u].z, (int)gq[u].x);
+            }
+            if (__all(ok)) break;
+            if (++spins > RES_SPIN_MAX ||
+                ((spins & 255) == 255 &&
+                 __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                bad = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        }
+    }
+    return bad;
+}
+
+// lane-strided slice of one padded row: entries lane, lane+64, ... ; the 16-bit columns are kept
+// as LDS byte offsets (8*column <= 16376), two per register
+template <int KE>
+__device__ __forceinline__ void res_load_slice(const ResLevelDesc& L, int row, bool valid, int lane,
+                                               unsigned (&c)[KE / 2], double (&a)[KE]) {
+    unsigned cc[KE];
+#pragma unroll
+    for (int q = 0; q < KE; ++q) {
+        const int e = lane + 64 * q;
+        const bool ok = valid && e < L.S;
+        const size_t off = ok ? (size_t)row * L.S + e : 0;
+        const unsigned short cj = L.pci[off];
+        const double aa = L.pva[off];
+        cc[q] = ok ? 8u * cj : 0u;
+        a[q] = ok ? aa : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < KE / 2; ++q) c[q] = cc[2 * q] | (cc[2 * q + 1] << 16);
+}
+
+// row dot product against the LDS vector at byte offset OFFB (a compile-time constant below
+// 64 KB: one ds_read_b64 with an immediate offset per entry)
+template <int KE, int OFFB>
+__device__ __forceinline__ double res_rowdot(unsigned (&c)[KE / 2], const double (&a)[KE],
+                                             const char* smb) {
+    double y[KE];
+#pragma unroll
+    for (int q = 0; q < KE / 2; ++q) {
+        // opaque: keeps the unpacked offsets from being hoisted out of the cycle loops (they
+        // would cost a register per matrix entry for the whole kernel)
+        asm volatile("" : "+v"(c[q]));
+        const unsigned lo = c[q] & 0xffffu, hi = c[q] >> 16;
+        y[2 * q] = *reinterpret_cast<const double*>(smb + OFFB + lo);
+        y[2 * q + 1] = *reinterpret_cast<const double*>(smb + OFFB + hi);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < KE; ++q) s += a[q] * y[q];
+    return s;
+}
+
+// CSR row of a transfer operator (global, L2-resident) against an LDS vector, one wave per row
+__device__ __forceinline__ double res_csr_rowdot(const ResCsr& M, int row, bool valid, int lane,
+                                                 const double* sm, int off) {
+    const int e0 = M.rp[valid ? row : 0];
+    const int e1 = valid ? M.rp[row + 1] : e0;
+    double s = 0.0;
+    for (int t = e0 + lane; t < e1; t += 64 * 4) {
+        int jj[4];
+        double aa[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tt = t + 64 * u;
+            const int tc = tt < e1 ? tt : e0;
+            jj[u] = M.ci[tc];
+            aa[u] = M.va[tc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += (t + 64 * u < e1) ? aa[u] * sm[off + jj[u]] : 0.0;
+    }
+    return wave_sum(s);
+}
+
+// Block sums of up to two per-thread partials through red[0..2*RES_WAVES): the caller has
+// written red[w] / red[RES_WAVES + w] before the barrier that precedes this call.
+__device__ __forceinline__ double res_red8(const double* red) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < RES_WAVES; ++k) t += red[k];
+    return t;
+}
+
+// out[0] = it, out[1] = rel_res, out[2] = res0; rel_resk at out[4 ..], rhok at out[4+maxit+2 ..]
+// (the layout of k_solve_small).  fixed_cycles > 0: exactly that many loop bodies, no stopping
+// rules (bench hook).  dbg (optional, 16 words): [0] shader clocks spent waiting in sweeps by
+// workgroup 0, [1] clocks of the whole loop, [2] number of hand-offs, [3] 100 MHz ticks of the loop.
+template <int KE1, int KE2>
+__global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const double* __restrict__ bvec,
+                                                    double* xg, double* out, int fixed_cycles) {
+    extern __shared__ __attribute__((aligned(16))) char res_smem[];
+    double* sm = reinterpret_cast<double*>(res_smem);
+    const char* smb = res_smem;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x, G = gridDim.x;
+    const int N1 = D.L1.N, N2 = D.L2.N, nf = D.L1.nf, nc = N1 - nf, Nt = D.Nt;
+    // LDS map (doubles): fixed slots of RES_NMAX entries, the gather targets in the first 64 KB so
+    // that a gather is one ds_read_b64 with an immediate offset (no address arithmetic to hoist)
+    constexpr int oX = 0, oE1 = RES_NMAX, oE2 = 2 * RES_NMAX, oRR1 = 3 * RES_NMAX;
+    constexpr int oR1 = 4 * RES_NMAX, oAX1 = 5 * RES_NMAX, oR2 = 6 * RES_NMAX, oRR2 = 7 * RES_NMAX;
+    constexpr int oAX2 = 8 * RES_NMAX;
+    constexpr int oR3 = 9 * RES_NMAX, oE3 = oR3 + RES_TAIL_MAX, oP3 = oE3 + RES_TAIL_MAX;
+    constexpr int oRED = oP3 + RES_TAIL_MAX;          // 2*RES_WAVES doubles
+    constexpr int oOWN = oRED + 2 * RES_WAVES;        // 8 scalars of each wave's rows
+    int* fail = reinterpret_cast<int*>(sm + oOWN + 8 * RES_WAVES);
+    long long* dbg_acc = reinterpret_cast<long long*>(sm + oOWN + 8 * RES_WAVES + 1);   // 3 words
+    double* red = sm + oRED;
+
+    // ---- rows of this wave ------------------------------------------------------------------
+    const int loF = (int)(((long long)b * nf) / G), hiF = (int)(((long long)(b + 1) * nf) / G);
+    const int loC = nf + (int)(((long long)b * nc) / G), hiC = nf + (int)(((long long)(b + 1) * nc) / G);
+    const int lo2 = (int)(((long long)b * N2) / G), hi2 = (int)(((long long)(b + 1) * N2) / G);
+    const int rowF = loF + w, rowC = loC + w, row2 = lo2 + w;
+    const bool vF = rowF < hiF, vC = rowC < hiC, v2 = row2 < hi2;
+    const int rF = vF ? rowF : 0, rC = vC ? rowC : 0, r2 = v2 ? row2 : 0;
+
+    // ---- matrix slices -> registers (the only read of the matrices in the whole solve) --------
+    unsigned cF[KE1 / 2], cC[KE1 / 2], c2[KE2 / 2];
+    double aF[KE1], aC[KE1], a2[KE2];
+    res_load_slice<KE1>(D.L1, rF, vF, lane, cF, aF);
+    res_load_slice<KE1>(D.L1, rC, vC, lane, cC, aC);
+    res_load_slice<KE2>(D.L2, r2, v2, lane, c2, a2);
+    // the rows' own scalars live in LDS (a register pair each would stay live for the whole solve)
+    if (lane == 0) {
+        sm[oOWN + 0 * RES_WAVES + w] = D.L1.diag[rF];
+        sm[oOWN + 1 * RES_WAVES + w] = D.L1.dinv[rF];
+        sm[oOWN + 2 * RES_WAVES + w] = bvec[rF];
+        sm[oOWN + 3 * RES_WAVES + w] = D.L1.diag[rC];
+        sm[oOWN + 4 * RES_WAVES + w] = D.L1.dinv[rC];
+        sm[oOWN + 5 * RES_WAVES + w] = bvec[rC];
+        sm[oOWN + 6 * RES_WAVES + w] = D.L2.diag[r2];
+        sm[oOWN + 7 * RES_WAVES + w] = D.L2.dinv[r2];
+    }
+#define dgF sm[oOWN + 0 * RES_WAVES + w]
+#define dvF sm[oOWN + 1 * RES_WAVES + w]
+#define bF sm[oOWN + 2 * RES_WAVES + w]
+#define dgC sm[oOWN + 3 * RES_WAVES + w]
+#define dvC sm[oOWN + 4 * RES_WAVES + w]
+#define bC sm[oOWN + 5 * RES_WAVES + w]
+#define dg2 sm[oOWN + 6 * RES_WAVES + w]
+#define dv2 sm[oOWN + 7 * RES_WAVES + w]
+    const bool nsp = D.isnsp != 0;
+    const double xx1 = nsp ? D.L1.xx[0] : 1.0, xx2 = nsp ? D.L2.xx[0] : 1.0;
+    for (int j = tid; j < N1; j += BT) {
+        sm[oX + j] = xg[j];
+        sm[oE1 + j] = 0.0;
+        sm[oAX1 + j] = D.L1.Axi[j];
+    }
+    for (int j = tid; j < N2; j += BT) {
+        sm[oE2 + j] = 0.0;
+        sm[oAX2 + j] = D.L2.Axi[j];
+    }
+    if (tid == 0) *fail = 0;
+    __syncthreads();
+
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(D.gran0, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
+    unsigned seq = 0;       // number of the last hand-off
+    bool dead = false;      // a spin gave up somewhere: skip every further wait
+    const bool dbg = D.dbg != nullptr && b == 0 && tid == 0;
+    if (dbg) {
+        dbg_acc[0] = 0;
+        dbg_acc[1] = __builtin_amdgcn_s_memtime();
+        dbg_acc[2] = __builtin_amdgcn_s_memrealtime();
+    }
+
+    // ---- hand-off wrapper: sweep + barrier + store + (optional) block sums + barrier ------------
+    // STORE(j, v) is called for every granule of the thread; EXTRA() runs once per thread in the
+    // store phase (fix-ups on rows the thread does not sweep); both may add to p0 / p1, whose block
+    // totals are returned in t0 / t1.
+#define RES_HANDOFF(NJ, n, STORE, EXTRA, want_sums, t0, t1)                                        \
+    do {                                                                                           \
+        double hv_[NJ];                                                                            \
+        if (dbg) dbg_acc[0] -= __builtin_amdgcn_s_memtime();                                       \
+        if (res_sweep<NJ>(rs, seq, (n), dead, D.tmo, hv_)) {                                          \
+            *fail = 1;                                                                             \
+            if (lane == 0) __hip_atomic_store(D.tmo, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+        }                                                       \
+        if (dbg) dbg_acc[0] += __builtin_amdgcn_s_memtime();                                       \
+        __syncthreads();                                                                           \
+        double p0 = 0.0, p1 = 0.0;                                                                 \
+        _Pragma("unroll") for (int u_ = 0; u_ < NJ; ++u_) {                                        \
+            const int j = tid + u_ * BT;                                                           \
+            if (j < (n)) {                                                                         \
+                const double v = hv_[u_];                                                          \
+                STORE;                                                                             \
+            }                                                                                      \
+        }                                                                                          \
+        EXTRA;                                                                                     \
+        if (want_sums) {                                                                           \
+            p0 = wave_sum(p0);                                                                     \
+            p1 = wave_sum(p1);                                                                     \
+            if (lane == 0) {                                                                       \
+                red[w] = p0;                                                                       \
+                red[RES_WAVES + w] = p1;                                                           \
+            }                                                                                      \
+        }                                                                                          \
+        __syncthreads();                                                                           \
+        if (want_sums) {                                                                           \
+            t0 = res_red8(red);                                                                    \
+            t1 = res_red8(red + RES_WAVES);                                                        \
+        }                                                                                          \
+        if (*fail) dead = true;                                                                 \
+    } while (0)
+
+    double c1 = 0.0, c2s = 0.0;     // kernel-space scalars of the next sweep on level 1 / 2
+    double res = 0.0, res0 = 0.0, prev = 0.0;
+    double dum0 = 0.0, dum1 = 0.0;
+    (void)dum0;
+    (void)dum1;
+
+    // r = b - A x (rows of this wave), ||r||, c1 for a zero start; E1 := 0        Class_AMG.m:89,96,103
+    auto top = [&]() {
+        const double sF = wave_sum(res_rowdot<KE1, 8 * oX>(cF, aF, smb));
+        const double sC = wave_sum(res_rowdot<KE1, 8 * oX>(cC, aC, smb));
+        ++seq;
+        if (lane == 0) {
+            if (vF) res_publish(rs, seq, rowF, bF - (sF + dgF * sm[oX + rowF]));
+            if (vC) res_publish(rs, seq, rowC, bC - (sC + dgC * sm[oX + rowC]));
+        }
+        double nrm2 = 0.0, sumr = 0.0;
+        RES_HANDOFF(4, N1, { sm[oR1 + j] = v; sm[oE1 + j] = 0.0; p0 += v * v; p1 += v; }, {}, true, nrm2,
+                    sumr);
+        c1 = nsp ? sumr / xx1 : 0.0;
+        return sqrt(nrm2);
+    };
+
+    // one half of a bigraph Gauss-Seidel sweep on level 1.  `first`: rows of the first half (the
+    // other half still holds the old iterate); second half: + the shift by c of both halves and
+    // the scalar of the next sweep.                         MG_Vcycle.m:15-21,34-38; Class_AMG.m:56-59
+    auto half1 = [&](bool frows, bool first, bool ezero) {
+        double s = 0.0, eo = 0.0;
+        const int row = frows ? rowF : rowC;
+        const bool valid = frows ? vF : vC;
+        const int rr_ = valid ? row : 0;
+        if (!(ezero && first)) s = wave_sum(frows ? res_rowdot<KE1, 8 * oE1>(cF, aF, smb) : res_rowdot<KE1, 8 * oE1>(cC, aC, smb));
+        if (!ezero) eo = sm[oE1 + rr_];
+        s += (frows ? dgF : dgC) * eo;
+        const double g_i = sm[oR1 + rr_] - s - sm[oAX1 + rr_] * c1;
+        const double wv = eo + (frows ? dvF : dvC) * g_i;
+        const int blk0 = frows ? 0 : nf, nblk = frows ? nf : nc;
+        ++seq;
+        if (lane == 0 && valid) res_publish(rs, seq, row - blk0, wv);
+        if (first) {
+            RES_HANDOFF(2, nblk, { sm[oE1 + blk0 + j] = v; }, {}, false, dum0, dum1);
+        } else {
+            // other half: w -> w + c ; this half: wv + c ; scalar of the next sweep
+            const int oth0 = frows ? nf : 0, noth = frows ? nc : nf;
+            const double cc = c1;
+            double xig = 0.0;
+            RES_HANDOFF(2, nblk,
+                        {
+                            const double en = v + cc;
+                            sm[oE1 + blk0 + j] = en;
+                            p0 += sm[oR1 + blk0 + j] - sm[oAX1 + blk0 + j] * en;
+                        },
+                        {
+                            for (int jo = tid; jo < noth; jo += BT) {
+                                const double en = sm[oE1 + oth0 + jo] + cc;
+                                sm[oE1 + oth0 + jo] = en;
+                                p0 += sm[oR1 + oth0 + jo] - sm[oAX1 + oth0 + jo] * en;
+                            }
+                        },
+                        nsp, xig, dum1);
+            c1 = nsp ? xig / xx1 : 0.0;
+        }
+    };
+    auto sweep1 = [&](bool post, bool ezero) {
+        half1(!post, true, ezero);    // pre: F rows first (Rk{1}); post: C rows first (Rk{1}')
+        half1(post, false, ezero);
+    };
+
+    // weighted-Jacobi sweep on level 2                                   MG_Vcycle.m:15-21; Class_AMG.m:84
+    auto sweep2 = [&](bool ezero) {
+        double s = 0.0, eo = 0.0;
+        if (!ezero) {
+            s = wave_sum(res_rowdot<KE2, 8 * oE2>(c2, a2, smb));
+            eo = sm[oE2 + r2];
+            s += dg2 * eo;
+        }
+        const double g_i = sm[oR2 + r2] - s - sm[oAX2 + r2] * c2s;
+        const double wv = eo + dv2 * g_i;
+        ++seq;
+        if (lane == 0 && v2) res_publish(rs, seq, row2, wv);
+        const double cc = c2s;
+        double xig = 0.0;
+        RES_HANDOFF(4, N2,
+                    {
+                        const double en = v + cc;
+                        sm[oE2 + j] = en;
+                        p0 += sm[oR2 + j] - sm[oAX2 + j] * en;
+                    },
+                    {}, nsp, xig, dum1);
+        c2s = nsp ? xig / xx2 : 0.0;
+    };
+
+    // tail level: restriction, Jacobi-PCG (PCG.m:68-87, zero guess), prolongation -- all of it by
+    // every workgroup on its own LDS copies, so no hand-off                     MG_Vcycle.m:27-31,43
+    auto tail = [&]() {
+        for (int i = w; i < Nt; i += RES_WAVES) {
+            const double s = res_csr_rowdot(D.Pt3, i, true, lane, sm, oRR2);
+            if (lane == 0) sm[oR3 + i] = s;
+        }
+        __syncthreads();
+        if (w == 0) {
+            const int i = lane < Nt ? lane : 0;
+            const bool valid = lane < Nt;
+            const int e0 = D.A3.rp[i], e1 = D.A3.rp[i + 1];
+            double dd = 0.0;
+            for (int t = e0; t < e1; ++t)
+                if (D.A3.ci[t] == i) dd = D.A3.va[t];
+            double r = valid ? sm[oR3 + i] : 0.0;
+            double p = valid ? r / dd : 0.0;
+            double d = 0.0;
+            double delta_new = wave_sum(valid ? r * p : 0.0);
+            const double thresh = 1e-11 * 1e-11 * delta_new;
+            long long it = 0;
+            while (it < D.pcg_maxit && delta_new > thresh) {
+                const double delta_old = delta_new;
+                if (valid) sm[oP3 + i] = p;
+                tiny_sync();
+                double q = 0.0;
+                if (valid)
+                    for (int t = e0; t < e1; ++t) q += D.A3.va[t] * sm[oP3 + D.A3.ci[t]];
+                tiny_sync();
+                const double qp = wave_sum(valid ? q * p : 0.0);
+                const double alpha = delta_old / qp;
+                d += alpha * p;
+                r = r - alpha * q;
+                const double wi = valid ? r / dd : 0.0;
+                delta_new = wave_sum(valid ? r * wi : 0.0);
+                p = wi + (delta_new / delta_old) * p;
+                ++it;
+            }
+            if (valid) sm[oE3 + i] = d;
+        }
+        __syncthreads();
+        double p0 = 0.0;
+        for (int j = tid; j < N2; j += BT) {
+            double s = 0.0;
+            for (int t = D.P3.rp[j]; t < D.P3.rp[j + 1]; ++t) s += D.P3.va[t] * sm[oE3 + D.P3.ci[t]];
+            const double en = sm[oE2 + j] + s;
+            sm[oE2 + j] = en;
+            p0 += sm[oR2 + j] - sm[oAX2 + j] * en;
+        }
+        if (nsp) {
+            p0 = wave_sum(p0);
+            if (lane == 0) red[w] = p0;
+        }
+        __syncthreads();
+        if (nsp) c2s = res_red8(red) / xx2;
+    };
+
+    // one visit of level 2 and everything below it
+    auto visit2 = [&](bool keep) {
+        const int nu = D.nu;
+        for (int s = 0; s < nu; ++s) sweep2(!keep && s == 0);
+        // rr = r - A e                                                           MG_Vcycle.m:27
+        {
+            const double s = wave_sum(res_rowdot<KE2, 8 * oE2>(c2, a2, smb)) + dg2 * sm[oE2 + r2];
+            ++seq;
+            if (lane == 0 && v2) res_publish(rs, seq, row2, sm[oR2 + r2] - s);
+            RES_HANDOFF(4, N2, { sm[oRR2 + j] = v; }, {}, false, dum0, dum1);
+        }
+        tail();
+        for (int s = 0; s < nu; ++s) sweep2(false);
+    };
+
+    // MG_Vcycle / MG_Wcycle from level 1 down; the correction ends in E1
+    auto cycle = [&]() {
+        const int nu = D.nu;
+        for (int s = 0; s < nu; ++s) sweep1(false, s == 0);
+        {   // rr = r - A e on both blocks
+            const double sF = wave_sum(res_rowdot<KE1, 8 * oE1>(cF, aF, smb)) + dgF * sm[oE1 + rF];
+            const double sC = wave_sum(res_rowdot<KE1, 8 * oE1>(cC, aC, smb)) + dgC * sm[oE1 + rC];
+            ++seq;
+            if (lane == 0) {
+                if (vF) res_publish(rs, seq, rowF, sm[oR1 + rF] - sF);
+                if (vC) res_publish(rs, seq, rowC, sm[oR1 + rC] - sC);
+            }
+            RES_HANDOFF(4, N1, { sm[oRR1 + j] = v; }, {}, false, dum0, dum1);
+        }
+        {   // r_2 = P' rr ; E2 := 0 ; c for the zero start
+            const double s = res_csr_rowdot(D.Pt2, r2, v2, lane, sm, oRR1);
+            ++seq;
+            if (lane == 0 && v2) res_publish(rs, seq, row2, s);
+            double sumr = 0.0;
+            RES_HANDOFF(4, N2, { sm[oR2 + j] = v; sm[oE2 + j] = 0.0; p0 += v; }, {}, nsp, sumr, dum1);
+            c2s = nsp ? sumr / xx2 : 0.0;
+        }
+        for (int leg = 0; leg < (D.wcycle ? 2 : 1); ++leg) visit2(leg == 1);      // MG_Wcycle.m:28-30
+        {   // e_1 += P e_2                                                        MG_Vcycle.m:31
+            const double sF = res_csr_rowdot(D.P2, rF, vF, lane, sm, oE2);
+            const double sC = res_csr_rowdot(D.P2, rC, vC, lane, sm, oE2);
+            ++seq;
+            if (lane == 0) {
+                if (vF) res_publish(rs, seq, rowF, sm[oE1 + rF] + sF);
+                if (vC) res_publish(rs, seq, rowC, sm[oE1 + rC] + sC);
+            }
+            double xig = 0.0;
+            RES_HANDOFF(4, N1, { sm[oE1 + j] = v; p0 += sm[oR1 + j] - sm[oAX1 + j] * v; }, {}, nsp, xig,
+                        dum1);
+            c1 = nsp ? xig / xx1 : 0.0;
+        }
+        for (int s = 0; s < nu; ++s) sweep1(true, false);
+    };
+
+    auto add_correction = [&]() {   // x += e                                       Class_AMG.m:98,101
+        for (int j = tid; j < N1; j += BT) sm[oX + j] = sm[oX + j] + sm[oE1 + j];
+        __syncthreads();
+    };
+
+    // ---- Class_AMG.m:86-109 (one call site of every step: the kernel is large) -----------------
+    const int maxit = D.maxit;
+    double* relk = out + 4;
+    double* rhok = out + 4 + (maxit + 2);
+    const bool writer = b == 0 && tid == 0;
+    const bool fixed = fixed_cycles > 0;
+    int it = 0, done = 0;
+    double rel_res = 0.0, last_rel = 1.0;
+    bool first = true;
+    for (;;) {
+        const double rnow = top();                                                // :89 / :103
+        if (first) {
+            first = false;
+            res0 = res = rnow;
+            if (!fixed) {
+                if (res0 == 0.0) {                                                // :91-92
+                    if (writer) {
+                        relk[0] = 0.0;
+                        rhok[0] = INFINITY;
+                    }
+                    break;
+                }
+                it = 1;                                                           // :94
+                if (writer) {
+                    relk[0] = 1.0;
+                    rhok[0] = NAN;
+                }
+            }
+        } else {
+            prev = res;
+            res = rnow;
+            rel_res = res / res0;                                                 // :104
+            const double rho = res / prev;                                        // :105
+            if (fixed) {
+                ++done;
+            } else {
+                if (writer) {
+                    relk[it] = rel_res;
+                    rhok[it] = rho;
+                }
+                last_rel = rel_res;
+                ++it;
+                if (rho > 1.0) break;                                             // :106
+            }
+        }
+        if (dead) break;
+        if (fixed ? done >= fixed_cycles : !(last_rel > D.retol && it <= maxit)) break;   // :95
+        if (D.anycycle) {
+            cycle();                                                              // :97-102
+            add_correction();
+        }
+    }
+    if (fixed)
+        it = fixed_cycles;
+    else if (res0 != 0.0)
+        it -= 1;                                                                  // :108
+    if (b == 0)
+        for (int j = tid; j < N1; j += BT) xg[j] = sm[oX + j];
+    if (writer) {
+        out[0] = (double)it;
+        out[1] = rel_res;
+        out[2] = res0;
+        out[3] = dead ? 1.0 : 0.0;
+    }
+    if (dbg) {
+        D.dbg[0] = dbg_acc[0];
+        D.dbg[1] = __builtin_amdgcn_s_memtime() - dbg_acc[1];
+        D.dbg[2] = seq;
+        D.dbg[3] = __builtin_amdgcn_s_memrealtime() - dbg_acc[2];
+    }
+#undef RES_HANDOFF
+#undef dgF
+#undef dvF
+#undef bF
+#undef dgC
+#undef dvC
+#undef bC
+#undef dg2
+#undef dv2
+}

@@ -1,0 +1,244 @@
+"""The workloads bench.py publishes, tested as such, and the level-resident
+solve kernel that runs the metric's one (csrc/ipd_resident.h).
+
+Metric workload (BASELINE.json): m=n=1024, regime D of SURVEY 8d with rho = 1 (Bernoulli mask
+seed 2), bk1 = 0.0038, tk = 0.0255, z ~ N(0,1) seed 3, guess = bk1*tk*U(0,1) seed 4, options of
+the Class 1 driver (smoth 5, theta 1/4, bigph, isnsp 1), V cycle; `--cycle w` and `--n1 2048` are
+the quoted variants.  Reference behaviour: AMG/Class_AMG.m:95-107, AMG/MG_Vcycle.m:12-41,
+AMG/MG_Wcycle.m:13-46.
+
+Checks: (i) hierarchy sizes; (ii) K timed loop bodies (ipd_amg_bench_cycles) == K iterations of
+Class_AMG (bit for bit, same kernels) and == the oracle's K iterations through A(x - x_ref) to
+1e-9, with the oracle's contraction; (iii) the resident kernel against the multi-launch path
+(IPD_NO_RESIDENT=1) on every shape class it accepts: residual histories to 1e-10, same cycle
+counts; (iv) the mask-operator and padded/unpadded multi-launch paths forced once each."""
+import os
+from contextlib import contextmanager
+from ctypes import byref, c_double, c_int, c_int32
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import bench
+from oracle import ipd_oracle as O
+from tests import problems as PR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ipd():
+    import codes_of_ipd_ssn_amg_method_amd as m
+    return m
+
+
+@contextmanager
+def env(**kv):
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update({k: str(v) for k, v in kv.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def options(cycle, n, isnsp=1, maxit=30, retol=1e-11):
+    return dict(retol=retol, bigph=1, maxit=maxit, theta=0.25, smoth=5, cycle=cycle, isnsp=isnsp,
+                inter=1, fnode=n)
+
+
+def solve_mode(h):
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    mode, grid, tmo = c_int32(), c_int32(), c_int32()
+    _lib.check(_lib.lib.ipd_amg_solve_mode(h.handle, byref(mode), byref(grid), byref(tmo)))
+    return mode.value, grid.value, tmo.value
+
+
+def same_history(it, relk, itc, relkc, tol=1e-10):
+    """Residual histories agree to `tol` over their common part.  The dense systems here reach the
+    rounding floor (2-4e-11 of the initial residual, above retol = 1e-11) after ONE cycle and then
+    stop at the first cycle whose residual happens to rise (rhok > 1, Class_AMG.m:106): which
+    cycle that is, is rounding noise -- it differs between any two summation orders, the oracle's
+    and the multi-launch kernels' own variants included -- so the counts may differ there, and
+    only there."""
+    k = min(it, itc) + 1
+    assert np.max(np.abs(relk[:k] - relkc[:k])) <= tol, (relk, relkc)
+    at_floor = max(relk[k - 1], relkc[k - 1]) <= 1e-9
+    assert it == itc or (at_floor and abs(it - itc) <= 4), (it, itc, relk, relkc)
+
+
+def bench_cycles(h, f, x0, cycles):
+    """x after `cycles` loop bodies through the hook bench.py times."""
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    db = _lib.DeviceBuffer.from_array(f)
+    dx = _lib.DeviceBuffer.from_array(x0)
+    ms, bpc = c_double(), c_double()
+    _lib.check(_lib.lib.ipd_amg_bench_cycles(h.handle, db.ptr, dx.ptr, c_int(cycles), byref(ms), byref(bpc)))
+    return dx.to_array(np.float64, f.size), ms.value, bpc.value
+
+
+def oracle_cycles(Ae, f, x0, opts, cycles):
+    """The same loop body with the SciPy oracle (Class_AMG.m:96-102 without the exit tests)."""
+    o = dict(opts)
+    o.update(guess=x0)
+    h = O.amg_setup(Ae, o, O.matlab_rng())
+    A = h.Ack[1]
+    x = x0.copy()
+    res = [np.linalg.norm(A @ x - f)]
+    for _ in range(cycles):
+        r = f - A @ x
+        e = O.MG_Wcycle(h, r, opts["isnsp"]) if opts["cycle"] == "w" else O.MG_Vcycle(h, r, opts["isnsp"])
+        x = x + e
+        res.append(np.linalg.norm(A @ x - f))
+    return x, np.array(res), h
+
+
+@pytest.fixture(scope="module")
+def metric_system(ipd):
+    m = n = 1024
+    s = bench.build_mask(m, n, "bernoulli", 1.0)
+    Ae, f, guess, H0 = bench.build_newton_system(ipd, m, n, s)
+    return m, n, s, Ae, f, guess
+
+
+@pytest.mark.parametrize("cycle", ["v", "w"])
+def test_metric_workload_against_oracle(ipd, metric_system, cycle):
+    m, n, s, Ae, f, guess = metric_system
+    opts = options(cycle, n)
+    h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    # (i) the hierarchy bench.py reports
+    assert h.level_sizes() == [2048, 1024, 1]
+    assert [h.level_dims(k)[1] for k in (1, 2, 3)] == [2099200, 1048576, 1]
+    mode, grid, _ = solve_mode(h)
+    assert mode == 2 and grid == 128, "the metric workload runs in the level-resident kernel"
+    # (ii) K timed loop bodies against the oracle's K iterations
+    K = 3
+    x, ms, bpc = bench_cycles(h, f, guess, K)
+    xo, reso, ho = oracle_cycles(Ae, f, guess, opts, K)
+    assert ho.J == 3
+    A = sp.csr_matrix(Ae)
+    nf = np.linalg.norm(f)
+    assert np.linalg.norm(A @ (x - xo)) <= 1e-9 * nf
+    res = np.linalg.norm(A @ x - f)
+    # this system contracts to the rounding floor (2e-10 of the initial residual) in ONE cycle,
+    # the oracle's too: beyond that only the floor can be compared
+    assert reso[1] < 1e-9 * reso[0] and res <= 1e-9 * reso[0], (res, reso)
+    assert bpc == h.cycle_bytes() and ms > 0
+    # ... and against K iterations of Class_AMG itself (same kernels: bit for bit)
+    h2 = ipd.AMGHierarchy(Ae, options(cycle, n, maxit=K, retol=0.0), ipd.MatlabRand())
+    x2, it2, rel2, relk2, rho2 = h2.solve(f, guess)
+    assert it2 == K
+    assert np.array_equal(x2, x)
+    # (the residual is rounding noise of size 1e-8 by then: ||r|| itself depends on the summation order)
+    assert abs(relk2[-1] - res / reso[0]) <= 1e-9 and relk2[1] <= 1e-9
+
+
+@pytest.mark.parametrize("cycle", ["v", "w"])
+def test_metric_workload_solve_history(ipd, metric_system, cycle):
+    """Full Class_AMG solve: resident kernel == multi-launch path == oracle (histories 1e-10)."""
+    m, n, s, Ae, f, guess = metric_system
+    opts = options(cycle, n)
+    h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    assert solve_mode(h)[0] == 2
+    x, it, rel, relk, rhok = h.solve(f, guess)
+    assert solve_mode(h)[2] == 0, "no hand-off of the resident kernel timed out"
+    with env(IPD_NO_RESIDENT=1):
+        hc = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    assert solve_mode(hc)[0] == 0
+    xc, itc, relc, relkc, rhokc = hc.solve(f, guess)
+    assert 0 < it < 30
+    same_history(it, relk, itc, relkc)
+    assert abs(rhok[1] - rhokc[1]) <= 1e-10
+    A = sp.csr_matrix(Ae)
+    assert np.linalg.norm(A @ (x - xc)) <= 1e-9 * np.linalg.norm(f)
+    assert rel <= 1e-9          # stopped at the floor by the rhok > 1 rule (or converged)
+    o = dict(opts)
+    o.update(guess=guess)
+    xo, ito, relo, relko, _ = O.Class_AMG(Ae, f, o, O.matlab_rng())
+    same_history(it, relk, ito, relko)
+
+
+SHAPES = [
+    # (m, n, rho, isnsp, cycle)     shape classes the resident kernel accepts (3 levels, tiny tail)
+    (512, 512, 1.0, 1, "v"),      # KE = 8, G = 64
+    (512, 512, 1.0, 0, "w"),      # no kernel-space correction
+    (256, 256, 1.0, 1, "w"),      # KE = 4, G = 32
+    (700, 900, 1.0, 1, "v"),      # rectangular, rows not divisible by the grid, KE = 16
+    (1024, 1024, 0.5, 1, "v"),    # ragged rows
+    (1000, 1000, 0.9, 1, "w"),
+]
+
+
+@pytest.mark.parametrize("m,n,rho,isnsp,cycle", SHAPES)
+def test_resident_matches_multilaunch(ipd, m, n, rho, isnsp, cycle):
+    s = PR.mask_bernoulli(m, n, rho, seed=5)
+    Ae, f, guess, H0 = bench.build_newton_system(ipd, m, n, s)
+    if sp.csgraph.connected_components(Ae)[0] != 1:
+        pytest.skip("mask not connected")
+    opts = options(cycle, n, isnsp=isnsp)
+    h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    mode, grid, _ = solve_mode(h)
+    with env(IPD_NO_RESIDENT=1):
+        hc = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    assert h.level_sizes() == hc.level_sizes()
+    if mode != 2:
+        pytest.skip("hierarchy %s is not taken by the resident kernel" % (h.level_sizes(),))
+    x, it, rel, relk, rhok = h.solve(f, guess)
+    assert solve_mode(h)[2] == 0
+    xc, itc, relc, relkc, rhokc = hc.solve(f, guess)
+    same_history(it, relk, itc, relkc)
+    A = sp.csr_matrix(Ae)
+    assert np.linalg.norm(A @ (x - xc)) <= 1e-9 * np.linalg.norm(f)
+    # zero guess and zero right-hand side (Class_AMG.m:91-92)
+    x0, it0, rel0, relk0, rhok0 = h.solve(f, None)
+    xc0, itc0, _, relkc0, _ = hc.solve(f, None)
+    same_history(it0, relk0, itc0, relkc0)
+    xz, itz, relz, relkz, rhokz = h.solve(np.zeros(m + n), None)
+    assert itz == 0 and relkz[0] == 0.0 and np.isinf(rhokz[0]) and not xz.any()
+
+
+def test_metric_workload_forced_paths(ipd, metric_system):
+    """(iv) the other operators of the metric workload, forced once each: level 1 through the bit
+    mask, padded rows off, LDS staging off -- all multi-launch, all against the resident kernel."""
+    m, n, s, Ae, f, guess = metric_system
+    opts = options("v", n)
+    h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    x, it, rel, relk, rhok = h.solve(f, guess)
+    for kv in (dict(IPD_NO_RESIDENT=1, IPD_MASKOP=1), dict(IPD_NO_RESIDENT=1, IPD_NO_PAD=1),
+               dict(IPD_NO_RESIDENT=1, IPD_NO_STAGE=1)):
+        with env(**kv):
+            hc = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+            if "IPD_MASKOP" in kv:
+                assert hc.attach_mask_operator(np.ones(m), np.ones(n), bench.TK)
+            xc, itc, relc, relkc, rhokc = hc.solve(f, guess)
+        assert solve_mode(hc)[0] == 0
+        same_history(it, relk, itc, relkc)
+
+
+def test_n2048_variant(ipd):
+    """`bench.py --n1 2048` (M = 4096: beyond the resident kernel, graph-replayed launches):
+    hierarchy, K timed loop bodies == K iterations of Class_AMG bit for bit, contraction."""
+    m = n = 2048
+    s = bench.build_mask(m, n, "bernoulli", 1.0)
+    Ae, f, guess, H0 = bench.build_newton_system(ipd, m, n, s)
+    opts = options("v", n)
+    h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    assert h.level_sizes() == [4096, 2048, 1]
+    assert [h.level_dims(k)[1] for k in (1, 2, 3)] == [8392704, 4194304, 1]
+    assert solve_mode(h)[0] == 0
+    h.attach_mask_operator(np.ones(m), np.ones(n), bench.TK)    # as bench.py does from 4 M entries on
+    K = 3
+    x, ms, bpc = bench_cycles(h, f, guess, K)
+    h2 = ipd.AMGHierarchy(Ae, options("v", n, maxit=K, retol=0.0), ipd.MatlabRand())
+    h2.attach_mask_operator(np.ones(m), np.ones(n), bench.TK)
+    x2, it2, rel2, relk2, rho2 = h2.solve(f, guess)
+    assert it2 == K and np.array_equal(x2, x)
+    A = sp.csr_matrix(Ae)
+    r0, r3 = np.linalg.norm(A @ guess - f), np.linalg.norm(A @ x - f)
+    assert r3 < 1e-3 * r0
+    assert abs(relk2[-1] - r3 / r0) <= 1e-10
