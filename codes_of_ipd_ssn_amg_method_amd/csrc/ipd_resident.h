@@ -41,7 +41,7 @@ static constexpr int RES_WAVES = BT / 64;     // row slots per block and workgro
 static constexpr int RES_TAIL_MAX = 64;       // rows of the redundantly solved tail level
 static constexpr int RES_NMAX = 4 * BT;        // rows per level (fixed LDS slots)
 static constexpr int RES_GRAN_MAX = RES_NMAX;  // granules per hand-off buffer
-static constexpr size_t RES_LDS_BYTES = sizeof(double) * ((size_t)9 * RES_NMAX + 3 * RES_TAIL_MAX + 10 * RES_WAVES + 6);
+static constexpr size_t RES_LDS_BYTES = sizeof(double) * ((size_t)9 * RES_NMAX + 3 * RES_TAIL_MAX + 12 * RES_WAVES + 6);
 static constexpr unsigned RES_SPIN_MAX = 1u << 18;
 
 struct ResLevelDesc {
@@ -221,7 +221,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     constexpr int oAX2 = 8 * RES_NMAX;
     constexpr int oR3 = 9 * RES_NMAX, oE3 = oR3 + RES_TAIL_MAX, oP3 = oE3 + RES_TAIL_MAX;
     constexpr int oRED = oP3 + RES_TAIL_MAX;          // 2*RES_WAVES doubles
-    constexpr int oOWN = oRED + 2 * RES_WAVES;        // 8 scalars of each wave's rows
+    constexpr int oPUB = oRED + 2 * RES_WAVES;        // values the waves publish this step (2 blocks)
+    constexpr int oOWN = oPUB + 2 * RES_WAVES;        // 8 scalars of each wave's rows
     int* fail = reinterpret_cast<int*>(sm + oOWN + 8 * RES_WAVES);
     long long* dbg_acc = reinterpret_cast<long long*>(sm + oOWN + 8 * RES_WAVES + 1);   // 3 words
     double* red = sm + oRED;
@@ -287,16 +288,28 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // STORE(j, v) is called for every granule of the thread; EXTRA() runs once per thread in the
     // store phase (fix-ups on rows the thread does not sweep); both may add to p0 / p1, whose block
     // totals are returned in t0 / t1.
-#define RES_HANDOFF(NJ, n, STORE, EXTRA, want_sums, t0, t1)                                        \
+    // The waves have left their values in sm[oPUB + w] (first block) / sm[oPUB + RES_WAVES + w]
+    // (second block); after the barrier -- which also ends the step's reads of the vectors that
+    // are about to change -- wave 0 publishes them: one store instruction, one 128-byte segment per
+    // block (a store per wave would be eight 16-byte partial-line writes: measured 2.6 us of waiting
+    // per hand-off against 1.4).  gA/cA, gB/cB: first granule and row count of the two blocks.
+#define RES_HANDOFF(NJ, n, gA, cA, gB, cB, STORE, EXTRA, want_sums, t0, t1)                        \
     do {                                                                                           \
         double hv_[NJ];                                                                            \
+        ++seq;                                                                                     \
+        __syncthreads();                                                                           \
+        if (w == 0) {                                                                              \
+            const int l8_ = lane & (RES_WAVES - 1);                                                \
+            const bool second_ = lane >= RES_WAVES;                                                \
+            if (lane < 2 * RES_WAVES && l8_ < (second_ ? (cB) : (cA)))                             \
+                res_publish(rs, seq, (second_ ? (gB) : (gA)) + l8_, sm[oPUB + lane]);              \
+        }                                                                                          \
         if (dbg) dbg_acc[0] -= __builtin_amdgcn_s_memtime();                                       \
         if (res_sweep<NJ>(rs, seq, (n), dead, D.tmo, hv_)) {                                          \
             *fail = 1;                                                                             \
             if (lane == 0) __hip_atomic_store(D.tmo, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-        }                                                       \
+        }                                                                                          \
         if (dbg) dbg_acc[0] += __builtin_amdgcn_s_memtime();                                       \
-        __syncthreads();                                                                           \
         double p0 = 0.0, p1 = 0.0;                                                                 \
         _Pragma("unroll") for (int u_ = 0; u_ < NJ; ++u_) {                                        \
             const int j = tid + u_ * BT;                                                           \
@@ -308,16 +321,16 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         EXTRA;                                                                                     \
         if (want_sums) {                                                                           \
             p0 = wave_sum(p0);                                                                     \
-            p1 = wave_sum(p1);                                                                     \
+            if ((want_sums) > 1) p1 = wave_sum(p1);                                                \
             if (lane == 0) {                                                                       \
                 red[w] = p0;                                                                       \
-                red[RES_WAVES + w] = p1;                                                           \
+                if ((want_sums) > 1) red[RES_WAVES + w] = p1;                                      \
             }                                                                                      \
         }                                                                                          \
         __syncthreads();                                                                           \
         if (want_sums) {                                                                           \
             t0 = res_red8(red);                                                                    \
-            t1 = res_red8(red + RES_WAVES);                                                        \
+            if ((want_sums) > 1) t1 = res_red8(red + RES_WAVES);                                   \
         }                                                                                          \
         if (*fail) dead = true;                                                                 \
     } while (0)
@@ -332,14 +345,13 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     auto top = [&]() {
         const double sF = wave_sum(res_rowdot<KE1, 8 * oX>(cF, aF, smb));
         const double sC = wave_sum(res_rowdot<KE1, 8 * oX>(cC, aC, smb));
-        ++seq;
         if (lane == 0) {
-            if (vF) res_publish(rs, seq, rowF, bF - (sF + dgF * sm[oX + rowF]));
-            if (vC) res_publish(rs, seq, rowC, bC - (sC + dgC * sm[oX + rowC]));
+            sm[oPUB + w] = bF - (sF + dgF * sm[oX + rF]);
+            sm[oPUB + RES_WAVES + w] = bC - (sC + dgC * sm[oX + rC]);
         }
         double nrm2 = 0.0, sumr = 0.0;
-        RES_HANDOFF(4, N1, { sm[oR1 + j] = v; sm[oE1 + j] = 0.0; p0 += v * v; p1 += v; }, {}, true, nrm2,
-                    sumr);
+        RES_HANDOFF(4, N1, loF, hiF - loF, loC, hiC - loC,
+                    { sm[oR1 + j] = v; sm[oE1 + j] = 0.0; p0 += v * v; p1 += v; }, {}, 2, nrm2, sumr);
         c1 = nsp ? sumr / xx1 : 0.0;
         return sqrt(nrm2);
     };
@@ -358,16 +370,16 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         const double g_i = sm[oR1 + rr_] - s - sm[oAX1 + rr_] * c1;
         const double wv = eo + (frows ? dvF : dvC) * g_i;
         const int blk0 = frows ? 0 : nf, nblk = frows ? nf : nc;
-        ++seq;
-        if (lane == 0 && valid) res_publish(rs, seq, row - blk0, wv);
+        if (lane == 0) sm[oPUB + w] = wv;
+        const int g0 = (frows ? loF : loC) - blk0, cnt = frows ? hiF - loF : hiC - loC;
         if (first) {
-            RES_HANDOFF(2, nblk, { sm[oE1 + blk0 + j] = v; }, {}, false, dum0, dum1);
+            RES_HANDOFF(2, nblk, g0, cnt, 0, 0, { sm[oE1 + blk0 + j] = v; }, {}, 0, dum0, dum1);
         } else {
             // other half: w -> w + c ; this half: wv + c ; scalar of the next sweep
             const int oth0 = frows ? nf : 0, noth = frows ? nc : nf;
             const double cc = c1;
             double xig = 0.0;
-            RES_HANDOFF(2, nblk,
+            RES_HANDOFF(2, nblk, g0, cnt, 0, 0,
                         {
                             const double en = v + cc;
                             sm[oE1 + blk0 + j] = en;
@@ -380,7 +392,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
                                 p0 += sm[oR1 + oth0 + jo] - sm[oAX1 + oth0 + jo] * en;
                             }
                         },
-                        nsp, xig, dum1);
+                        (nsp ? 1 : 0), xig, dum1);
             c1 = nsp ? xig / xx1 : 0.0;
         }
     };
@@ -399,17 +411,16 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         }
         const double g_i = sm[oR2 + r2] - s - sm[oAX2 + r2] * c2s;
         const double wv = eo + dv2 * g_i;
-        ++seq;
-        if (lane == 0 && v2) res_publish(rs, seq, row2, wv);
+        if (lane == 0) sm[oPUB + w] = wv;
         const double cc = c2s;
         double xig = 0.0;
-        RES_HANDOFF(4, N2,
+        RES_HANDOFF(4, N2, lo2, hi2 - lo2, 0, 0,
                     {
                         const double en = v + cc;
                         sm[oE2 + j] = en;
                         p0 += sm[oR2 + j] - sm[oAX2 + j] * en;
                     },
-                    {}, nsp, xig, dum1);
+                    {}, (nsp ? 1 : 0), xig, dum1);
         c2s = nsp ? xig / xx2 : 0.0;
     };
 
@@ -477,9 +488,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         // rr = r - A e                                                           MG_Vcycle.m:27
         {
             const double s = wave_sum(res_rowdot<KE2, 8 * oE2>(c2, a2, smb)) + dg2 * sm[oE2 + r2];
-            ++seq;
-            if (lane == 0 && v2) res_publish(rs, seq, row2, sm[oR2 + r2] - s);
-            RES_HANDOFF(4, N2, { sm[oRR2 + j] = v; }, {}, false, dum0, dum1);
+            if (lane == 0) sm[oPUB + w] = sm[oR2 + r2] - s;
+            RES_HANDOFF(4, N2, lo2, hi2 - lo2, 0, 0, { sm[oRR2 + j] = v; }, {}, 0, dum0, dum1);
         }
         tail();
         for (int s = 0; s < nu; ++s) sweep2(false);
@@ -492,33 +502,31 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         {   // rr = r - A e on both blocks
             const double sF = wave_sum(res_rowdot<KE1, 8 * oE1>(cF, aF, smb)) + dgF * sm[oE1 + rF];
             const double sC = wave_sum(res_rowdot<KE1, 8 * oE1>(cC, aC, smb)) + dgC * sm[oE1 + rC];
-            ++seq;
             if (lane == 0) {
-                if (vF) res_publish(rs, seq, rowF, sm[oR1 + rF] - sF);
-                if (vC) res_publish(rs, seq, rowC, sm[oR1 + rC] - sC);
+                sm[oPUB + w] = sm[oR1 + rF] - sF;
+                sm[oPUB + RES_WAVES + w] = sm[oR1 + rC] - sC;
             }
-            RES_HANDOFF(4, N1, { sm[oRR1 + j] = v; }, {}, false, dum0, dum1);
+            RES_HANDOFF(4, N1, loF, hiF - loF, loC, hiC - loC, { sm[oRR1 + j] = v; }, {}, 0, dum0, dum1);
         }
         {   // r_2 = P' rr ; E2 := 0 ; c for the zero start
             const double s = res_csr_rowdot(D.Pt2, r2, v2, lane, sm, oRR1);
-            ++seq;
-            if (lane == 0 && v2) res_publish(rs, seq, row2, s);
+            if (lane == 0) sm[oPUB + w] = s;
             double sumr = 0.0;
-            RES_HANDOFF(4, N2, { sm[oR2 + j] = v; sm[oE2 + j] = 0.0; p0 += v; }, {}, nsp, sumr, dum1);
+            RES_HANDOFF(4, N2, lo2, hi2 - lo2, 0, 0, { sm[oR2 + j] = v; sm[oE2 + j] = 0.0; p0 += v; }, {},
+                        (nsp ? 1 : 0), sumr, dum1);
             c2s = nsp ? sumr / xx2 : 0.0;
         }
         for (int leg = 0; leg < (D.wcycle ? 2 : 1); ++leg) visit2(leg == 1);      // MG_Wcycle.m:28-30
         {   // e_1 += P e_2                                                        MG_Vcycle.m:31
             const double sF = res_csr_rowdot(D.P2, rF, vF, lane, sm, oE2);
             const double sC = res_csr_rowdot(D.P2, rC, vC, lane, sm, oE2);
-            ++seq;
             if (lane == 0) {
-                if (vF) res_publish(rs, seq, rowF, sm[oE1 + rF] + sF);
-                if (vC) res_publish(rs, seq, rowC, sm[oE1 + rC] + sC);
+                sm[oPUB + w] = sm[oE1 + rF] + sF;
+                sm[oPUB + RES_WAVES + w] = sm[oE1 + rC] + sC;
             }
             double xig = 0.0;
-            RES_HANDOFF(4, N1, { sm[oE1 + j] = v; p0 += sm[oR1 + j] - sm[oAX1 + j] * v; }, {}, nsp, xig,
-                        dum1);
+            RES_HANDOFF(4, N1, loF, hiF - loF, loC, hiC - loC,
+                        { sm[oE1 + j] = v; p0 += sm[oR1 + j] - sm[oAX1 + j] * v; }, {}, (nsp ? 1 : 0), xig, dum1);
             c1 = nsp ? xig / xx1 : 0.0;
         }
         for (int s = 0; s < nu; ++s) sweep1(true, false);

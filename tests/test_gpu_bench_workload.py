@@ -67,7 +67,9 @@ def same_history(it, relk, itc, relkc, tol=1e-10):
     and the multi-launch kernels' own variants included -- so the counts may differ there, and
     only there."""
     k = min(it, itc) + 1
-    assert np.max(np.abs(relk[:k] - relkc[:k])) <= tol, (relk, relkc)
+    a, b = relk[:k], relkc[:k]
+    floor = (a <= 1e-9) & (b <= 1e-9)      # ||r|| ~ 1e-8 absolute there: pure rounding, any order
+    assert np.all((np.abs(a - b) <= tol) | floor), (relk, relkc)
     at_floor = max(relk[k - 1], relkc[k - 1]) <= 1e-9
     assert it == itc or (at_floor and abs(it - itc) <= 4), (it, itc, relk, relkc)
 
