@@ -1455,7 +1455,7 @@ extern "C" int ipd_amg_solve_mode(const ipd_amg* h, int32_t* mode, int32_t* grid
 }
 
 extern "C" int ipd_amg_bench_resident(ipd_amg* h, const double* b_dev, double* x_dev, int cycles,
-                                      double* total_ms, int64_t stamps[4]) {
+                                      double* total_ms, int64_t stamps[10]) {
     return ipd_guard([&] {
         IPD_REQUIRE(h && b_dev && x_dev && cycles > 0 && total_ms && stamps, IPD_E_ARG, "bad argument");
         ipd_ctx* ctx = h->ctx;
@@ -1472,9 +1472,9 @@ extern "C" int ipd_amg_bench_resident(ipd_amg* h, const double* b_dev, double* x
                     "resident kernel gave up (not every workgroup was resident)");
         IPD_HIP(hipMemcpyAsync(x_dev, h->x, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
                                ctx->stream));
-        long long hs[4];
-        ctx->fetch(dbg, hs, 4);
-        for (int i = 0; i < 4; ++i) stamps[i] = hs[i];
+        long long hs[10];
+        ctx->fetch(dbg, hs, 10);
+        for (int i = 0; i < 10; ++i) stamps[i] = hs[i];
         *total_ms = msf;
     });
 }

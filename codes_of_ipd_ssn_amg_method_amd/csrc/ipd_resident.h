@@ -41,7 +41,7 @@ static constexpr int RES_WAVES = BT / 64;     // row slots per block and workgro
 static constexpr int RES_TAIL_MAX = 64;       // rows of the redundantly solved tail level
 static constexpr int RES_NMAX = 4 * BT;        // rows per level (fixed LDS slots)
 static constexpr int RES_GRAN_MAX = RES_NMAX;  // granules per hand-off buffer
-static constexpr size_t RES_LDS_BYTES = sizeof(double) * ((size_t)9 * RES_NMAX + 3 * RES_TAIL_MAX + 12 * RES_WAVES + 6);
+static constexpr size_t RES_LDS_BYTES = sizeof(double) * ((size_t)9 * RES_NMAX + 3 * RES_TAIL_MAX + 12 * RES_WAVES + 12);
 static constexpr unsigned RES_SPIN_MAX = 1u << 18;
 
 struct ResLevelDesc {
@@ -204,7 +204,8 @@ __device__ __forceinline__ double res_red8(const double* red) {
 // out[0] = it, out[1] = rel_res, out[2] = res0; rel_resk at out[4 ..], rhok at out[4+maxit+2 ..]
 // (the layout of k_solve_small).  fixed_cycles > 0: exactly that many loop bodies, no stopping
 // rules (bench hook).  dbg (optional, 16 words): [0] shader clocks spent waiting in sweeps by
-// workgroup 0, [1] clocks of the whole loop, [2] number of hand-offs, [3] 100 MHz ticks of the loop.
+// workgroup 0, [1] clocks of the whole loop, [2] number of hand-offs, [3] 100 MHz ticks of the loop,
+// [4] clocks in the barrier before the publish, [5] in the store phase, [6] in the closing barrier.
 template <int KE1, int KE2>
 __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const double* __restrict__ bvec,
                                                     double* xg, double* out, int fixed_cycles) {
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     constexpr int oPUB = oRED + 2 * RES_WAVES;        // values the waves publish this step (2 blocks)
     constexpr int oOWN = oPUB + 2 * RES_WAVES;        // 8 scalars of each wave's rows
     int* fail = reinterpret_cast<int*>(sm + oOWN + 8 * RES_WAVES);
-    long long* dbg_acc = reinterpret_cast<long long*>(sm + oOWN + 8 * RES_WAVES + 1);   // 3 words
+    long long* dbg_acc = reinterpret_cast<long long*>(sm + oOWN + 8 * RES_WAVES + 1);   // 8 words
     double* red = sm + oRED;
 
     // ---- rows of this wave ------------------------------------------------------------------
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     bool dead = false;      // a spin gave up somewhere: skip every further wait
     const bool dbg = D.dbg != nullptr && b == 0 && tid == 0;
     if (dbg) {
-        dbg_acc[0] = 0;
+        dbg_acc[0] = dbg_acc[3] = dbg_acc[4] = dbg_acc[5] = dbg_acc[6] = dbg_acc[7] = 0;
         dbg_acc[1] = __builtin_amdgcn_s_memtime();
         dbg_acc[2] = __builtin_amdgcn_s_memrealtime();
     }
@@ -297,7 +298,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     do {                                                                                           \
         double hv_[NJ];                                                                            \
         ++seq;                                                                                     \
+        if (dbg) dbg_acc[3] -= __builtin_amdgcn_s_memtime();                                       \
         __syncthreads();                                                                           \
+        if (dbg) dbg_acc[3] += __builtin_amdgcn_s_memtime();                                       \
         if (w == 0) {                                                                              \
             const int l8_ = lane & (RES_WAVES - 1);                                                \
             const bool second_ = lane >= RES_WAVES;                                                \
@@ -309,7 +312,11 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
             *fail = 1;                                                                             \
             if (lane == 0) __hip_atomic_store(D.tmo, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
         }                                                                                          \
-        if (dbg) dbg_acc[0] += __builtin_amdgcn_s_memtime();                                       \
+        if (dbg) {                                                                                 \
+            const long long t_ = __builtin_amdgcn_s_memtime();                                     \
+            dbg_acc[0] += t_;                                                                      \
+            dbg_acc[4] -= t_;                                                                      \
+        }                                                                                          \
         double p0 = 0.0, p1 = 0.0;                                                                 \
         _Pragma("unroll") for (int u_ = 0; u_ < NJ; ++u_) {                                        \
             const int j = tid + u_ * BT;                                                           \
@@ -327,7 +334,13 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
                 if ((want_sums) > 1) red[RES_WAVES + w] = p1;                                      \
             }                                                                                      \
         }                                                                                          \
+        if (dbg) {                                                                                 \
+            const long long t_ = __builtin_amdgcn_s_memtime();                                     \
+            dbg_acc[4] += t_;                                                                      \
+            dbg_acc[5] -= t_;                                                                      \
+        }                                                                                          \
         __syncthreads();                                                                           \
+        if (dbg) dbg_acc[5] += __builtin_amdgcn_s_memtime();                                       \
         if (want_sums) {                                                                           \
             t0 = res_red8(red);                                                                    \
             if ((want_sums) > 1) t1 = res_red8(red + RES_WAVES);                                   \
@@ -491,7 +504,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
             if (lane == 0) sm[oPUB + w] = sm[oR2 + r2] - s;
             RES_HANDOFF(4, N2, lo2, hi2 - lo2, 0, 0, { sm[oRR2 + j] = v; }, {}, 0, dum0, dum1);
         }
+        if (dbg) dbg_acc[7] -= __builtin_amdgcn_s_memtime();
         tail();
+        if (dbg) dbg_acc[7] += __builtin_amdgcn_s_memtime();
         for (int s = 0; s < nu; ++s) sweep2(false);
     };
 
@@ -509,7 +524,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
             RES_HANDOFF(4, N1, loF, hiF - loF, loC, hiC - loC, { sm[oRR1 + j] = v; }, {}, 0, dum0, dum1);
         }
         {   // r_2 = P' rr ; E2 := 0 ; c for the zero start
+            if (dbg) dbg_acc[6] -= __builtin_amdgcn_s_memtime();
             const double s = res_csr_rowdot(D.Pt2, r2, v2, lane, sm, oRR1);
+            if (dbg) dbg_acc[6] += __builtin_amdgcn_s_memtime();
             if (lane == 0) sm[oPUB + w] = s;
             double sumr = 0.0;
             RES_HANDOFF(4, N2, lo2, hi2 - lo2, 0, 0, { sm[oR2 + j] = v; sm[oE2 + j] = 0.0; p0 += v; }, {},
@@ -518,8 +535,10 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         }
         for (int leg = 0; leg < (D.wcycle ? 2 : 1); ++leg) visit2(leg == 1);      // MG_Wcycle.m:28-30
         {   // e_1 += P e_2                                                        MG_Vcycle.m:31
+            if (dbg) dbg_acc[6] -= __builtin_amdgcn_s_memtime();
             const double sF = res_csr_rowdot(D.P2, rF, vF, lane, sm, oE2);
             const double sC = res_csr_rowdot(D.P2, rC, vC, lane, sm, oE2);
+            if (dbg) dbg_acc[6] += __builtin_amdgcn_s_memtime();
             if (lane == 0) {
                 sm[oPUB + w] = sm[oE1 + rF] + sF;
                 sm[oPUB + RES_WAVES + w] = sm[oE1 + rC] + sC;
@@ -606,6 +625,11 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         D.dbg[1] = __builtin_amdgcn_s_memtime() - dbg_acc[1];
         D.dbg[2] = seq;
         D.dbg[3] = __builtin_amdgcn_s_memrealtime() - dbg_acc[2];
+        D.dbg[4] = dbg_acc[3];
+        D.dbg[5] = dbg_acc[4];
+        D.dbg[6] = dbg_acc[5];
+        D.dbg[7] = dbg_acc[6];
+        D.dbg[8] = dbg_acc[7];
     }
 #undef RES_HANDOFF
 #undef dgF

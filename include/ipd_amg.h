@@ -382,9 +382,12 @@ int ipd_amg_cycle_bytes(const ipd_amg* h, double* bytes_per_cycle);
 int ipd_amg_solve_mode(const ipd_amg* h, int32_t* mode, int32_t* grid, int32_t* timeouts);
 /* Mode 2 only: `cycles` loop bodies in one launch with in-kernel stamps of workgroup 0:
  * stamps[0] shader clocks spent waiting in hand-off sweeps, [1] shader clocks of the launch,
- * [2] hand-offs, [3] 100 MHz ticks of the launch.  total_ms: HIP events.        */
+ * [2] hand-offs, [3] 100 MHz ticks of the launch, [4] clocks in the barrier ahead of the
+ * publish (the wave's wait for the workgroup's slowest row), [5] in the store phase,
+ * [6] in the closing barrier, [7] in the CSR row walks of the two transfers, [8] in the tail
+ * level's solve; the rest is the row dot products.  total_ms: HIP events.          */
 int ipd_amg_bench_resident(ipd_amg* h, const double* b_dev, double* x_dev, int cycles,
-                           double* total_ms, int64_t stamps[4]);
+                           double* total_ms, int64_t stamps[10]);
 
 /* Wall-clock attribution of the driver's phases when IPD_PROFILE=1 (each phase is then
  * bracketed by stream synchronisations).  Slots: 0 ASAt, 1 build Ae, 2 components,

@@ -34,10 +34,12 @@ def _run(lib, fn, h, f, x0, cycles):
     return x
 
 
-@pytest.mark.parametrize("mask,cycle", [("dense", "v"), ("tree", "v"), ("tree", "w")])
-def test_sharded_emulation_is_bit_exact(ipd, mask, cycle):
+@pytest.mark.parametrize("mask,cycle,N1", [("dense", "v", 512), ("tree", "v", 512), ("tree", "w", 512),
+                                           ("dense", "v", 2048)])
+def test_sharded_emulation_is_bit_exact(ipd, mask, cycle, N1):
+    """N1 = 2048 is BASELINE config 4's size (m=n=2048, M = 4096, 8 owners)."""
     from codes_of_ipd_ssn_amg_method_amd import _lib
-    m = n = 512
+    m = n = N1
     s = PR.mask_bernoulli(m, n, 1.0) if mask == "dense" else PR.mask_tree(m, n, seed=3)
     Ae, pd = newton_matrix(m, n, s)
     f = np.concatenate([pd["q"], -pd["p"]]) * pd["z"]
@@ -45,16 +47,18 @@ def test_sharded_emulation_is_bit_exact(ipd, mask, cycle):
     o = O.amg_options_class1(cycle)
     o.update(fnode=n, isnsp=1)
     os.environ["IPD_NO_SMALL"] = "1"   # compare like with like: the multi-launch path
+    os.environ["IPD_NO_RESIDENT"] = "1"
     try:
         h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
     finally:
         os.environ.pop("IPD_NO_SMALL")
+        os.environ.pop("IPD_NO_RESIDENT")
     ref = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles, h, f, x0, 3)
     os.environ["IPD_NO_GRAPH"] = "1"
     eager = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles, h, f, x0, 3)
     os.environ.pop("IPD_NO_GRAPH")
     assert np.array_equal(ref, eager)           # graph replay == eager launches
-    for G in (2, 4, 8):
+    for G in ((8,) if N1 > 512 else (2, 4, 8)):
         os.environ["IPD_SHARD_EMULATE"] = str(G)
         try:
             got = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles_sharded, h, f, x0, 3)
@@ -75,10 +79,12 @@ def test_rccl_communicator_of_one(ipd):
     o = O.amg_options_class1("v")
     o.update(fnode=n, isnsp=1)
     os.environ["IPD_NO_SMALL"] = "1"
+    os.environ["IPD_NO_RESIDENT"] = "1"
     try:
         h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
     finally:
         os.environ.pop("IPD_NO_SMALL")
+        os.environ.pop("IPD_NO_RESIDENT")
     ref = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles, h, f, x0, 2)
     ident = np.zeros(_lib.COMM_ID_BYTES, np.uint8)
     _lib.check(_lib.lib.ipd_comm_get_unique_id(_lib.bptr(ident)))

@@ -31,16 +31,21 @@ def main():
     h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
     db = _lib.DeviceBuffer.from_array(f)
     dx = _lib.DeviceBuffer.from_array(guess)
-    st = (c_int64 * 4)()
+    st = (c_int64 * 10)()
     ms = c_double()
     for rep in range(3):
         _lib.check(_lib.lib.ipd_amg_bench_resident(h.handle, db.ptr, dx.ptr, c_int(a.cycles), byref(ms), st))
-        wait, tot, nh, ticks = [int(v) for v in st]
+        wait, tot, nh, ticks, bar1, store, bar2, xfer, tail = [int(v) for v in st][:9]
         clk_mhz = tot / (ticks / 100.0)
         print("cycles=%d  %.3f ms  -> %.2f us/cycle, %d hand-offs (%.1f per cycle, %.2f us each); "
               "workgroup 0: waiting in sweeps %.1f %% (%.2f us per hand-off), shader clock %.0f MHz"
               % (a.cycles, ms.value, 1e3 * ms.value / a.cycles, nh, nh / a.cycles,
                  1e3 * ms.value / nh, 100.0 * wait / tot, wait / clk_mhz / nh, clk_mhz))
+        rest = tot - wait - bar1 - store - bar2 - xfer - tail
+        print("   per cycle (us): transfers (CSR walks of P', P) %.2f | tail level %.2f" % (
+            xfer / clk_mhz / a.cycles, tail / clk_mhz / a.cycles))
+        print("   per hand-off (us): row work %.2f | barrier before publish %.2f | sweep wait %.2f | "
+              "store+sums %.2f | closing barrier %.2f" % tuple(v / clk_mhz / nh for v in (rest, bar1, wait, store, bar2)))
 
 
 if __name__ == "__main__":
