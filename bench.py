@@ -152,11 +152,13 @@ def main():
     dx = _lib.DeviceBuffer.from_array(guess)
 
     sharded = world > 1 and args.mode == "sharded"
-    shard_note = None
+    rccl = None
     if sharded:
         # RCCL communicator for the in-library all-gathers; the unique id travels over gloo.
+        # A rank that cannot join makes EVERY rank exit non-zero: a replicas number printed
+        # where the sharded one is expected would be read as the scaling curve.
         import torch
-        ok = 1
+        ok, why = 1, ""
         try:
             idbuf = np.zeros(_lib.COMM_ID_BYTES, np.uint8)
             if rank == 0:
@@ -165,14 +167,25 @@ def main():
             dist.broadcast(t, 0)
             _lib.check(_lib.lib.ipd_comm_init(ctx.handle, _lib.bptr(idbuf), c_int(rank),
                                               c_int(world)))
-        except Exception as exc:  # every rank must take the same path: agree over gloo
-            ok = 0
-            shard_note = "RCCL init failed (%s)" % (str(exc)[:120],)
+        except Exception as exc:
+            ok, why = 0, str(exc)
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            sharded = False
-            shard_note = shard_note or "RCCL init failed on another rank"
+            sys.stderr.write("bench.py: rank %d of %d: RCCL communicator could not be set up%s; "
+                             "no sharded number can be measured -- exiting (use --mode replicas for "
+                             "independent systems)\n" % (rank, world, (": " + why) if why else
+                                                         " on another rank"))
+            sys.stderr.flush()
+            dist.destroy_process_group()
+            sys.exit(2)
+        from ctypes import c_int32 as _ci32
+        rr_, nn_ = _ci32(), _ci32()
+        _lib.check(_lib.lib.ipd_comm_stats(ctx.handle, byref(rr_), byref(nn_), None, None, _ci32(1)))
+        rccl = {"nranks_seen_by_rccl": int(nn_.value), "rank_seen_by_rccl": int(rr_.value)}
+        if rccl["nranks_seen_by_rccl"] != world:
+            sys.stderr.write("bench.py: RCCL reports %d ranks, launched %d\n" % (nn_.value, world))
+            sys.exit(2)
 
     def run_with(fn, cycles):
         ms, bpc = c_double(), c_double()
@@ -204,6 +217,12 @@ def main():
     replicas_result = None
     if sharded:
         wall, ev_ms, bytes_per_cycle = timed(_lib.lib.ipd_amg_bench_cycles_sharded)
+        ag, agv = c_int64(), c_int64()
+        from ctypes import c_int32 as _ci32
+        _lib.check(_lib.lib.ipd_comm_stats(ctx.handle, None, None, byref(ag), byref(agv), _ci32(0)))
+        ncyc = args.steps + max(args.warmup, 0)
+        rccl["allgather_launches_per_cycle"] = ag.value / ncyc
+        rccl["allgather_vectors_per_cycle"] = agv.value / ncyc
         # the throughput-oriented alternative of SURVEY 8e, reported beside the sharded curve
         rwall, _, _ = timed(_lib.lib.ipd_amg_bench_cycles)
         replicas_result = {"value": args.steps * M * world / rwall, "unit": "DoF*cycles/s",
@@ -248,6 +267,27 @@ def main():
 
     units = args.steps * M * (world if (world > 1 and not sharded) else 1)
     value = units / wall
+
+    # did the timed steps do the work?  relative residual of the iterate they left behind
+    # (warm-up + timed loop bodies, Class_AMG.m:103-104); a run that does not contract is an error
+    from ctypes import c_int32 as _ci32
+    x_end = dx.to_array(np.float64, M)
+    r0 = float(np.linalg.norm(Ae @ guess - f))
+    rel_res_after = float(np.linalg.norm(Ae @ x_end - f)) / r0
+    mode_, grid_, tmo_ = _ci32(), _ci32(), _ci32()
+    _lib.check(_lib.lib.ipd_amg_solve_mode(h.handle, byref(mode_), byref(grid_), byref(tmo_)))
+    resident = mode_.value == 2 and not sharded
+    if not np.isfinite(rel_res_after) or rel_res_after > 1e-6:
+        sys.stderr.write("bench.py: the timed cycles did not contract the residual "
+                         "(rel_res_after_steps = %g)\n" % rel_res_after)
+        sys.exit(3)
+    if tmo_.value:
+        sys.stderr.write("bench.py: %d launch(es) of the resident kernel gave up (workgroups not "
+                         "co-resident) and were redone by the multi-launch path\n" % tmo_.value)
+    nu = opts["smoth"]
+    visits2 = 2 if args.cycle == "w" else 1
+    launches_classic = 4 * nu + 2 + visits2 * (2 * nu + 4) + 1 + 2    # sweeps, resid, transfers, PCG, top, norm
+    handoffs = 4 * nu + 3 + visits2 * (2 * nu + 1) + 1 if h.J == 3 else None
     result = {
         "metric": "V-cycle throughput (DoF*cycles/sec), m=n=%d OT grid" % m,
         "value": value, "unit": "DoF*cycles/s", "n_gpus": world, "steps": args.steps,
@@ -265,9 +305,16 @@ def main():
         "cycle_bytes_algorithmic": bytes_per_cycle,
         "cycle_GBps_algorithmic": bytes_per_cycle * args.steps / wall / 1e9,
         "device_ms_per_step_events": ev_ms / args.steps,
+        "rel_res_after_steps": rel_res_after,
+        "execution": ({"mode": "level-resident kernel (csrc/ipd_resident.h): the timed steps are ONE launch",
+                       "workgroups": grid_.value, "launches_per_cycle": 1.0 / args.steps,
+                       "handoffs_per_cycle": handoffs, "resident_kernel_timeouts": tmo_.value}
+                      if resident else
+                      {"mode": "one launch per phase" + (", graph replay" if not sharded else ", eager + RCCL"),
+                       "launches_per_cycle": launches_classic if h.J == 3 else None}),
         "replicas": replicas_result,
         "batched": batched,
-        "shard_note": shard_note,
+        "rccl": rccl,
         "setup_seconds_host_api": setup_s,
     }
 
@@ -307,8 +354,8 @@ def main():
         # HBM traffic per launch of the same kernel from the committed rocprofv3 PMC passes
         # (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, gfx950 x2 read
         # correction applied by tools/summarize_pmc.py); null when no profile is present
-        traffic = None
         import glob
+        traffic = None
         for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))[-1:]:
             try:
                 pm = json.load(open(pf))
@@ -322,12 +369,41 @@ def main():
                         traffic = d["hbm_traffic_bytes_per_launch"]
             except Exception:
                 traffic = None
-        result["roofline"] = {"bound": "hbm", "kernel": "k_smooth", "achieved": achieved,
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                              "traffic": traffic,
-                              "avg_us_per_launch": 1e3 * tot_ms / launches if launches else None,
-                              "avg_bytes_per_launch": tot_bytes / launches if launches else None,
-                              "per_level": per_level}
+        ksm = {"bound": "hbm", "kernel": "k_smooth", "achieved": achieved,
+               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "traffic": traffic,
+               "avg_us_per_launch": 1e3 * tot_ms / launches if launches else None,
+               "avg_bytes_per_launch": tot_bytes / launches if launches else None,
+               "per_level": per_level}
+        if resident:
+            # The dominant kernel IS the whole timed region: one launch of k_resident runs the
+            # `steps` loop bodies.  achieved = algorithmic bytes of the launch (B_V of SURVEY 8d
+            # x steps) / its duration (HIP events on the library's stream).  The kernel moves far
+            # fewer bytes than that: the matrices of levels 1-2 are read ONCE per launch into
+            # registers, so `traffic` (PMC, per launch of `steps` cycles) is tiny beside it.
+            ach = bytes_per_cycle * args.steps / ev_ms / 1e6
+            tr = None
+            for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))[-1:]:
+                try:
+                    d = json.load(open(pf)).get("k_resident")
+                    if d:   # traffic = fixed part (matrix load) + per-cycle part, from two dispatches
+                        tr = d["hbm_traffic_bytes_fixed"] + d["hbm_traffic_bytes_per_cycle"] * args.steps
+                except Exception:
+                    tr = None
+            result["roofline"] = {
+                "bound": "hbm", "kernel": "k_resident", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr,
+                "cycles_per_launch": args.steps, "us_per_launch": 1e3 * ev_ms,
+                "algorithmic_bytes_per_launch": bytes_per_cycle * args.steps,
+                "us_per_handoff": 1e3 * ev_ms / (args.steps * handoffs) if handoffs else None,
+                "note": "algorithmic bytes (every sweep re-reads its matrix) over time: the kernel "
+                        "itself keeps the matrices in registers, and the 38 MB hierarchy is "
+                        "Infinity-Cache resident anyway, so FETCH_SIZE/WRITE_SIZE are not HBM bytes "
+                        "here; the step is latency-bound (hand-off ~1 us + dependent row work), "
+                        "see profiles/r2_resident_stamps.txt",
+                "multi_launch_k_smooth": ksm}
+        else:
+            result["roofline"] = ksm
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(Ae, f, guess, opts, n)
             result["cpu_baseline"]["host_cores_available"] = os.cpu_count()

@@ -9,6 +9,8 @@
 struct RcclState {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    long long allgather_calls = 0;   // grouped launches
+    long long allgather_vectors = 0; // ncclAllGather calls inside them
 };
 
 #define IPD_NCCL(expr)                                                                    \
@@ -41,6 +43,8 @@ void comm_allgather_inplace(ipd_ctx* ctx, double* const* bases, int nvec, int co
         IPD_NCCL(ncclAllGather(bases[v] + (size_t)c->rank * count, bases[v], (size_t)count,
                                ncclDouble, c->comm, ctx->stream));
     IPD_NCCL(ncclGroupEnd());
+    c->allgather_calls += 1;
+    c->allgather_vectors += nvec;
 }
 
 extern "C" int ipd_comm_get_unique_id(uint8_t id[IPD_COMM_ID_BYTES]) {
@@ -67,6 +71,25 @@ extern "C" int ipd_comm_init(ipd_ctx* ctx, const uint8_t id[IPD_COMM_ID_BYTES], 
         std::memcpy(&u, id, sizeof(u));
         IPD_NCCL(ncclCommInitRank(&st->comm, nranks, u, rank));
         ctx->comm = st.release();
+    });
+}
+
+// What RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank) and how
+// many all-gathers the library has issued on it since ipd_comm_init (reset = 1 zeroes them).
+extern "C" int ipd_comm_stats(ipd_ctx* ctx, int32_t* rank, int32_t* nranks, int64_t* allgather_calls,
+                              int64_t* allgather_vectors, int32_t reset) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx, IPD_E_ARG, "ctx is NULL");
+        RcclState* c = ctx->comm;
+        IPD_REQUIRE(c && c->comm, IPD_E_COMM, "communicator not initialised (ipd_comm_init)");
+        int r = 0, n = 0;
+        IPD_NCCL(ncclCommUserRank(c->comm, &r));
+        IPD_NCCL(ncclCommCount(c->comm, &n));
+        if (rank) *rank = r;
+        if (nranks) *nranks = n;
+        if (allgather_calls) *allgather_calls = c->allgather_calls;
+        if (allgather_vectors) *allgather_vectors = c->allgather_vectors;
+        if (reset) c->allgather_calls = c->allgather_vectors = 0;
     });
 }
 

@@ -400,6 +400,10 @@ int ipd_prof_read(double* seconds, int64_t* calls, int32_t reset);
 int ipd_comm_get_unique_id(uint8_t id[IPD_COMM_ID_BYTES]);
 int ipd_comm_init(ipd_ctx*, const uint8_t id[IPD_COMM_ID_BYTES], int rank, int nranks);
 int ipd_comm_finalize(ipd_ctx*);
+/* Rank and size as RCCL reports them for the context's communicator, and the all-gathers issued
+ * on it so far: grouped launches and the vectors inside them; reset != 0 zeroes the counts.   */
+int ipd_comm_stats(ipd_ctx*, int32_t* rank, int32_t* nranks, int64_t* allgather_calls,
+                   int64_t* allgather_vectors, int32_t reset);
 /* Row-block sharded variant of ipd_amg_bench_cycles: every rank holds the same
  * hierarchy, owns rows [rank*N_k/G, (rank+1)*N_k/G) of every level, and the
  * iterate is re-assembled with ncclAllGather after each smoother half-sweep.  */

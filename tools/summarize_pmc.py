@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc counter_collection.csv files into per-kernel means.
 
-usage: summarize_pmc.py OUT.json NAME=counter_collection.csv [NAME=...]
+usage: summarize_pmc.py OUT.json NAME=counter_collection.csv [NAME=...] [RESIDENT_CYCLES=w,k]
+RESIDENT_CYCLES: the profiled command launched k_resident twice, with w (warm-up) and k (timed)
+cycles; its traffic is then split into a fixed part (the one read of the matrices into registers)
+and a per-cycle part (hand-off granules, transfer operators): "k_resident" entry.
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB per dispatch.  On gfx950
 FETCH_SIZE counts 64 B per 128-B request for wide coalesced streaming reads
 (MI355X_MICROARCH.md, section HBM): hbm_read_bytes = 2 * FETCH_SIZE * 1024.
@@ -15,8 +18,13 @@ import sys
 def main():
     out = sys.argv[1]
     res = collections.defaultdict(dict)
+    res_cycles = None
+    per_dispatch = collections.defaultdict(dict)
     for arg in sys.argv[2:]:
         name, path = arg.split("=", 1)
+        if name == "RESIDENT_CYCLES":
+            res_cycles = [int(v) for v in path.split(",")]
+            continue
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == name:
@@ -24,6 +32,8 @@ def main():
         for k, v in agg.items():
             res[k][name + "_KiB_mean"] = sum(v) / len(v)
             res[k]["dispatches_" + name] = len(v)
+            if "k_resident" in k:
+                per_dispatch[k][name] = v
     for k, d in res.items():
         f = d.get("FETCH_SIZE_KiB_mean")
         w = d.get("WRITE_SIZE_KiB_mean")
@@ -33,6 +43,14 @@ def main():
             d["hbm_write_bytes_per_launch"] = w * 1024.0
         if f is not None and w is not None:
             d["hbm_traffic_bytes_per_launch"] = 2.0 * f * 1024.0 + w * 1024.0
+    for k, d in per_dispatch.items():
+        if res_cycles and all(len(d.get(n, [])) == len(res_cycles) for n in ("FETCH_SIZE", "WRITE_SIZE")):
+            tr = [2.0 * f * 1024.0 + w * 1024.0 for f, w in zip(d["FETCH_SIZE"], d["WRITE_SIZE"])]
+            (c0, c1), (t0, t1) = res_cycles[:2], tr[:2]
+            per = (t1 - t0) / (c1 - c0)
+            res["k_resident"] = {"kernel": k, "dispatch_cycles": res_cycles, "hbm_traffic_bytes": tr,
+                                 "hbm_traffic_bytes_per_cycle": per,
+                                 "hbm_traffic_bytes_fixed": t0 - per * c0}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 
 
