@@ -143,6 +143,7 @@ struct ipd_ctx {
     volatile unsigned* mailbox = nullptr;   // [0] ticket, [16..48) payload words
     unsigned mailbox_ticket = 0;
     int num_cu = 256;
+    long long asat_nnz_hint = 0;   // entries of the last ASAt result (sizes the next one's arrays)
     RcclState* comm = nullptr;
     ipd_ctx* aux = nullptr;   // second stream/arena for work that overlaps with this context's
 

@@ -180,6 +180,18 @@ struct AsatPlan {
     int* rowlen;                  // [n+m]
 };
 
+// WIDE: m % 8 == 0 and s 8-byte aligned -- lane l reads the 64 bytes of column j0+l as eight
+// 8-byte words and packs each to 8 bits (nonzero byte -> bit), so the lane's column mask needs
+// no ballot; otherwise byte loads + one ballot per column.
+__device__ __forceinline__ unsigned bytes_to_bits(unsigned long long x) {
+    x |= x >> 4;
+    x |= x >> 2;
+    x |= x >> 1;
+    x &= 0x0101010101010101ull;
+    return (unsigned)((x * 0x0102040810204080ull) >> 56);
+}
+
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_asat_masks(const uint8_t* __restrict__ s, AsatPlan pl) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -188,13 +200,25 @@ __global__ __launch_bounds__(256) void k_asat_masks(const uint8_t* __restrict__ 
     const int i0 = ib * 64, j0 = jb * 64;
     const int i = i0 + lane;
     unsigned long long colm = 0ull;
+    if (WIDE && i0 + 64 <= pl.m) {
+        const int j = j0 + lane;
+        const unsigned long long* src =
+            reinterpret_cast<const unsigned long long*>(s + (size_t)(j < pl.n ? j : 0) * pl.m + i0);
+        unsigned long long wd[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wd[k] = src[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) colm |= (unsigned long long)bytes_to_bits(wd[k]) << (8 * k);
+        if (j >= pl.n) colm = 0ull;
+    } else {
 #pragma unroll 8
-    for (int jj = 0; jj < 64; ++jj) {
-        const int j = j0 + jj;
-        uint8_t b = 0;
-        if (i < pl.m && j < pl.n) b = s[(size_t)j * pl.m + i];
-        const unsigned long long mk = __ballot(b != 0);
-        if (lane == jj) colm = mk;
+        for (int jj = 0; jj < 64; ++jj) {
+            const int j = j0 + jj;
+            uint8_t b = 0;
+            if (i < pl.m && j < pl.n) b = s[(size_t)j * pl.m + i];
+            const unsigned long long mk = __ballot(b != 0);
+            if (lane == jj) colm = mk;
+        }
     }
     unsigned long long rowm = 0ull;
 #pragma unroll 8
@@ -236,83 +260,170 @@ __global__ __launch_bounds__(256) void k_asat_offsets(AsatPlan pl, const double*
     }
 }
 
+// Off-diagonal entries.  One wave per 64x64 tile; for every column (then every row) of the tile
+// that has entries, lane b owns bit b of its mask word and writes its entry at the word's base
+// position + the number of set bits below b: the 64 stores of a step are consecutive entries
+// (one lane walking its own row wrote with a stride of a whole row: 50 us at rho = 1, m=n=1024,
+// for 25 MB; this takes 9).
+__device__ __forceinline__ unsigned long long wave_bcast64(unsigned long long v, int srclane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, srclane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), srclane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double wave_bcast_f64(double v, int srclane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), srclane),
+                            __builtin_amdgcn_readlane(__double2loint(v), srclane));
+}
+
 __global__ __launch_bounds__(256) void k_asat_fill(AsatPlan pl, const double* __restrict__ p,
                                                    const double* __restrict__ q,
                                                    const int* __restrict__ rp,
-                                                   int* __restrict__ ci, double* __restrict__ va) {
+                                                   int* __restrict__ ci, double* __restrict__ va,
+                                                   int cap /* entries allocated */) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= pl.nib * pl.njb) return;
     const int ib = tile % pl.nib, jb = tile / pl.nib;
     const int i0 = ib * 64, j0 = jb * 64;
-    {   // rows [0,n): column j of Y
-        const int j = j0 + lane;
-        if (j < pl.n) {
-            unsigned long long cm = pl.colmask[(size_t)ib * pl.n + j];
-            if (cm) {
-                int pos = rp[j] + 1 + pl.coloff[(size_t)ib * pl.n + j];
-                const double qj = q[j];
-                while (cm) {
-                    const int b = __ffsll((long long)cm) - 1;
-                    cm &= cm - 1ull;
-                    const int i = i0 + b;
-                    ci[pos] = pl.n + i;
-                    va[pos] = qj * p[i];  // q_j * (p_i * Y_ij)
-                    ++pos;
-                }
+    const int il = i0 + lane, jl = j0 + lane;
+    const bool iok = il < pl.m, jok = jl < pl.n;
+    const unsigned long long colm = jok ? pl.colmask[(size_t)ib * pl.n + jl] : 0ull;
+    const unsigned long long rowm = iok ? pl.rowmask[(size_t)jb * pl.m + il] : 0ull;
+    const int cpos = jok ? rp[jl] + 1 + pl.coloff[(size_t)ib * pl.n + jl] : 0;
+    const int rpos = iok ? rp[pl.n + il] + pl.rowoff[(size_t)jb * pl.m + il] : 0;
+    const double pv = iok ? p[il] : 0.0, qv = jok ? q[jl] : 0.0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // rows [0,n): column j of Y -> entries (j, n+i), ascending i
+    for (unsigned long long nz = __ballot(colm != 0ull); nz; nz &= nz - 1ull) {
+        const int jj = __ffsll((long long)nz) - 1;
+        const unsigned long long cm = wave_bcast64(colm, jj);
+        const int pos0 = __builtin_amdgcn_readlane(cpos, jj);
+        const double qj = wave_bcast_f64(qv, jj);
+        if ((cm >> lane) & 1ull) {
+            const int pos = pos0 + __popcll(cm & below);
+            if (pos < cap) {
+                ci[pos] = pl.n + il;
+                va[pos] = qj * pv;   // q_j * (p_i * Y_ij)
             }
         }
     }
-    {   // rows [n,n+m): row i of Y
-        const int i = i0 + lane;
-        if (i < pl.m) {
-            unsigned long long rm = pl.rowmask[(size_t)jb * pl.m + i];
-            if (rm) {
-                int pos = rp[pl.n + i] + pl.rowoff[(size_t)jb * pl.m + i];
-                const double pi = p[i];
-                while (rm) {
-                    const int b = __ffsll((long long)rm) - 1;
-                    rm &= rm - 1ull;
-                    const int j = j0 + b;
-                    ci[pos] = j;
-                    va[pos] = pi * q[j];  // p_i * (Y_ij * q_j)
-                    ++pos;
-                }
+    // rows [n,n+m): row i of Y -> entries (n+i, j), ascending j
+    for (unsigned long long nz = __ballot(rowm != 0ull); nz; nz &= nz - 1ull) {
+        const int ii = __ffsll((long long)nz) - 1;
+        const unsigned long long rm = wave_bcast64(rowm, ii);
+        const int pos0 = __builtin_amdgcn_readlane(rpos, ii);
+        const double pi = wave_bcast_f64(pv, ii);
+        if ((rm >> lane) & 1ull) {
+            const int pos = pos0 + __popcll(rm & below);
+            if (pos < cap) {
+                ci[pos] = jl;
+                va[pos] = pi * qv;   // p_i * (Y_ij * q_j)
             }
         }
     }
 }
 
-// Diagonal values, accumulated sequentially in ascending index order exactly as
-// the sparse products U'*p and Q*q of ASAt.m:19 do (one lane per H row).
-__global__ __launch_bounds__(256) void k_asat_diag(AsatPlan pl, const double* __restrict__ p,
-                                                   const double* __restrict__ q,
-                                                   const int* __restrict__ rp,
-                                                   int* __restrict__ ci, double* __restrict__ va) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < pl.n) {
-        const int cnt = pl.cntc[t];
-        if (cnt > 0) {
-            const int pos = rp[t];
-            double sum = 0.0;
-            for (int e = pos + 1; e <= pos + cnt; ++e) {
-                const double pi = p[ci[e] - pl.n];
-                sum = sum + pi * pi;  // (p_i*Y_ij) * p_i
-            }
-            ci[pos] = t;
-            va[pos] = sum;
+// Diagonal values, accumulated sequentially in ascending index order exactly as the sparse
+// products U'*p and Q*q of ASAt.m:19 do.  The order of the ADDS is what the bits fix, not the
+// order of the loads.  A lane owns one H row and walks the row's words of the bit mask (coalesced
+// across the 64 rows of the wave; not the column indices the fill pass wrote, so no dependent
+// gather); per tile, lane l squares entry l of p (or q) -- the next tile's already in flight --
+// and the wave loops, with a scalar bit scan, over the bit positions ANY of its rows has: the
+// square comes out of lane b's register (v_readlane), a row without the bit adds +0.0, which
+// leaves its sum as it is.  Nothing but the mask words and the vector is read.
+// (One lane per row walking ci[e] -> p[ci[e]] in memory took 439 us at rho = 1, m=n=1024.)
+// Blocks [0, nbc) are the rows [0,n) (column sums, vector p), the others the rows [n,n+m).
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__global__ __launch_bounds__(64) void k_asat_diag(AsatPlan pl, const double* __restrict__ p,
+                                                  const double* __restrict__ q, int nbc,
+                                                  const int* __restrict__ rp, int* __restrict__ ci,
+                                                  double* __restrict__ va, int cap) {
+    const int lane = threadIdx.x;
+    const int side = blockIdx.x >= nbc ? 1 : 0;                 // uniform
+    const int nrow = side ? pl.m : pl.n, len = side ? pl.n : pl.m;
+    const int nt = side ? pl.njb : pl.nib;
+    const double* __restrict__ vec = side ? q : p;
+    const unsigned long long* __restrict__ masks = side ? pl.rowmask : pl.colmask;
+    const int idx = (blockIdx.x - (side ? nbc : 0)) * 64 + lane;
+    const bool live = idx < nrow;
+    const int ic = live ? idx : 0;
+    const int cnt = live ? (side ? pl.cntr[ic] : pl.cntc[ic]) : 0;
+    double sum = 0.0;
+    constexpr int CH = 8;    // tiles whose mask words and vector entries are requested together
+    for (int t0 = 0; t0 < nt; t0 += CH) {
+        unsigned long long wb[CH];
+        double vb[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int t = t0 + k;
+            const bool tok = t < nt;
+            const unsigned long long wv = masks[(size_t)(tok ? t : 0) * nrow + ic];
+            const int e = t * 64 + lane;
+            const double vv = vec[(tok && e < len) ? e : 0];
+            wb[k] = (tok && live) ? wv : 0ull;
+            vb[k] = vv;
         }
-    } else if (t < pl.n + pl.m) {
-        const int cnt = pl.cntr[t - pl.n];
-        if (cnt > 0) {
-            const int pos = rp[t];
-            double sum = 0.0;
-            for (int e = pos; e < pos + cnt; ++e) {
-                const double qj = q[ci[e]];
-                sum = sum + qj * qj;  // (Y_ij*q_j) * q_j
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const unsigned long long w = wb[k];
+            const double sq = vb[k] * vb[k];          // (p_i*Y_ij) * p_i, (Y_ij*q_j) * q_j
+            const int slo = __double2loint(sq), shi = __double2hiint(sq);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const unsigned wh = half ? (unsigned)(w >> 32) : (unsigned)w;
+                unsigned u = wave_or_u32(wh);         // scalar: positions any row of the wave has
+                if (u == 0u) continue;
+                if (u == 0xFFFFFFFFu) {
+                    // every position present somewhere (dense masks): fixed lanes and bit numbers,
+                    // no scalar bit scan; a row without the bit adds +0.0 (mask 0 / ~0 from the bit)
+#pragma unroll
+                    for (int bpos = 0; bpos < 32; ++bpos) {
+                        const int m = __builtin_amdgcn_sbfe(wh, bpos, 1);
+                        const int xl = __builtin_amdgcn_readlane(slo, half * 32 + bpos) & m;
+                        const int xh = __builtin_amdgcn_readlane(shi, half * 32 + bpos) & m;
+                        sum = sum + __hiloint2double(xh, xl);
+                    }
+                    continue;
+                }
+                if (__popc(u) <= 6) {
+                    // few positions (the realistic, tree-like masks): every lane takes its own bits,
+                    // the squares come from the owning lanes' registers (ds_bpermute, no memory)
+                    unsigned mine = wh;
+                    while (__any(mine != 0u)) {
+                        const bool has = mine != 0u;
+                        const int bpos = has ? __builtin_ctz(mine) : 0;
+                        mine &= mine - 1u;            // 0 stays 0
+                        const double y = __shfl(sq, half * 32 + bpos);
+                        sum = sum + (has ? y : 0.0);
+                    }
+                    continue;
+                }
+                while (u) {
+                    const int bpos = __builtin_ctz(u);
+                    u &= u - 1u;
+                    const int m = __builtin_amdgcn_sbfe(wh, bpos, 1);
+                    const int xl = __builtin_amdgcn_readlane(slo, half * 32 + bpos) & m;
+                    const int xh = __builtin_amdgcn_readlane(shi, half * 32 + bpos) & m;
+                    sum = sum + __hiloint2double(xh, xl);
+                }
             }
-            ci[pos + cnt] = t;
-            va[pos + cnt] = sum;
+        }
+    }
+    if (cnt > 0) {
+        const int row = side ? pl.n + idx : idx;
+        const int pos = rp[row] + (side ? cnt : 0);
+        if (pos < cap) {
+            ci[pos] = row;
+            va[pos] = sum;
         }
     }
 }
@@ -365,6 +476,10 @@ void csr_drop_zeros(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out) {
 void kkt_asat(ipd_ctx* ctx, Arena& dst, const uint8_t* s, const double* p, const double* q, int m,
               int n, Csr* H) {
     IPD_REQUIRE(m > 0 && n > 0, IPD_E_ARG, "ASAt: empty p or q");
+    // H has at most 2*m*n + m + n entries and its row pointers, entry counts and tile counts are
+    // 32-bit: refuse what could wrap (e.g. m = n = 40000 at rho ~ 1 fits in HBM but not in int32)
+    IPD_REQUIRE(2LL * m * n + m + n < (1LL << 31) - 64, IPD_E_LIMIT,
+                "ASAt: 2*m*n + m + n must stay below 2^31 (32-bit row pointers)");
     Arena& tmp = *ctx->scratch;
     AsatPlan pl;
     pl.m = m;
@@ -382,28 +497,51 @@ void kkt_asat(ipd_ctx* ctx, Arena& dst, const uint8_t* s, const double* p, const
     int* rp = dst.alloc<int>((size_t)M + 2);  // rp[M] = nnz, rp[M+1] = zero-square flag
     const int ntiles = pl.nib * pl.njb;
     IPD_HIP(hipMemsetAsync(rp + M + 1, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_asat_masks, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, s, pl);
+    if (m % 8 == 0 && (reinterpret_cast<uintptr_t>(s) & 7) == 0)
+        hipLaunchKernelGGL(k_asat_masks<true>, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, s, pl);
+    else
+        hipLaunchKernelGGL(k_asat_masks<false>, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, s, pl);
     IPD_KERNEL_CHECK();
     hipLaunchKernelGGL(k_asat_offsets, dim3(cdiv(M, 256)), dim3(256), 0, ctx->stream, pl, p, q,
                        rp + M + 1);
     IPD_KERNEL_CHECK();
     exclusive_scan_i32(ctx, pl.rowlen, rp, M);
-    int meta[2];
-    ctx->fetch(rp + M, meta, 2);
+    // The entry count sizes ci/va, and reading it back is a host round trip in the middle of the
+    // assembly.  Consecutive Newton steps have similar active sets, so the arrays are sized from
+    // the previous call's count (+25 %) and the fill runs at once; the count is read afterwards,
+    // and only when it exceeds the guess (the kernels never write past `cap`) the fill is redone.
+    int meta[2] = {0, 0};
     Csr h;
     h.nr = h.nc = M;
-    h.nnz = meta[0];
     h.rp = rp;
-    h.ci = dst.alloc<int>((size_t)h.nnz);
-    h.va = dst.alloc<double>((size_t)h.nnz);
-    if (h.nnz) {
+    auto fill = [&](int cap) {
         hipLaunchKernelGGL(k_asat_fill, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, pl, p, q,
-                           rp, h.ci, h.va);
+                           rp, h.ci, h.va, cap);
         IPD_KERNEL_CHECK();
-        hipLaunchKernelGGL(k_asat_diag, dim3(cdiv(M, 256)), dim3(256), 0, ctx->stream, pl, p, q, rp,
-                           h.ci, h.va);
+        // 64-thread blocks: the sums are one dependent chain per row, so rows go to as many CUs
+        // as there are (a 256-thread block per 256 rows left 248 CUs idle at m = n = 1024)
+        // one wave per 64 rows (the sums are one dependent chain per row), both sides in one launch
+        hipLaunchKernelGGL(k_asat_diag, dim3(cdiv(n, 64) + cdiv(m, 64)), dim3(64), 0, ctx->stream, pl, p, q,
+                           cdiv(n, 64), rp, h.ci, h.va, cap);
         IPD_KERNEL_CHECK();
+    };
+    const long long worst = 2LL * m * n + M;
+    long long guess = ctx->asat_nnz_hint > 0 ? std::min(worst, ctx->asat_nnz_hint + ctx->asat_nnz_hint / 4 + 64) : 0;
+    if (guess > 0) {
+        h.ci = dst.alloc<int>((size_t)guess);
+        h.va = dst.alloc<double>((size_t)guess);
+        fill((int)guess);
+        ctx->fetch(rp + M, meta, 2);
+        h.nnz = meta[0];
     }
+    if (guess == 0 || meta[0] > guess) {
+        if (guess == 0) ctx->fetch(rp + M, meta, 2);
+        h.nnz = meta[0];
+        h.ci = dst.alloc<int>((size_t)h.nnz);
+        h.va = dst.alloc<double>((size_t)h.nnz);
+        if (h.nnz) fill(h.nnz);
+    }
+    ctx->asat_nnz_hint = h.nnz;
     if (meta[1] && h.nnz) {
         Csr clean;
         csr_drop_zeros(ctx, dst, h, &clean);
