@@ -2,6 +2,9 @@
 // entry points that do not launch kernels.
 #include "ipd_internal.h"
 
+#include <mutex>
+#include <set>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -91,6 +94,13 @@ __global__ void k_mailbox(const unsigned* __restrict__ src, int nwords, volatile
     __threadfence_system();   // the payload is visible to the host before the ticket is
     __syncthreads();
     if (i == 0) box[0] = ticket;
+}
+
+bool ipd_lds_optin_needed(const void* kernel, int device) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    return done.insert({kernel, device}).second;
 }
 
 static bool mailbox_enabled() {

@@ -587,12 +587,7 @@ void pcg_dev(ipd_ctx* ctx, const Csr& H, const double* e, const double* guess, d
         g.a = a;
         g.nf = (int)nf;
         g.tmp = tmp.alloc<double>(2 * (size_t)H.nr);
-        static bool attr_set = false;
-        if (!attr_set) {
-            IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_gen),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024));
-            attr_set = true;
-        }
+        IPD_OPTIN_LDS(ctx, k_pcg_gen, 60 * 1024);
         hipLaunchKernelGGL(k_pcg_gen, dim3(1), dim3(BT), sizeof(double) * (size_t)H.nr, ctx->stream, g);
     } else {
         hipLaunchKernelGGL(k_pcg, dim3(1), dim3(BT), 0, ctx->stream, a);

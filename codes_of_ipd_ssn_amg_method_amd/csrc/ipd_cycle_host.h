@@ -255,8 +255,7 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
     }
 #define IPD_RES_LAUNCH(KE)                                                                          \
     do {                                                                                            \
-        IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resident<KE, KE>),              \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));       \
+        IPD_OPTIN_LDS(ctx, (k_resident<KE, KE>), 156 * 1024);                                       \
         hipLaunchKernelGGL((k_resident<KE, KE>), dim3(st->res_G), dim3(BT), st->res_lds, ctx->stream, \
                            D, b_dev, x, st->res_out, fixed_cycles);                                 \
     } while (0)
@@ -637,16 +636,9 @@ void amg_prepare_levels(ipd_amg* h) {
         }
         return reinterpret_cast<SolveDesc*>(img);
     };
-    static bool attr_set = false;
-    if (!attr_set) {
-        IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subcycle),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        attr_set = true;
-    }
+    IPD_OPTIN_LDS(ctx, k_solve_small<true>, 156 * 1024);
+    IPD_OPTIN_LDS(ctx, k_solve_small<false>, 156 * 1024);
+    IPD_OPTIN_LDS(ctx, k_subcycle, 156 * 1024);
     // Level 2 as a semi-cached level (r, e, e2 in LDS; matrix rows from L2) with levels 3..J fully
     // cached: returns the dynamic LDS needed behind a staging area of `stage` bytes, 0 = no
     auto semi_plan = [&](size_t stage) -> size_t {

@@ -1323,7 +1323,15 @@ void apd_iterate(ipd_apd* h, const ipd_apd_opts& o, const AmgOpts& amg, ipd_rng*
     double bk_next = bk1;
     if (bk1 < 1e-8 && rr > resk) {                                                 // :245 restart
         copy_dev(h, h->v, h->u, h->U);                                             // vk1 = xk
-        bk_next = c2 ? 10.0 * bk1 : rng->next_double();                            // rand / 10*bk1
+        if (c2) {
+            bk_next = 10.0 * bk1;                                                  // Class2 :255
+        } else {
+            // rand (:246) through the stream's fill(): a replayed stream, its exhaustion error and
+            // the count of consumed numbers are honoured (next_double() bypassed all three)
+            double v = 0.0;
+            rng->fill(&v, 1);
+            bk_next = v;
+        }
         ++h->restarts;
         apd_end(h, false, h->u, h->lam, kk, &fx);
         rr = max_rr(h, kk);

@@ -654,12 +654,7 @@ static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, 
             ctx->upload(d_local, local.data(), (size_t)M);
             IPD_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
             const size_t lds = sizeof(double) * ((size_t)maxnb * (maxnb + 1) + maxnb);
-            static bool attr_set = false;
-            if (!attr_set) {
-                IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_small_blocks),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-                attr_set = true;
-            }
+            IPD_OPTIN_LDS(ctx, k_small_blocks, 96 * 1024);
             hipLaunchKernelGGL(k_small_blocks, dim3(nblk), dim3(256), lds, ctx->stream, d_boff,
                                d_nodes, d_local, Ae.rp, Ae.ci, Ae.va, f, u, bad);
             IPD_KERNEL_CHECK();

@@ -210,6 +210,17 @@ struct ProfScope {
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Opt-in to more than 64 KiB of dynamic LDS.  The attribute is per DEVICE (a process may hold
+// contexts on several), so it is remembered per (kernel, device) pair, under a lock (contexts
+// are used from several host threads).  ipd_core.cpp
+bool ipd_lds_optin_needed(const void* kernel, int device);
+#define IPD_OPTIN_LDS(ctx, kernel, bytes)                                                        \
+    do {                                                                                         \
+        if (ipd_lds_optin_needed(reinterpret_cast<const void*>(kernel), (ctx)->device))          \
+            IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                   \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)));   \
+    } while (0)
+
 // ---------------------------------------------------------------------------
 // cross-TU device routines (all asynchronous on ctx->stream unless noted)
 // ---------------------------------------------------------------------------

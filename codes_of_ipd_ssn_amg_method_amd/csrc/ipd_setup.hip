@@ -767,13 +767,7 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
             IPD_KERNEL_CHECK();
             dense_rowcount(ctx, N, Nc, Nc, dense, rowcnt);
         } else {
-            static bool attr_set = false;
-            if (!attr_set) {
-                IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_W),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            128 * 1024));
-                attr_set = true;
-            }
+            IPD_OPTIN_LDS(ctx, k_build_W, 128 * 1024);
             const int bw_threads = (double)A.nnz / std::max(N, 1) >= 96.0 ? 256 : 64;
             hipLaunchKernelGGL(k_build_W, dim3(std::min(N, 16384)), dim3(bw_threads),
                                (size_t)Nc * 16, ctx->stream, N, Nc, A.rp, A.ci, A.va, diag, strong,

@@ -231,7 +231,8 @@ void csr_upload_from_csc(ipd_ctx* ctx, Arena& a, const ipd_csc* A, bool symmetri
     std::vector<int> jc((size_t)nc + 1), ir((size_t)nnz);
     for (int c = 0; c <= nc; ++c) jc[c] = (int)A->jc[c];
     for (int c = 0; c < nc; ++c) {
-        IPD_REQUIRE(A->jc[c] <= A->jc[c + 1], IPD_E_ARG, "sparse input: column pointers decrease");
+        IPD_REQUIRE(A->jc[c] >= 0 && A->jc[c] <= A->jc[c + 1] && A->jc[c + 1] <= nnz, IPD_E_ARG,
+                    "sparse input: column pointers decrease or exceed nnz");
         for (int64_t t = A->jc[c]; t < A->jc[c + 1]; ++t) {
             const int64_t r = A->ir[t];
             IPD_REQUIRE(r >= 0 && r < nr, IPD_E_ARG, "sparse input: row index out of range");
@@ -627,13 +628,7 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
         rowbits = tmp.alloc<unsigned long long>((size_t)(nr ? nr : 1) * (size_t)((nc + 4095) / 4096 + 1));
         if (nr > 0) {
             const size_t lds = std::max<size_t>((size_t)nc * 8, 16);
-            static bool attr_set = false;
-            if (!attr_set) {
-                IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_spgemm_rows),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            128 * 1024));
-                attr_set = true;
-            }
+            IPD_OPTIN_LDS(ctx, k_spgemm_rows, 128 * 1024);
             const int threads = (Y.nr > 0 && (double)Y.nnz / Y.nr >= 96.0) ? 256 : 64;
             hipLaunchKernelGGL(k_spgemm_rows, dim3(std::min(nr, 16384)), dim3(threads), lds,
                                ctx->stream, nr, nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense,

@@ -293,16 +293,34 @@ def test_restart_rule_matches_oracle():
     ref = D.apd_ssn_class1(pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], np.inf, inner="amg",
                            start=(xs, ls), rng=O.matlab_rng(), maxit=1, bk0=1e-9, vk0=v0)
     assert np.array_equal(ref["xk"], xs) and ref["bk"] > 1e-3      # the oracle did restart
+    amg = dict(retol=1e-11, bigph=1, maxit=30, theta=1 / 4, smoth=5, cycle="w", isnsp=1, inter=1)
     ws = ws_of(1, pr)
     ws.set_state(xs, v0, ls, 1e-9)
-    out = ws.run(dict(retol=1e-11, bigph=1, maxit=30, theta=1 / 4, smoth=5, cycle="w", isnsp=1,
-                      inter=1), ipd().MatlabRand(5489), iters=1)
+    rng = ipd().MatlabRand(5489)
+    out = ws.run(amg, rng, iters=1)
     u, v, lam, bk = ws.state()
     assert out["restarts"] == 1 and out["k"] == 1
     assert np.array_equal(u, xs) and np.array_equal(v, xs) and np.array_equal(lam, ls)
     assert bk == ref["bk"]
     hist = ws.history()
     assert abs(hist["KKT_xk"][1] - ref["KKT_xk"][1]) <= 1e-12 * (1 + ref["KKT_xk"][1])
+    ws.close()
+    # the restart's rand is drawn through the stream like every other one: it is COUNTED, and a
+    # replayed stream (ipd_rng_create_replay: values recorded elsewhere, e.g. from MATLAB) feeds it
+    used = rng.consumed
+    vals = ipd().MatlabRand(5489).rand(used)
+    assert vals[-1] == ref["bk"], "the restart consumed the last number of the stream"
+    ws = ws_of(1, pr)
+    ws.set_state(xs, v0, ls, 1e-9)
+    rep = ipd().MatlabRand(replay=vals)
+    out = ws.run(amg, rep, iters=1)
+    assert out["restarts"] == 1 and ws.state()[3] == ref["bk"] and rep.consumed == used
+    ws.close()
+    # one value short: the stream runs dry AT the restart and says so instead of returning 0.0
+    ws = ws_of(1, pr)
+    ws.set_state(xs, v0, ls, 1e-9)
+    with pytest.raises(ipd().IpdError):
+        ws.run(amg, ipd().MatlabRand(replay=vals[:-1]), iters=1)
     ws.close()
 
 
