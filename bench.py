@@ -74,12 +74,19 @@ def cpu_baseline(Ae, f, guess, opts, n, budget_s=8.0):
     M = A.shape[0]
     wc = opts["cycle"] == "w"
     cc = CpuCycle(h, opts["isnsp"])
-    ncores = os.cpu_count() or 1
+    # cores this process may run on (the box's cgroup share, not the machine's core count:
+    # OpenMP threads beyond it only spin against each other)
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
     runs = []
     for thr in sorted({1, min(8, ncores), min(32, ncores), ncores}):
-        cc.run(f, guess, 2, wc, thr)                           # warm-up (thread pool, caches)
+        x, sec, res = cc.run(f, guess, 1, wc, thr)            # warm-up (thread pool, caches)
+        if sec > 2.0:                                          # oversubscribed: not a baseline
+            continue
         x, sec, res = cc.run(f, guess, 3, wc, thr)            # cycle-time estimate
-        cyc = int(max(20, min(2000, 2.5 / max(sec / 3, 1e-7))))  # ~2.5 s per thread count
+        cyc = int(max(10, min(2000, 2.5 / max(sec / 3, 1e-7))))  # ~2.5 s per thread count
         x, sec, res = cc.run(f, guess, cyc, wc, thr)
         runs.append({"threads": thr, "cycles": cyc, "seconds": sec, "ms_per_cycle": 1e3 * sec / cyc,
                      "value": M * cyc / sec, "rel_res_after": float(res[-1] / res[0])})
@@ -99,7 +106,7 @@ def cpu_baseline(Ae, f, guess, opts, n, budget_s=8.0):
     return dict(value=best["value"], unit="DoF*cycles/s", cores=best["threads"], kind="port",
                 sample="oracle/cpu_cycle.c (C/OpenMP, explicit smoother matrices as the reference): "
                        "%d %s-cycles of the same hierarchy in %.2f s at %d thread(s), the best of the "
-                       "thread counts tried (host has %d cores; oracle setup %.1f s excluded)" % (
+                       "thread counts tried (%d cores usable by this process; oracle setup %.1f s excluded)" % (
                            best["cycles"], opts["cycle"].upper(), best["seconds"], best["threads"],
                            ncores, t_setup),
                 ms_per_cycle=best["ms_per_cycle"], by_threads=runs,

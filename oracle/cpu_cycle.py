@@ -16,6 +16,8 @@ def build():
 
 
 def _load():
+    # idle OpenMP threads sleep instead of spinning (the box's CPU share is smaller than the machine)
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     if not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(os.path.join(HERE, "cpu_cycle.c")):
         build()
     lib = ctypes.CDLL(SO)
