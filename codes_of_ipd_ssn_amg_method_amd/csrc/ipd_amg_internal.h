@@ -51,6 +51,11 @@ struct ipd_amg {
     ipd_ctx* ctx = nullptr;
     std::shared_ptr<CycleState> cyc;  // launch geometry + partial-sum buffers
     std::unique_ptr<Arena> arena;
+    // Hierarchy whose rand-independent part this one shares (levels 1 and 2 of a bigraph
+    // hierarchy: A_1, its smoother data and padded copy, P_2, P_2', A_2 -- the level-1 transfer
+    // draws no random numbers, AMG/transfer.m:19-25): constant device arrays are pointed at, not
+    // copied; work vectors and everything from level 2's C/F split down are this hierarchy's own.
+    std::shared_ptr<ipd_amg> donor;
     AmgOpts opts;
     int J = 0;
     std::vector<Level> L;  // 1-based like the MATLAB cells; L[0] unused
@@ -70,7 +75,8 @@ void amg_mis_set(ipd_ctx* ctx, const Csr& A, double theta, ipd_rng* rng, uint8_t
                  uint8_t* isF, uint8_t* strong_out /*nnz bytes or NULL*/);
 void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int level,
                   ipd_rng* rng, Csr* Ac, Csr* P, Csr* Pt, uint8_t* cmask /*A.nr bytes*/);
-ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng);
+ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng,
+                   const std::shared_ptr<ipd_amg>& donor = nullptr);
 int amg_coarsest_threshold(int N);
 
 // ipd_cycle.hip

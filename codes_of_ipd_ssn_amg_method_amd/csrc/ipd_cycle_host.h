@@ -295,12 +295,28 @@ void amg_prepare_levels(ipd_amg* h) {
     // readback for all levels), second pass: padded copies and launch geometry
     int* maxoff = ctx->scratch->alloc<int>((size_t)h->J + 1);
     IPD_HIP(hipMemsetAsync(maxoff, 0, sizeof(int) * ((size_t)h->J + 1), ctx->stream));
+    // levels whose constant data come from the donor hierarchy (see ipd_amg::donor)
+    const ipd_amg* donor = h->donor.get();
+    const CycleState* dst_ = donor ? donor->cyc.get() : nullptr;
+    auto shared_level = [&](int k) { return dst_ && k <= 2 && k <= donor->J; };
     for (int k = 1; k <= h->J; ++k) {
         Level& lv = h->L[k];
         const int N = lv.A.nr;
         lv.N = N;
         lv.nf = (k == 1 && h->opts.bigph) ? (int)h->opts.fnode : 0;
         IPD_REQUIRE(lv.nf < N, IPD_E_ARG, "fnode must be smaller than the matrix size");
+        if (shared_level(k)) {
+            const Level& dl = donor->L[k];
+            lv.dinv = dl.dinv;
+            lv.Axi = dl.Axi;
+            lv.xx = dl.xx;
+            lv.r = ar.alloc<double>((size_t)N);
+            lv.e = ar.alloc<double>((size_t)N);
+            lv.e2 = ar.alloc<double>((size_t)N);
+            lv.w = ar.alloc<double>((size_t)N);
+            lv.rr = ar.alloc<double>((size_t)N);
+            continue;
+        }
         lv.dinv = ar.alloc<double>((size_t)N);
         lv.Axi = ar.alloc<double>((size_t)N);
         lv.xx = ar.alloc<double>(1);
@@ -344,7 +360,18 @@ void amg_prepare_levels(ipd_amg* h) {
             const char* ns = std::getenv("IPD_NO_STAGE");
             if (ns && ns[0] == '1') rn.staged = 0;
         }
-        build_padded(ctx, ar, lv.A, rows_per_launch, cu, hmax[(size_t)k], &rn.dev);
+        if (shared_level(k)) {   // the donor's padded copy and the geometry that goes with it
+            const LevelDev& dd = dst_->run[(size_t)k].dev;
+            rn.dev.S = dd.S;
+            rn.dev.pci = dd.pci;
+            rn.dev.pva = dd.pva;
+            rn.dev.diag = dd.diag;
+            rn.dev.L = dd.L;
+            rn.dev.G = dd.G;
+            lv.lanes = donor->L[k].lanes;
+        } else {
+            build_padded(ctx, ar, lv.A, rows_per_launch, cu, hmax[(size_t)k], &rn.dev);
+        }
     }
     for (int k = 1; k < h->J; ++k) {
         Level& fine = h->L[k];

@@ -412,6 +412,11 @@ struct HybridCache {
     Components cc;
     std::vector<std::unique_ptr<ipd_amg, void (*)(ipd_amg*)>> hier;   // in order of use
     size_t next = 0;
+    // donors (default path): the first call records its hierarchies, the second call's setups
+    // share their rand-independent part (amg_setup's `donor`): bit-identical results
+    bool record_donors = false, use_donors = false;
+    std::vector<std::shared_ptr<ipd_amg>> donors;
+    size_t next_donor = 0;
 };
 
 // Work postponed to the solve phase of a Hybrid_AMG call: AMG4POT's two calls set their
@@ -435,6 +440,15 @@ static std::function<void(int*, double*)> class_amg_prepare(
     ipd_amg* h = nullptr;
     if (cache && cache->valid && cache->next < cache->hier.size()) {
         h = cache->hier[cache->next++].get();          // second right-hand side: same operator
+    } else if (cache && (cache->record_donors || cache->use_donors)) {
+        ProfScope ps(ctx, PROF_AMG_SETUP);
+        std::shared_ptr<ipd_amg> donor;
+        if (cache->use_donors && cache->next_donor < cache->donors.size())
+            donor = cache->donors[cache->next_donor++];
+        own = std::shared_ptr<ipd_amg>(amg_setup(ctx, A, o, rng, donor), ipd_amg_destroy);
+        h = own.get();
+        if (mh.p && o.bigph) amg_attach_maskop(h, mh.p, mh.q, mh.m, mh.n, mh.tk, true);
+        if (cache->record_donors) cache->donors.push_back(own);
     } else {
         ProfScope ps(ctx, PROF_AMG_SETUP);
         std::unique_ptr<ipd_amg, void (*)(ipd_amg*)> fresh(amg_setup(ctx, A, o, rng), ipd_amg_destroy);
@@ -773,9 +787,15 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
     ipd_ctx* aux = ipd_ctx_aux(ctx);
     Deferred first, second;
     bool have_first = false;
+    const char* nd = getenv("IPD_NO_DONOR");
+    const bool donors = !(nd && nd[0] == '1');
     auto solve = [&](const double* rhs, double* x, HybridOut* o) {
         if (!have_first) {
-            hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o, nullptr, &first);
+            cache.record_donors = donors;
+            hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o,
+                              donors ? &cache : nullptr, &first);
+            cache.record_donors = false;
+            cache.use_donors = donors;
             have_first = true;
             return;
         }
@@ -784,7 +804,8 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
         // gain -- the setup is bound by its host round trips -- so both setups stay on this
         // thread and only the solve phases, which consume no random numbers, run concurrently.)
         CallScope aux_scope(aux);
-        hybrid_amg_cached(aux, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o, nullptr, &second);
+        hybrid_amg_cached(aux, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o,
+                          donors ? &cache : nullptr, &second);
         std::exception_ptr err;
         std::thread other([&] {
             try {
@@ -805,6 +826,7 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
         other.join();
         first.clear();    // releases the hierarchies
         second.clear();
+        cache.donors.clear();
         if (err0) std::rethrow_exception(err0);
         if (err) std::rethrow_exception(err);
     };

@@ -839,7 +839,13 @@ AmgOpts amg_fill_twogrid_defaults(const ipd_amg_opts* in) {
 // 1 + fix(size(A,1)^(1/3)) in floating point (Class_AMG.m:76)
 int amg_coarsest_threshold(int N) { return 1 + (int)std::floor(std::pow((double)N, 1.0 / 3.0)); }
 
-ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng) {
+// `donor`: a hierarchy of the SAME matrix and options set up earlier (AMG4POT's first right-hand
+// side, Class2/AMG4POT.m:46-47).  The reference sets up twice; the two hierarchies are equal up
+// to and including A_2 -- only mis_set (levels >= 2) consumes random numbers -- so that part is
+// shared and the rest is built with the stream's next numbers exactly as a full setup would:
+// same bits, same rand consumption, without the most expensive product of the setup.
+ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng,
+                   const std::shared_ptr<ipd_amg>& donor) {
     IPD_REQUIRE(A.nr == A.nc && A.nr > 0, IPD_E_ARG, "Class_AMG: A must be square and non-empty");
     if (o.bigph)  // Class_AMG.m:36-40
         IPD_REQUIRE(o.fnode > 0, IPD_E_ARG, "amg_options.bigph = 1 requires Nf > 0");
@@ -850,9 +856,28 @@ ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng) {
     h->opts = o;
     h->L.resize(2);
     h->J = 1;
-    csr_copy(ctx, *h->arena, A, &h->L[1].A);
-    h->L[1].N = A.nr;
     const int thr = amg_coarsest_threshold(A.nr);
+    const bool share = donor && o.bigph && !o.twogrid && donor->J >= 2 && donor->opts.bigph &&
+                       !donor->opts.twogrid && donor->opts.fnode == o.fnode &&
+                       donor->opts.isnsp == o.isnsp && donor->opts.inter == o.inter &&
+                       donor->L[1].A.nr == A.nr && donor->L[1].A.nnz == A.nnz && A.nr > thr &&
+                       donor->ctx->device == ctx->device;
+    if (share) {
+        h->donor = donor;
+        h->L[1].A = donor->L[1].A;
+        h->L[1].N = A.nr;
+        Level nl;
+        nl.A = donor->L[2].A;
+        nl.P = donor->L[2].P;
+        nl.Pt = donor->L[2].Pt;
+        nl.cmask = donor->L[2].cmask;
+        nl.N = nl.A.nr;
+        h->L.push_back(nl);
+        h->J = 2;
+    } else {
+        csr_copy(ctx, *h->arena, A, &h->L[1].A);
+        h->L[1].N = A.nr;
+    }
     auto more = [&] {   // Class_AMG.m:76; twogrid_bigph.m builds exactly one coarse level
         return o.twogrid ? h->J < 2 : h->L[h->J].A.nr > thr;
     };
