@@ -120,7 +120,7 @@ EXPORTS = [
     "ipd_dmat_multiply", "ipd_spmv_dev",
     "ipd_ax_dev", "ipd_aty_dev", "ipd_asat_dev", "ipd_amg_setup_dev", "ipd_amg_solve_dev",
     "ipd_hybrid_amg_dev", "ipd_amg_bench_cycles", "ipd_amg_bench_sweeps", "ipd_amg_cycle_bytes", "ipd_amg_solve_mode", "ipd_amg_bench_resident", "ipd_comm_get_unique_id",
-    "ipd_comm_init", "ipd_comm_finalize", "ipd_comm_stats", "ipd_amg_bench_cycles_sharded",
+    "ipd_comm_init", "ipd_comm_finalize", "ipd_comm_stats", "ipd_ctx_set_component_order", "ipd_amg_bench_cycles_sharded",
     "ipd_apd_opts_init", "ipd_apd_create", "ipd_apd_destroy", "ipd_apd_dims", "ipd_apd_warmup",
     "ipd_apd_set_state", "ipd_apd_get_state", "ipd_apd_run", "ipd_apd_history",
     "ipd_apd_records", "ipd_apd_begin", "ipd_apd_eval", "ipd_apd_bench_eval", "ipd_prof_read", "ipd_amg_bench_subcycle",

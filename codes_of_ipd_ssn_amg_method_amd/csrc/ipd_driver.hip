@@ -1658,6 +1658,7 @@ extern "C" int ipd_apd_run(ipd_apd* h, const ipd_apd_opts* o, const ipd_amg_opts
                            ipd_rng* rng, int32_t iters, ipd_apd_result* res) {
     return ipd_guard([&] {
         IPD_REQUIRE(h && rng, IPD_E_ARG, "NULL argument");
+        h->ctx->comp_order.clear();   // a recorded component order belongs to ONE Newton system
         ipd_apd_opts oo;
         if (o)
             oo = *o;

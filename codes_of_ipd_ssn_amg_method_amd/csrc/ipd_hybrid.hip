@@ -272,7 +272,57 @@ static void find_components(ipd_ctx* ctx, const Csr& A, Components* out) {
     out->p.assign((size_t)N, 0);
     std::vector<int> cur(out->r.begin(), out->r.end() - 1);
     for (int i = 0; i < N; ++i) out->p[(size_t)cur[(size_t)out->blocks[i]]++] = i;
+    // An injected visiting order (SURVEY A-9: MATLAB's dmperm order is undocumented, so a recorded
+    // one can be replayed): component k of the result is the one whose smallest member is
+    // comp_order[k].  Members stay ascending inside a component (F side first).  The order only
+    // moves info(2), the loop order and with it the order in which rand is consumed.
+    if (!ctx->comp_order.empty()) {
+        const std::vector<int>& ord = ctx->comp_order;
+        IPD_REQUIRE((int)ord.size() == nc, IPD_E_ARG,
+                    "component order: as many entries as there are components expected");
+        std::vector<int> newid((size_t)nc, -1);
+        for (int k = 0; k < nc; ++k) {
+            const int sm = ord[(size_t)k];
+            IPD_REQUIRE(sm >= 0 && sm < N && par[(size_t)sm] == sm && newid[(size_t)cid[(size_t)sm]] < 0,
+                        IPD_E_ARG, "component order: entries must be the smallest members of distinct components");
+            newid[(size_t)cid[(size_t)sm]] = k;
+        }
+        Components re;
+        re.ncomp = nc;
+        re.blocks.resize((size_t)N);
+        re.sizes.assign((size_t)nc, 0);
+        for (int c = 0; c < nc; ++c) re.sizes[(size_t)newid[(size_t)c]] = out->sizes[(size_t)c];
+        re.r.assign((size_t)nc + 1, 0);
+        for (int c = 0; c < nc; ++c) re.r[(size_t)c + 1] = re.r[(size_t)c] + re.sizes[(size_t)c];
+        re.p.assign((size_t)N, 0);
+        std::vector<int> cur2(re.r.begin(), re.r.end() - 1);
+        for (int i = 0; i < N; ++i) {
+            const int c = newid[(size_t)out->blocks[(size_t)i]];
+            re.blocks[(size_t)i] = c;
+            re.p[(size_t)cur2[(size_t)c]++] = i;
+        }
+        *out = re;
+    }
 }
+
+// One-shot: the order applies to the NEXT top-level call that visits components on this context
+// (components, Hybrid_AMG, AMG4POT and their two-grid / PCG variants) and is cleared when that
+// call returns.  order == NULL or ncomp == 0 clears it.
+extern "C" int ipd_ctx_set_component_order(ipd_ctx* ctx, const int64_t* smallest_members, int64_t ncomp) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(ctx && ncomp >= 0 && ncomp < (int64_t(1) << 30), IPD_E_ARG, "bad argument");
+        ctx->comp_order.clear();
+        if (smallest_members)
+            for (int64_t k = 0; k < ncomp; ++k) ctx->comp_order.push_back((int)smallest_members[k]);
+    });
+}
+struct CompOrderScope {   // clears the injected order when the top-level call ends
+    ipd_ctx* ctx;
+    explicit CompOrderScope(ipd_ctx* c) : ctx(c) {}
+    ~CompOrderScope() {
+        if (ctx) ctx->comp_order.clear();
+    }
+};
 
 // ---------------------------------------------------------------------------
 // sub-matrix of one component: Aek = Ae(pk,pk), pk ascending
@@ -1036,6 +1086,7 @@ extern "C" int ipd_components(ipd_ctx* ctx, const ipd_csc* A, int64_t* blocks, i
         IPD_REQUIRE(ctx && A && blocks && sizes && p && r && ncomp, IPD_E_ARG, "NULL argument");
         IPD_REQUIRE(A->nrows == A->ncols, IPD_E_ARG, "Adjacency matrix must be square");
         CallScope scope(ctx);
+        CompOrderScope order_scope(ctx);
         Csr a;
         csr_upload_from_csc(ctx, *ctx->scratch, A, true, &a);  // undirected graph: pattern symmetric
         Components cc;
@@ -1063,6 +1114,7 @@ static int hybrid_host(ipd_ctx* ctx, const ipd_prob* pd, const AmgOpts& ao, ipd_
         IPD_REQUIRE(ctx && zeta, IPD_E_ARG, "NULL argument");
         check_prob(pd, false);
         CallScope scope(ctx);
+        CompOrderScope order_scope(ctx);
         Arena& tmp = *ctx->scratch;
         const int m = (int)pd->m, n = (int)pd->n, M = m + n;
         Csr H0;
@@ -1110,6 +1162,7 @@ extern "C" int ipd_hybrid_amg_dev(ipd_ctx* ctx, const ipd_dmat* H0, const double
         IPD_REQUIRE(ctx && H0 && p_dev && q_dev && z_dev && zeta_dev, IPD_E_ARG, "NULL argument");
         IPD_REQUIRE(m > 0 && n > 0, IPD_E_ARG, "bad m/n");
         CallScope scope(ctx);
+        CompOrderScope order_scope(ctx);
         HybridOut ho;
         hybrid_amg_dev(ctx, H0->m, t_dev, p_dev, q_dev, (int)m, (int)n, bk1, tk, z_dev,
                        amg_fill_defaults(o), rng, zeta_dev, &ho);
@@ -1129,6 +1182,7 @@ static int amg4pot_host(ipd_ctx* ctx, const ipd_prob* pd, const AmgOpts& ao, ipd
         IPD_REQUIRE(ctx && zeta, IPD_E_ARG, "NULL argument");
         check_prob(pd, true);
         CallScope scope(ctx);
+        CompOrderScope order_scope(ctx);
         Arena& tmp = *ctx->scratch;
         const int m = (int)pd->m, n = (int)pd->n, M = m + n;
         const size_t mn = (size_t)m * n;
@@ -1183,6 +1237,7 @@ static int aug_host(ipd_ctx* ctx, const ipd_prob* pd, const ipd_pcg_opts* o, boo
         const double tol = (o && o->retol >= 0) ? o->retol : 1e-11;                 // PCG.m:25-26
         const long long maxit = (o && o->maxit >= 0) ? o->maxit : 10000;
         CallScope scope(ctx);
+        CompOrderScope order_scope(ctx);
         Arena& tmp = *ctx->scratch;
         const int m = (int)pd->m, n = (int)pd->n, M = m + n;
         const size_t mn = (size_t)m * n;

@@ -202,6 +202,13 @@ int ipd_pcg(ipd_ctx*, const ipd_csc* H, const double* e, const double* guess,
  * components numbered by smallest member (dmperm's order is unpinned).       */
 int ipd_components(ipd_ctx*, const ipd_csc* A, int64_t* blocks, int64_t* sizes,
                    int64_t* p, int64_t* r, int64_t* ncomp);
+/* Replays a recorded visiting order of the components (components.m:35-39 takes it from
+ * dmperm, whose order is undocumented; Hybrid_AMG.m:55-57 visits in that order, which fixes
+ * info(2) and the order in which rand is consumed): smallest_members[k] = the smallest member
+ * (0-based) of the component to visit k-th, i.e. min(ps(rs(k):rs(k+1)-1))-1 of a MATLAB
+ * recording.  One-shot: applies to the next components / Hybrid_AMG / AMG4POT (and variants)
+ * call on this context.  NULL clears it.  Members stay ascending inside a component.        */
+int ipd_ctx_set_component_order(ipd_ctx*, const int64_t* smallest_members, int64_t ncomp);
 /* [zeta,itamg,resamg,info] = Hybrid_AMG(prob_data,amg_options) Hybrid_AMG.m:1 */
 int ipd_hybrid_amg(ipd_ctx*, const ipd_prob* pd, const ipd_amg_opts* o, ipd_rng* rng,
                    double* zeta, int32_t* itamg, double* resamg, int64_t info[2]);

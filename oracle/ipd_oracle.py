@@ -917,6 +917,11 @@ def AMG4POT(prob_data: dict, amg_options: dict, rng: np.random.RandomState,
     pd["z"] = w
     ww, it2, res2, info2 = hybrid(pd, amg_options, rng, trace=trace)      # :47
     tt = sg ** 2 / (phi_e - sg ** 2 * (v @ vv))                          # :53
+    # :54 reads `ww + tt*vv*v'*ww`, which MATLAB evaluates left to right: the M x M outer product
+    # (tt*vv)*v' times ww through a dense BLAS gemv whose summation order is the library's
+    # (unpinnable).  The associative form below differs from it by rounding only (~1e-16
+    # relative, far inside the 1e-10 bar); it is the one deliberate departure from the oracle's
+    # "reproduce MATLAB's order" rule.
     zeta1 = ww + tt * vv * (v @ ww)
     zeta2 = (z2 - sg * (v @ zeta1)) / phi_e
     zeta = np.concatenate([zeta1, [zeta2]])

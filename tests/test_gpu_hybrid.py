@@ -71,7 +71,7 @@ def test_hybrid_amg(ipd, name, m, n, mk, tfrac, cycle, pq_random):
     # cycle counts agree unless the history stagnates at the rounding floor (rel_res within
     # the 1e-10 comparison bar of retol = 1e-11): there the count is decided by noise
     noise_floor = res <= 1e-10 and reso <= 1e-10
-    assert abs(it - ito) <= 1 or noise_floor, (it, ito, res, reso)
+    assert abs(it - ito) <= 1 or (noise_floor and abs(it - ito) <= 3), (it, ito, res, reso)
     He = _he(pd)
     nz = np.linalg.norm(pd["z"])
     assert np.linalg.norm(He @ z - pd["z"]) <= max(1e-9, 20 * np.linalg.norm(He @ zo - pd["z"]) / nz) * nz
@@ -133,3 +133,58 @@ def test_system_dump_roundtrip(ipd, monkeypatch, tmp_path):
     assert np.array_equal(Ae.indptr, ref.indptr) and np.array_equal(Ae.indices, ref.indices)
     assert np.array_equal(Ae.data, ref.data)
     assert np.array_equal(f, qp * pd["z"])
+
+
+def test_component_order_injection(ipd, monkeypatch):
+    """SURVEY A-9: MATLAB's dmperm order of the components is undocumented; a recorded order can be
+    replayed (ipd_ctx_set_component_order).  The order moves info(2) and the order in which the
+    large components draw their random numbers -- checked against the oracle visiting the
+    components in the same (here: reversed) order."""
+    from ctypes import c_int64
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    m, n = 260, 250
+    rs = np.random.RandomState(3)
+    Y = np.zeros((m, n), np.uint8)     # two large components (>100 nodes) and a few small ones
+    Y[:120, :110] = PR.mask_tree(120, 110, seed=1).reshape(120, 110, order="F")
+    Y[120:250, 110:240] = PR.mask_tree(130, 130, seed=2).reshape(130, 130, order="F")
+    Y[250:255, 240:245] = 1
+    s = Y.reshape(-1, order="F").copy()
+    pd = PR.make_prob(m, n, s, pq_random=True)
+    pd["H0"] = O.ASAt(s, pd["p"], pd["q"])
+    opts = O.amg_options_class1("v")
+    blocks, sizes, ps, rs_ = O.components(pd["H0"])
+    ncomp = len(sizes)
+    assert (sizes > 100).sum() == 2
+    order = np.arange(ncomp)[::-1]                       # visit in reverse
+    smallest = np.array([ps[rs_[k]:rs_[k + 1]].min() for k in order], np.int64)
+
+    def permuted(A):
+        b, sz, p_, r_ = orig(A)
+        newid = np.empty(ncomp, np.int64)
+        newid[order] = np.arange(ncomp)
+        b2 = newid[b]
+        sz2 = sz[order]
+        p2 = np.argsort(b2, kind="stable")
+        return b2, sz2, p2, np.concatenate([[0], np.cumsum(sz2)])
+
+    orig = O.components
+    tr0, tr1 = [], []
+    z0, it0, res0, info0 = O.Hybrid_AMG(pd, opts, O.matlab_rng(), trace=tr0)
+    monkeypatch.setattr(O, "components", permuted)
+    z1, it1, res1, info1 = O.Hybrid_AMG(pd, opts, O.matlab_rng(), trace=tr1)
+    monkeypatch.setattr(O, "components", orig)
+    assert info0[1] != info1[1]                          # the oracle itself sees the order
+    ctx = _lib.get_ctx()
+    _lib.check(_lib.lib.ipd_ctx_set_component_order(ctx.handle, smallest.ctypes.data_as(_lib.c_void_p),
+                                                    c_int64(ncomp)))
+    rng = ipd.MatlabRand()
+    z, it, res, info = ipd.Hybrid_AMG(pd, opts, rng)
+    assert np.array_equal(info, info1)
+    assert np.linalg.norm(z - z1) <= 1e-6 * max(1.0, np.linalg.norm(z1))
+    # one-shot: the next call is back to the default order
+    z_, it_, res_, info_ = ipd.Hybrid_AMG(pd, opts, ipd.MatlabRand())
+    assert np.array_equal(info_, info0)
+    with pytest.raises(ipd.IpdError):
+        _lib.check(_lib.lib.ipd_ctx_set_component_order(ctx.handle, smallest[:-1].ctypes.data_as(_lib.c_void_p),
+                                                        c_int64(ncomp - 1)))
+        ipd.Hybrid_AMG(pd, opts, ipd.MatlabRand())
