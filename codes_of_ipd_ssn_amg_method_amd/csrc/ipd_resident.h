@@ -164,10 +164,16 @@ __device__ __forceinline__ double res_rowdot(unsigned (&c)[KE / 2], const double
         y[2 * q] = *reinterpret_cast<const double*>(smb + OFFB + lo);
         y[2 * q + 1] = *reinterpret_cast<const double*>(smb + OFFB + hi);
     }
-    double s = 0.0;
+    // four partial sums (entries q, q+4, ...): the dependent add chain is a quarter as long
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-    for (int q = 0; q < KE; ++q) s += a[q] * y[q];
-    return s;
+    for (int q = 0; q < KE; q += 4) {
+        s0 += a[q] * y[q];
+        s1 += a[q + 1] * y[q + 1];
+        s2 += a[q + 2] * y[q + 2];
+        s3 += a[q + 3] * y[q + 3];
+    }
+    return (s0 + s1) + (s2 + s3);
 }
 
 // CSR row of a transfer operator (global, L2-resident) against an LDS vector, one wave per row
@@ -176,18 +182,18 @@ __device__ __forceinline__ double res_csr_rowdot(const ResCsr& M, int row, bool 
     const int e0 = M.rp[valid ? row : 0];
     const int e1 = valid ? M.rp[row + 1] : e0;
     double s = 0.0;
-    for (int t = e0 + lane; t < e1; t += 64 * 4) {
-        int jj[4];
-        double aa[4];
+    for (int t = e0 + lane; t < e1; t += 64 * 8) {   // 8 entries per lane in flight: a 1025-entry row = 3 trips
+        int jj[8];
+        double aa[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int tt = t + 64 * u;
             const int tc = tt < e1 ? tt : e0;
             jj[u] = M.ci[tc];
             aa[u] = M.va[tc];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s += (t + 64 * u < e1) ? aa[u] * sm[off + jj[u]] : 0.0;
+        for (int u = 0; u < 8; ++u) s += (t + 64 * u < e1) ? aa[u] * sm[off + jj[u]] : 0.0;
     }
     return wave_sum(s);
 }
@@ -440,9 +446,27 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // tail level: restriction, Jacobi-PCG (PCG.m:68-87, zero guess), prolongation -- all of it by
     // every workgroup on its own LDS copies, so no hand-off                     MG_Vcycle.m:27-31,43
     auto tail = [&]() {
-        for (int i = w; i < Nt; i += RES_WAVES) {
-            const double s = res_csr_rowdot(D.Pt3, i, true, lane, sm, oRR2);
-            if (lane == 0) sm[oR3 + i] = s;
+        if (Nt == 1) {
+            // one row: its entries are dealt to all the waves, the eight partial sums are added in
+            // wave order (a single wave walking 1024 entries took four dependent trips)
+            const int e0 = D.Pt3.rp[0], e1 = D.Pt3.rp[1];
+            double s = 0.0;
+            for (int t = e0 + tid; t < e1; t += BT * 2) {
+                const int t1 = t + BT;
+                const int ja = D.Pt3.ci[t], jb = D.Pt3.ci[t1 < e1 ? t1 : e0];
+                const double aa = D.Pt3.va[t], ab = D.Pt3.va[t1 < e1 ? t1 : e0];
+                s += aa * sm[oRR2 + ja];
+                s += t1 < e1 ? ab * sm[oRR2 + jb] : 0.0;
+            }
+            s = wave_sum(s);
+            if (lane == 0) red[w] = s;
+            __syncthreads();
+            if (tid == 0) sm[oR3] = res_red8(red);
+        } else {
+            for (int i = w; i < Nt; i += RES_WAVES) {
+                const double s = res_csr_rowdot(D.Pt3, i, true, lane, sm, oRR2);
+                if (lane == 0) sm[oR3 + i] = s;
+            }
         }
         __syncthreads();
         if (w == 0) {
