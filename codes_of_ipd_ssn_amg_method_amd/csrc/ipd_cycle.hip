@@ -1747,4 +1747,5 @@ __global__ __launch_bounds__(BT) void k_subcycle(const SolveDesc* __restrict__ D
 }
 
 #include "ipd_resident.h"
+#include "ipd_mid.h"
 #include "ipd_cycle_host.h"

@@ -54,6 +54,13 @@ struct CycleState {
     double* res_out = nullptr;
     unsigned char* res_block = nullptr;   // [gran0 | gran1 | tmo]: zeroed before every launch
     int res_timeouts = 0;    // launches whose bounded spins gave up (then: multi-launch path)
+    // whole solve of a realistic hierarchy in one workgroup (ipd_mid.h): levels 1-2 thread-per-row
+    // with rows in registers and vectors in LDS, levels 3..J out of the LDS image
+    bool mid_ok = false;
+    MidDesc mid_desc{};
+    SolveDesc* d_mid = nullptr;
+    size_t mid_lds = 0;
+    double* mid_out = nullptr;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};  // captured Class_AMG loop bodies (x->x2, x2->x)
     const double* gb = nullptr;                    // right-hand side the graphs were captured for
     ~CycleState() {
@@ -283,6 +290,31 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
     }
     if (out_host) *out_host = std::move(out);
     return true;
+}
+
+// The single-workgroup whole solve of a realistic hierarchy (ipd_mid.h) on the iterate in x.
+static void run_mid(ipd_amg* h, CycleState* st, const double* b_dev, double* x, int fixed_cycles,
+                    std::vector<double>* out_host, float* ms) {
+    ipd_ctx* ctx = h->ctx;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ms) {
+        IPD_HIP(hipEventCreate(&e0));
+        IPD_HIP(hipEventCreate(&e1));
+        IPD_HIP(hipEventRecord(e0, ctx->stream));
+    }
+    hipLaunchKernelGGL(k_solve_mid, dim3(1), dim3(BT), st->mid_lds, ctx->stream,
+                       (const SolveDesc*)st->d_mid, st->mid_desc, b_dev, x, st->mid_out, fixed_cycles);
+    IPD_KERNEL_CHECK();
+    if (ms) IPD_HIP(hipEventRecord(e1, ctx->stream));
+    const size_t nout = 4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2);
+    std::vector<double> out(nout);
+    ctx->fetch(st->mid_out, out.data(), nout);
+    if (ms) {
+        IPD_HIP(hipEventElapsedTime(ms, e0, e1));
+        IPD_HIP(hipEventDestroy(e0));
+        IPD_HIP(hipEventDestroy(e1));
+    }
+    if (out_host) *out_host = std::move(out);
 }
 
 void amg_prepare_levels(ipd_amg* h) {
@@ -794,10 +826,90 @@ void amg_prepare_levels(ipd_amg* h) {
             }
         }
     }
+    // (c) realistic hierarchies whose levels 1-2 are too big for (a) and too small to need many
+    // CUs: the whole solve in ONE workgroup (ipd_mid.h)
+    {
+        const char* nm = std::getenv("IPD_NO_MID");
+        const bool cyc = h->opts.cycle == 'w' || h->opts.cycle == 'v';
+        bool ok = !(nm && nm[0] == '1') && !st->small_ok && lean_vectors && h->J >= 3 &&
+                  h->J <= SOLVE_ML && !h->opts.twogrid && (cyc || true);
+        if (ok) {
+            const Level& l1 = h->L[1];
+            const Level& l2 = h->L[2];
+            const Level& l3 = h->L[3];
+            // short rows (the register copy holds MID_RC entries of a row; longer rows pay a trip
+            // to L2 per sweep) and levels that fit the thread-per-row layout
+            ok = l1.A.nr <= MID_RPT * BT && l2.A.nr <= MID_RPT2 * BT && l3.A.nr <= BT &&
+                 (double)l1.A.nnz <= 7.0 * l1.A.nr && (double)l2.A.nnz <= 7.0 * l2.A.nr &&
+                 (double)l2.P.nnz <= 8.0 * l1.A.nr && (double)l3.P.nnz <= 8.0 * l2.A.nr;
+            for (int k = 3; k <= h->J && ok; ++k) ok = small_level(k);
+        }
+        if (ok) {
+            const size_t stage = 16;
+            size_t used = 0;
+            const int k_lds = plan_lds(stage, &used);
+            if (k_lds <= 3 && blk_from(3) == 3) {
+                std::unique_ptr<SolveDesc> sd(new SolveDesc());
+                fill_desc(sd.get());
+                sd->k_lds = 3;
+                sd->k_tiny = tiny_from(3);
+                sd->k_blk = blk_from(3);
+                sd->stage_bytes = (int)stage;
+                size_t img_total = 0;
+                SolveDesc* img = build_image(sd.get(), 3, stage, &img_total);
+                {
+                    auto mid_level = [&](int k) {
+                        const Level& lv = h->L[k];
+                        const Level& ch = h->L[k + 1];
+                        MidLevel m;
+                        m.N = lv.A.nr;
+                        m.nf = lv.nf;
+                        m.Nc = ch.A.nr;
+                        m.rp = lv.A.rp;
+                        m.ci = lv.A.ci;
+                        m.va = lv.A.va;
+                        m.dinv = lv.dinv;
+                        m.Axi = lv.Axi;
+                        m.xx = lv.xx;
+                        m.Rrp = ch.Pt.rp;
+                        m.Rci = ch.Pt.ci;
+                        m.Rva = ch.Pt.va;
+                        m.Prp = ch.P.rp;
+                        m.Pci = ch.P.ci;
+                        m.Pva = ch.P.va;
+                        return m;
+                    };
+                    MidDesc md;
+                    md.L1 = mid_level(1);
+                    md.L2 = mid_level(2);
+                    md.J = h->J;
+                    md.nu = h->opts.smoth;
+                    md.isnsp = h->opts.isnsp;
+                    md.wcycle = h->opts.cycle == 'w';
+                    md.anycycle = cyc;
+                    md.maxit = h->opts.maxit;
+                    md.retol = h->opts.retol;
+                    md.e1 = h->L[1].e;
+                    md.e1b = h->L[1].e2;
+                    md.w1 = h->L[1].w;
+                    md.r1 = h->L[1].r;
+                    md.e2 = h->L[2].e;
+                    md.e2b = h->L[2].e2;
+                    md.r2 = h->L[2].r;
+                    st->mid_desc = md;
+                    st->d_mid = img;
+                    st->mid_lds = img_total;
+                    st->mid_out = ar.alloc<double>(4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2));
+                    st->mid_ok = true;
+                    IPD_OPTIN_LDS(ctx, k_solve_mid, 156 * 1024);
+                }
+            }
+        }
+    }
     plan_resident(h, st.get());
     if (const char* dbg = std::getenv("IPD_DEBUG_LEVELS"); dbg && dbg[0] == '1') {
-        std::fprintf(stderr, "[ipd] J=%d small=%d k_sub=%d resident=%d(G=%d,KE=%d) levels:", h->J,
-                     (int)st->small_ok, st->k_sub, (int)st->res_ok, st->res_G, st->res_ke);
+        std::fprintf(stderr, "[ipd] J=%d small=%d k_sub=%d mid=%d resident=%d(G=%d,KE=%d) levels:", h->J,
+                     (int)st->small_ok, st->k_sub, (int)st->mid_ok, (int)st->res_ok, st->res_G, st->res_ke);
         for (int k = 1; k <= h->J; ++k) std::fprintf(stderr, " %d/%d", h->L[k].A.nr, h->L[k].A.nnz);
         std::fprintf(stderr, "\n");
     }
@@ -1272,6 +1384,20 @@ void amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev, dou
         else
             IPD_HIP(hipMemsetAsync(xa, 0, sizeof(double) * (size_t)N, ctx->stream));
     }
+    if (st->mid_ok && st->shard_ranks == 1) {
+        std::vector<double> out;
+        run_mid(h, st, b_dev, xa, 0, &out, nullptr);
+        const int its = (int)out[0];
+        if (rel_resk) std::memcpy(rel_resk, out.data() + 4, sizeof(double) * ((size_t)its + 1));
+        if (rhok) std::memcpy(rhok, out.data() + 4 + (o.maxit + 2), sizeof(double) * ((size_t)its + 1));
+        if (x_dev)
+            IPD_HIP(hipMemcpyAsync(x_dev, xa, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+        if (it_out) *it_out = its;
+        if (rel_res_out) *rel_res_out = out[1];
+        ctx->sync();
+        return;
+    }
     launch_top(h, st, b_dev, xa, nullptr, xb, true);                            // :89
     std::swap(xa, xb);
     double hh[5];
@@ -1467,7 +1593,7 @@ extern "C" int ipd_amg_solve_mode(const ipd_amg* h, int32_t* mode, int32_t* grid
     if (!h || !mode) return IPD_E_ARG;
     const CycleState* st = h->cyc.get();
     if (!st) return IPD_E_ARG;
-    *mode = st->small_ok ? 1 : (st->res_ok ? 2 : 0);
+    *mode = st->small_ok ? 1 : (st->res_ok ? 2 : (st->mid_ok ? 3 : 0));
     if (grid) *grid = st->res_ok ? st->res_G : (st->small_ok ? 1 : 0);
     if (timeouts) *timeouts = st->res_timeouts;
     return IPD_OK;
@@ -1577,6 +1703,18 @@ extern "C" int ipd_amg_bench_cycles(ipd_amg* h, const double* b_dev, double* x_d
                 if (bytes_per_cycle) *bytes_per_cycle = cycle_bytes(h);
                 return;
             }
+        }
+        if (st->mid_ok) {  // one single-workgroup launch runs all the cycles
+            IPD_HIP(hipMemcpyAsync(h->x, x_dev, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+            float msf = 0.f;
+            run_mid(h, st, b_dev, h->x, cycles, nullptr, &msf);
+            IPD_HIP(hipMemcpyAsync(x_dev, h->x, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+            ctx->sync();
+            *total_ms = msf;
+            if (bytes_per_cycle) *bytes_per_cycle = cycle_bytes(h);
+            return;
         }
         const char* ng = std::getenv("IPD_NO_GRAPH");
         const bool use_graph = !(ng && ng[0] == '1');
