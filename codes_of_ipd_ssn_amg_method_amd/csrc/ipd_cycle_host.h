@@ -57,6 +57,7 @@ struct CycleState {
     // whole solve of a realistic hierarchy in one workgroup (ipd_mid.h): levels 1-2 thread-per-row
     // with rows in registers and vectors in LDS, levels 3..J out of the LDS image
     bool mid_ok = false;
+    bool mid_l3c = false;   // level 3 chunked in the kernel (image from level 4) / image from level 3
     MidDesc mid_desc{};
     SolveDesc* d_mid = nullptr;
     size_t mid_lds = 0;
@@ -302,8 +303,12 @@ static void run_mid(ipd_amg* h, CycleState* st, const double* b_dev, double* x, 
         IPD_HIP(hipEventCreate(&e1));
         IPD_HIP(hipEventRecord(e0, ctx->stream));
     }
-    hipLaunchKernelGGL(k_solve_mid, dim3(1), dim3(BT), st->mid_lds, ctx->stream,
-                       (const SolveDesc*)st->d_mid, st->mid_desc, b_dev, x, st->mid_out, fixed_cycles);
+    if (st->mid_l3c)
+        hipLaunchKernelGGL(k_solve_mid<true>, dim3(1), dim3(BT), st->mid_lds, ctx->stream,
+                           (const SolveDesc*)st->d_mid, st->mid_desc, b_dev, x, st->mid_out, fixed_cycles);
+    else
+        hipLaunchKernelGGL(k_solve_mid<false>, dim3(1), dim3(BT), st->mid_lds, ctx->stream,
+                           (const SolveDesc*)st->d_mid, st->mid_desc, b_dev, x, st->mid_out, fixed_cycles);
     IPD_KERNEL_CHECK();
     if (ms) IPD_HIP(hipEventRecord(e1, ctx->stream));
     const size_t nout = 4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2);
@@ -827,19 +832,27 @@ void amg_prepare_levels(ipd_amg* h) {
         }
     }
     // (c) realistic hierarchies whose levels 1-2 are too big for (a) and too small to need many
-    // CUs: the whole solve in ONE workgroup (ipd_mid.h)
+    // CUs: the whole solve in ONE workgroup (ipd_mid.h).  Level 3 is either the root of the LDS
+    // image (when it fits) or, typically (a few hundred rows of 10-70 entries: more than LDS
+    // holds), walked in chunks from L2 with the image starting at level 4.
     {
-        const char* nm = std::getenv("IPD_NO_MID");
+        // OPT-IN (IPD_MID=1): measured on the Newton systems of the m=n=1024 Class 1 run
+        // (levels 2048 / 1024 / ~280 / ~80 / ...), it is no faster than the multi-launch path
+        // (0.74-1.0 ms against 0.55-0.75 ms per W cycle): one CU cannot hold the rows of levels 1-3
+        // AND their vectors, so every phase still pays dependent L2 round trips (0.5-0.7 us each,
+        // nothing to overlap them with in a single workgroup), and the W cycle's time is mostly the
+        // 2^(k-1) visits of the tiny levels, which this kernel runs with the same code.
+        const char* nm = std::getenv("IPD_MID");
         const bool cyc = h->opts.cycle == 'w' || h->opts.cycle == 'v';
-        bool ok = !(nm && nm[0] == '1') && !st->small_ok && lean_vectors && h->J >= 3 &&
-                  h->J <= SOLVE_ML && !h->opts.twogrid && (cyc || true);
+        bool ok = (nm && nm[0] == '1') && !st->small_ok && lean_vectors && h->J >= 3 &&
+                  h->J <= SOLVE_ML && !h->opts.twogrid;
         if (ok) {
             const Level& l1 = h->L[1];
             const Level& l2 = h->L[2];
             const Level& l3 = h->L[3];
-            // short rows (the register copy holds MID_RC entries of a row; longer rows pay a trip
-            // to L2 per sweep) and levels that fit the thread-per-row layout
-            ok = l1.A.nr <= MID_RPT * BT && l2.A.nr <= MID_RPT2 * BT && l3.A.nr <= BT &&
+            // short rows on levels 1-2 (the register copy holds MID_RC entries of a row; longer rows
+            // pay a trip to L2 per sweep) and levels that fit the thread-per-row layout
+            ok = l1.A.nr <= MID_RPT * BT && l2.A.nr <= MID_RPT2 * BT &&
                  (double)l1.A.nnz <= 7.0 * l1.A.nr && (double)l2.A.nnz <= 7.0 * l2.A.nr &&
                  (double)l2.P.nnz <= 8.0 * l1.A.nr && (double)l3.P.nnz <= 8.0 * l2.A.nr;
             for (int k = 3; k <= h->J && ok; ++k) ok = small_level(k);
@@ -848,16 +861,23 @@ void amg_prepare_levels(ipd_amg* h) {
             const size_t stage = 16;
             size_t used = 0;
             const int k_lds = plan_lds(stage, &used);
-            if (k_lds <= 3 && blk_from(3) == 3) {
+            const int root = k_lds <= 3 ? 3 : 4;   // first level of the image
+            const bool l3c = root == 4;
+            ok = k_lds <= 4 && h->J >= root && blk_from(root) == root && h->L[root].A.nr <= BT;
+            const int N3 = h->L[3].A.nr;
+            const int nch_max = l3c ? h->L[3].A.nnz / MID_CH + N3 + 1 : 0;
+            if (ok) {
                 std::unique_ptr<SolveDesc> sd(new SolveDesc());
                 fill_desc(sd.get());
-                sd->k_lds = 3;
-                sd->k_tiny = tiny_from(3);
-                sd->k_blk = blk_from(3);
+                sd->k_lds = root;
+                sd->k_tiny = tiny_from(root);
+                sd->k_blk = blk_from(root);
                 sd->stage_bytes = (int)stage;
                 size_t img_total = 0;
-                SolveDesc* img = build_image(sd.get(), 3, stage, &img_total);
-                {
+                SolveDesc* img = build_image(sd.get(), root, stage, &img_total);
+                const size_t l3_off = r16(img_total);
+                const size_t l3_bytes = l3c ? sizeof(double) * ((size_t)3 * N3 + (size_t)nch_max) : 0;
+                if (l3_off + l3_bytes <= 156 * 1024) {
                     auto mid_level = [&](int k) {
                         const Level& lv = h->L[k];
                         const Level& ch = h->L[k + 1];
@@ -880,8 +900,28 @@ void amg_prepare_levels(ipd_amg* h) {
                         return m;
                     };
                     MidDesc md;
+                    std::memset(&md, 0, sizeof(md));
                     md.L1 = mid_level(1);
                     md.L2 = mid_level(2);
+                    md.l3_off = (unsigned)l3_off;
+                    md.nch_max = nch_max;
+                    if (l3c) {
+                        md.L3 = mid_level(3);
+                        int* cnt = ar.alloc<int>((size_t)N3 + 1);
+                        int* row_ch = ar.alloc<int>((size_t)N3 + 1);
+                        int* ch_t0 = ar.alloc<int>((size_t)nch_max);
+                        hipLaunchKernelGGL(k_mid_chunk_counts, dim3(cdiv(N3, 256)), dim3(256), 0, ctx->stream,
+                                           N3, h->L[3].A.rp, cnt);
+                        IPD_KERNEL_CHECK();
+                        exclusive_scan_i32(ctx, cnt, row_ch, N3);
+                        hipLaunchKernelGGL(k_mid_chunk_fill, dim3(cdiv(N3, 256)), dim3(256), 0, ctx->stream,
+                                           N3, h->L[3].A.rp, (const int*)row_ch, ch_t0);
+                        IPD_KERNEL_CHECK();
+                        md.row_ch = row_ch;
+                        md.ch_t0 = ch_t0;
+                    } else {
+                        md.L3.N = N3;   // the level below level 2 (sizes only)
+                    }
                     md.J = h->J;
                     md.nu = h->opts.smoth;
                     md.isnsp = h->opts.isnsp;
@@ -897,11 +937,13 @@ void amg_prepare_levels(ipd_amg* h) {
                     md.e2b = h->L[2].e2;
                     md.r2 = h->L[2].r;
                     st->mid_desc = md;
+                    st->mid_l3c = l3c;
                     st->d_mid = img;
-                    st->mid_lds = img_total;
+                    st->mid_lds = l3_off + l3_bytes;
                     st->mid_out = ar.alloc<double>(4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2));
                     st->mid_ok = true;
-                    IPD_OPTIN_LDS(ctx, k_solve_mid, 156 * 1024);
+                    IPD_OPTIN_LDS(ctx, k_solve_mid<false>, 156 * 1024);
+                    IPD_OPTIN_LDS(ctx, k_solve_mid<true>, 156 * 1024);
                 }
             }
         }

@@ -21,11 +21,15 @@
 //     one launch and one read-back per solve.
 // Arithmetic per row is the multi-launch kernels' (phase_smooth, phase_resid, phase_xfer,
 // phase_top); a row's dot product is accumulated in column order by one thread.
+//
+// STATUS: opt-in (IPD_MID=1), correct (same cycle counts and residuals as the multi-launch path,
+// tests/test_gpu_mid.py) but not faster on the systems it was built for -- see the note at its
+// planning code in ipd_cycle_host.h and DESIGN.md section 6.
 #pragma once
 
 static constexpr int MID_RPT = 4;   // rows per thread on level 1 (up to MID_RPT*BT rows)
 static constexpr int MID_RPT2 = 2;  // rows per thread on level 2
-static constexpr int MID_RC = 6;    // entries of a row kept in registers
+static constexpr int MID_RC = 4;    // entries of a row kept in registers (6: 90 spilled registers)
 
 struct MidLevel {
     int N, nf, Nc;
@@ -42,8 +46,17 @@ struct MidLevel {
     const int* Pci;
     const double* Pva;
 };
+static constexpr int MID_CH = 32;    // entries per chunk of a chunked level-3 row
 struct MidDesc {
     MidLevel L1, L2;
+    // level 3 when it is too big for the LDS image (a few hundred rows of 10-70 entries): its rows
+    // are cut into chunks of MID_CH entries, a thread forms a chunk's partial dot product from L2,
+    // the row owners add their rows' chunks in order; the image then starts at level 4
+    MidLevel L3;
+    const int* row_ch;    // [N3+1] first chunk of a row; row_ch[N3] = number of chunks
+    const int* ch_t0;     // first entry of a chunk
+    unsigned l3_off;      // byte offset in dynamic LDS of e3a | e3b | r3 | chunk sums
+    int nch_max;
     int J, nu, isnsp, wcycle, anycycle, maxit;
     double retol;
     double *e1, *e1b, *w1, *r1, *e2, *e2b, *r2;   // vectors of levels 1 and 2 (global)
@@ -59,6 +72,38 @@ __device__ __forceinline__ int mid_col(MidRow& R, int u) {
     // opaque: keeps the unpacked columns from being hoisted out of the solve loops (a register each)
     if (!(u & 1)) asm volatile("" : "+v"(R.cp[u >> 1]));
     return (int)((u & 1) ? (R.cp[u >> 1] >> 16) : (R.cp[u >> 1] & 0xffffu));
+}
+
+// chunk tables of a level: row_ch = exclusive scan of ceil(len/MID_CH), ch_t0 from it
+__global__ void k_mid_chunk_counts(int N, const int* __restrict__ rp, int* __restrict__ cnt) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
+        cnt[i] = (rp[i + 1] - rp[i] + MID_CH - 1) / MID_CH;
+}
+__global__ void k_mid_chunk_fill(int N, const int* __restrict__ rp, const int* __restrict__ row_ch,
+                                 int* __restrict__ ch_t0) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        int c = row_ch[i];
+        for (int t = rp[i]; t < rp[i + 1]; t += MID_CH) ch_t0[c++] = t;
+    }
+}
+
+// partial dot product of one chunk (entries [t0, t1), at most MID_CH of them) with x in LDS
+__device__ __forceinline__ double mid_chunk_dot(const int* __restrict__ ci, const double* __restrict__ va,
+                                                int t0, int t1, AS3 const double* x) {
+    double s = 0.0;
+    for (int t = t0; t < t1; t += 8) {
+        int cc[8];
+        double vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int tt = t + u < t1 ? t + u : t0;
+            cc[u] = ci[tt];
+            vv[u] = va[tt];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (t + u < t1) ? vv[u] * x[cc[u]] : 0.0;
+    }
+    return s;
 }
 
 // (the level's arrays are passed as plain pointers: a descriptor taken by reference through the
@@ -159,6 +204,7 @@ __device__ __forceinline__ double mid_block_sum(double v, AS3 double* part) {
 
 // out[] as k_solve_small: out[0] = it, out[1] = rel_res, out[2] = res0; rel_resk at out[4 ..],
 // rhok at out[4+maxit+2 ..].  fixed_cycles > 0: that many loop bodies, no stopping rules.
+template <bool L3C>   // L3C: level 3 chunked here, the LDS image starts at level 4; else at level 3
 __global__ __launch_bounds__(BT) void k_solve_mid(const SolveDesc* __restrict__ D_global, const MidDesc M,
                                                   const double* __restrict__ b, double* xg, double* out,
                                                   int fixed_cycles) {
@@ -200,7 +246,26 @@ __global__ __launch_bounds__(BT) void k_solve_mid(const SolveDesc* __restrict__ 
     double* e2 = M.e2;
     double* e2b = M.e2b;
     double* r2 = M.r2;
-    AS3 double* r3 = as_lds(LD->L[3].lv.r);
+    // level 3: right-hand side in the image (root of the sub-cycle) or, chunked, vectors of its own
+    AS3 double* e3 = (AS3 double*)(dyn_raw + M.l3_off);
+    AS3 double* e3b = e3 + M.L3.N;
+    AS3 double* r3 = L3C ? e3b + M.L3.N : as_lds(LD->L[3].lv.r);
+    AS3 double* psum = e3b + 2 * M.L3.N;
+    AS3 double* r4 = as_lds(LD->L[L3C ? 4 : 3].lv.r);
+    const int N4 = M.L3.Nc;
+    const int* rp3 = M.L3.rp;
+    const int* ci3 = M.L3.ci;
+    const double* va3 = M.L3.va;
+    const double *dinv3 = M.L3.dinv, *axi3 = M.L3.Axi;
+    const int *R3rp = M.L3.Rrp, *R3ci = M.L3.Rci, *P3rp = M.L3.Prp, *P3ci = M.L3.Pci;
+    const double *R3va = M.L3.Rva, *P3va = M.L3.Pva;
+    const int* row_ch = M.row_ch;
+    const int* ch_t0 = M.ch_t0;
+    const int nch = L3C ? row_ch[N3] : 0;
+    const double xx3 = (L3C && nsp) ? M.L3.xx[0] : 1.0;
+    double sumr3 = 0.0, axe3 = 0.0;
+    bool ez3 = true;
+    (void)r4;
 
     // ---- rows of this thread -> registers -------------------------------------------------------
     MidRow A1[MID_RPT], A2[MID_RPT2];
@@ -324,6 +389,73 @@ __global__ __launch_bounds__(BT) void k_solve_mid(const SolveDesc* __restrict__ 
         ez2 = false;
     };
 
+    // ---- chunked level 3 (L3C) ---------------------------------------------------------------
+    // A3 * x: chunk sums by all threads, then (after the barrier) a row's chunks added in order
+    auto l3_chunks = [&](AS3 const double* x) __attribute__((always_inline)) {
+        for (int k = tid; k < nch; k += BT) {
+            const int t0 = ch_t0[k];
+            // the chunk ends at the next chunk's start or at the end of the matrix
+            const int t1 = k + 1 < nch ? ch_t0[k + 1] : rp3[N3];
+            psum[k] = mid_chunk_dot(ci3, va3, t0, min(t1, t0 + MID_CH), x);
+        }
+        __syncthreads();
+    };
+    auto l3_row = [&](int row) __attribute__((always_inline)) {
+        double sd = 0.0;
+        for (int k = row_ch[row]; k < row_ch[row + 1]; ++k) sd += psum[k];
+        return sd;
+    };
+    auto sweep3 = [&]() __attribute__((always_inline)) {
+        const double cc = nsp ? (sumr3 - (ez3 ? 0.0 : axe3)) / xx3 : 0.0;
+        if (!ez3) l3_chunks(e3);
+        double acc = 0.0;
+        for (int row = tid; row < N3; row += BT) {
+            const double eo = ez3 ? 0.0 : e3[row];
+            const double sd = ez3 ? 0.0 : l3_row(row);
+            const double ax = axi3[row];
+            const double v = eo + dinv3[row] * (r3[row] - sd - ax * cc) + cc;
+            e3b[row] = v;
+            acc += ax * v;
+        }
+        axe3 = nsp ? mid_block_sum(acc, part) : 0.0;
+        if (!nsp) __syncthreads();
+        AS3 double* t = e3;
+        e3 = e3b;
+        e3b = t;
+        ez3 = false;
+    };
+    auto visit3 = [&](bool keep) __attribute__((always_inline)) {
+        if (!keep) {
+            ez3 = true;
+            if (nu == 0) {
+                for (int row = tid; row < N3; row += BT) e3[row] = 0.0;
+                ez3 = false;
+                axe3 = 0.0;
+                __syncthreads();
+            }
+        }
+        for (int s = 0; s < nu; ++s) sweep3();
+        l3_chunks(e3);                                                     // rr = r - A e  :27
+        for (int row = tid; row < N3; row += BT) e3b[row] = r3[row] - l3_row(row);
+        __syncthreads();
+        for (int i = tid; i < N4; i += BT) r4[i] = mid_csr_dot(R3rp, R3ci, R3va, i, true, e3b);
+        __syncthreads();
+        for (int v4 = 0; v4 < ((wcyc && 4 < J) ? 2 : 1); ++v4) sol_cycle(c, 4, v4 == 1);
+        {
+            AS3 const double* e4 = lds_e(c, 4);
+            double acc = 0.0;
+            for (int row = tid; row < N3; row += BT) {
+                const double v = e3[row] + mid_csr_dot(P3rp, P3ci, P3va, row, true, e4);
+                e3[row] = v;
+                acc += axi3[row] * v;
+            }
+            axe3 = nsp ? mid_block_sum(acc, part) : 0.0;
+            if (!nsp) __syncthreads();
+        }
+        for (int s = 0; s < nu; ++s) sweep3();
+    };
+    (void)visit3;
+
     // one visit of level 2 and everything below it                          MG_Vcycle.m:12-41
     auto visit2 = [&](bool keep) __attribute__((always_inline)) {
         if (!keep) {
@@ -343,18 +475,34 @@ __global__ __launch_bounds__(BT) void k_solve_mid(const SolveDesc* __restrict__ 
             if (row < N2) e2b[row] = r2[row] - mid_row_dot<false>(ci2, va2, A2[j], e2, e2, 0, 0, false);
         }
         __syncthreads();
-        for (int i = tid; i < N3; i += BT) r3[i] = mid_csr_dot(R2rp, R2ci, R2va, i, true, e2b);
-        __syncthreads();
-        // :29, and MG_Wcycle.m:30's second correction (one call site: the sub-cycle is large)
-        for (int v3 = 0; v3 < ((wcyc && 3 < J) ? 2 : 1); ++v3) sol_cycle(c, 3, v3 == 1);
+        {
+            double sr = 0.0;
+            for (int i = tid; i < N3; i += BT) {
+                const double v = mid_csr_dot(R2rp, R2ci, R2va, i, true, e2b);
+                r3[i] = v;
+                sr += v;
+            }
+            if (L3C && nsp)
+                sumr3 = mid_block_sum(sr, part);
+            else
+                __syncthreads();
+        }
+        AS3 const double* e3res;
+        if constexpr (L3C) {
+            for (int v3 = 0; v3 < ((wcyc && 3 < J) ? 2 : 1); ++v3) visit3(v3 == 1);        // :29 / MG_Wcycle.m:30
+            e3res = e3;
+        } else {
+            // :29, and MG_Wcycle.m:30's second correction (one call site: the sub-cycle is large)
+            for (int v3 = 0; v3 < ((wcyc && 3 < J) ? 2 : 1); ++v3) sol_cycle(c, 3, v3 == 1);
+            e3res = lds_e(c, 3);
+        }
         {   // e2 += P e3                                                                :31
-            AS3 const double* e3 = lds_e(c, 3);
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < MID_RPT2; ++j) {
                 const int row = tid + j * BT;
                 if (row < N2) {
-                    const double v = e2[row] + mid_csr_dot(P2rp, P2ci, P2va, row, true, e3);
+                    const double v = e2[row] + mid_csr_dot(P2rp, P2ci, P2va, row, true, e3res);
                     e2[row] = v;
                     acc += A2[j].axi * v;
                 }
