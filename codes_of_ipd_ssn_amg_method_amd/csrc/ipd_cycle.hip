@@ -21,7 +21,9 @@
 // compare residual histories to 1e-10.
 #include "ipd_amg_internal.h"
 
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <mutex>
 
 #include "ipd_cycle_dev.h"

@@ -236,12 +236,46 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     st->res_ok = true;
 }
 
-// One resident kernel at a time per device: two of them would each hold part of the CUs and
-// wait for workgroups that cannot start (the spins are bounded, but the launch would be lost).
-static std::mutex& resident_mutex(int device) {
-    static std::mutex m[64];
-    return m[device & 63];
+// Resident kernels need all their workgroups on the chip at once (one per CU): as many of them may
+// run side by side as their grids fit into the device's CUs -- two of 128 workgroups on an MI355X
+// (AMG4POT's two concurrent solves, bench.py --batch 2) -- and a further one waits for a free slot
+// (a solve lasts a millisecond or two; running it as launches beside two resident kernels slows all
+// three: --batch 4 fell from 2 x 20 M to 17.6 M DoF*cycles/s) and takes the multi-launch path only
+// if none frees up within 50 ms.  (The spins are bounded, so an over-commitment could only cost the
+// launch, never hang.)
+struct ResidentSlots {
+    std::mutex mu;
+    std::condition_variable cv;
+    int used[64] = {0};
+    bool acquire(int device, int workgroups, int cus) {
+        std::unique_lock<std::mutex> lock(mu);
+        if (workgroups > cus) return false;
+        const bool got = cv.wait_for(lock, std::chrono::milliseconds(50),
+                                     [&] { return used[device & 63] + workgroups <= cus; });
+        if (!got) return false;
+        used[device & 63] += workgroups;
+        return true;
+    }
+    void release(int device, int workgroups) {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            used[device & 63] -= workgroups;
+        }
+        cv.notify_all();
+    }
+};
+static ResidentSlots& resident_slots() {
+    static ResidentSlots s;
+    return s;
 }
+struct ResidentLease {
+    int device, wgs;
+    bool ok;
+    ResidentLease(int d, int w, int cus) : device(d), wgs(w), ok(resident_slots().acquire(d, w, cus)) {}
+    ~ResidentLease() {
+        if (ok) resident_slots().release(device, wgs);
+    }
+};
 
 // Runs the whole solve (fixed_cycles == 0) or exactly fixed_cycles loop bodies on the
 // iterate in x (in: guess, out: result).  Returns false when the kernel could not be used
@@ -250,8 +284,8 @@ static std::mutex& resident_mutex(int device) {
 static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double* x, int fixed_cycles,
                          std::vector<double>* out_host, float* ms, long long* dbg_dev = nullptr) {
     ipd_ctx* ctx = h->ctx;
-    std::unique_lock<std::mutex> lock(resident_mutex(ctx->device), std::try_to_lock);
-    if (!lock.owns_lock()) return false;
+    ResidentLease lease(ctx->device, st->res_G, st->num_cu);
+    if (!lease.ok) return false;
     ResDesc D = st->res_desc;
     D.dbg = dbg_dev;
     IPD_HIP(hipMemsetAsync(st->res_block, 0, 2 * (size_t)RES_GRAN_MAX * 16 + 16, ctx->stream));
