@@ -312,7 +312,11 @@ def main():
                          "co-resident) and were redone by the multi-launch path\n" % tmo_.value)
     nu = opts["smoth"]
     visits2 = 2 if args.cycle == "w" else 1
-    launches_classic = 4 * nu + 2 + visits2 * (2 * nu + 4) + 1 + 2    # sweeps, resid, transfers, PCG, top, norm
+    # phases of the multi-launch path: sweeps (2 launches on the Gauss-Seidel level), residual,
+    # restriction, coarse PCG, prolongation, top, norm; where P'A is small (csrc: T1.nnz <= 2^18)
+    # residual + restriction are ONE launch, r_c = P'r - (P'A)e
+    fused_rrc = [h.level_dims(k)[1] * 2 <= (1 << 18) for k in (1, 2)] if h.J == 3 else None
+    launches_classic = 4 * nu + 2 + visits2 * (2 * nu + 4) + 1 + 2
     handoffs = 4 * nu + 3 + visits2 * (2 * nu + 1) + 1 if h.J == 3 else None
     result = {
         "metric": "V-cycle throughput (DoF*cycles/sec), m=n=%d OT grid" % m,
@@ -337,7 +341,8 @@ def main():
                        "handoffs_per_cycle": handoffs, "resident_kernel_timeouts": tmo_.value}
                       if resident else
                       {"mode": "one launch per phase" + (", graph replay" if not sharded else ", eager + RCCL"),
-                       "launches_per_cycle": launches_classic if h.J == 3 else None}),
+                       "launches_per_cycle": launches_classic if h.J == 3 else None,
+                       "residual_restriction_fused_estimate": fused_rrc}),
         "replicas": replicas_result,
         "batched": batched,
         "rccl": rccl,

@@ -28,6 +28,8 @@ struct Level {
     Csr A;              // Ack{k}
     Csr P;              // Prok{k}   : N_{k-1} x N_k   (k >= 2; stored on the coarse level)
     Csr Pt;             // Prok{k}'  : N_k x N_{k-1}   (restriction, CSR)
+    Csr T1;             // Prok{k}'*A_{k-1} : the first product of the Galerkin triple (transfer.m:66),
+                        // kept for the fused residual + restriction  r_k = P'r - (P'A) e
     uint8_t* cmask = nullptr;  // isC of level k-1 (N_{k-1} bytes), k >= 2
     // smoother Rk{k}: level 1 with bigph -> forward Gauss-Seidel on the [F|C] blocks
     // (dinv = 1/diag, nf = fnode); otherwise weighted Jacobi (dinv = 0.5/diag, nf = 0)
@@ -74,7 +76,8 @@ void amg_strength_mask(ipd_ctx* ctx, const Csr& A, double theta, uint8_t* strong
 void amg_mis_set(ipd_ctx* ctx, const Csr& A, double theta, ipd_rng* rng, uint8_t* isC,
                  uint8_t* isF, uint8_t* strong_out /*nnz bytes or NULL*/);
 void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int level,
-                  ipd_rng* rng, Csr* Ac, Csr* P, Csr* Pt, uint8_t* cmask /*A.nr bytes*/);
+                  ipd_rng* rng, Csr* Ac, Csr* P, Csr* Pt, uint8_t* cmask /*A.nr bytes*/,
+                  Csr* T1out = nullptr /* Pt*A kept in dst when asked for */);
 ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng,
                    const std::shared_ptr<ipd_amg>& donor = nullptr);
 int amg_coarsest_threshold(int N);

@@ -48,6 +48,12 @@ __global__ __launch_bounds__(BT) void k_xfer(XferArgs a) {
     extern __shared__ __attribute__((aligned(16))) double xs_dyn[];
     phase_xfer<STAGED>(a, blockIdx.x, gridDim.x, &lds, xs_dyn);
 }
+template <bool STAGED>
+__global__ __launch_bounds__(BT) void k_rrc(RrcArgs a) {
+    __shared__ PhaseLds lds;
+    extern __shared__ __attribute__((aligned(16))) double xs_dyn[];
+    phase_rrc<STAGED>(a, blockIdx.x, gridDim.x, &lds, xs_dyn);
+}
 template <bool STAGED, bool PAD>
 __global__ __launch_bounds__(BT) void k_top(TopArgs a) {
     __shared__ PhaseLds lds;

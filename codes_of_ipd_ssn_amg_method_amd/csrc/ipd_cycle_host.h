@@ -1299,28 +1299,62 @@ void amg_cycle(ipd_amg* h, int k, int isnsp, bool wcycle, bool keep_e) {
         }
     }
     for (int s = 0; s < nu; ++s) launch_sweep(h, st, k, isnsp, false);          // :14-25
-    if (rn.staged && phase_is_small(st, lv.N, rn.dev.L, (double)lv.A.nnz, lv.N)) {  // :27
-        ResidDesc& rd = push_phase(ctx, st, PH_RESID, lv.N).u.r;
-        rd.lv = rn.dev;
-        rd.e = lv.e;
-        rd.row0 = 0;
-        rd.row1 = lv.N;
-    } else {
-        run_rows(ctx, st, 0, lv.N,
-                 [&](int r0, int r1) { launch_resid(ctx, rn, lv.e, r0, r1, cu); }, {lv.rr});
-    }
-    {
-        XferArgs ra = rn.restrict_args;
-        if (ra.staged && phase_is_small(st, ra.nrows, ra.L, (double)h->L[k + 1].Pt.nnz, ra.ncols))
-            push_phase(ctx, st, PH_XFER, ra.ncols).u.x = ra;
-        else
+    const bool resid_small = rn.staged && phase_is_small(st, lv.N, rn.dev.L, (double)lv.A.nnz, lv.N);
+    XferArgs ra = rn.restrict_args;
+    const bool rest_small =
+        ra.staged && phase_is_small(st, ra.nrows, ra.L, (double)h->L[k + 1].Pt.nnz, ra.ncols);
+    const char* nrrc = std::getenv("IPD_NO_RRC");
+    const bool no_rrc = nrrc && nrrc[0] == '1';
+    const Csr& T1 = h->L[k + 1].T1;
+    // Fused where the two launches are latency-bound (measured: tree-mask W cycle 0.432 -> 0.413 ms,
+    // realistic Newton systems -2...-3.5 %); once T1 is megabytes the pair is bandwidth-bound and the
+    // fused walk (CSR T1, 12 B per entry, against the padded A, 10 B) is the slower one (regime D at
+    // m=n=2048: 0.321 -> 0.342 ms), so large T1 keep the two launches.
+    if (!no_rrc && !resid_small && !rest_small && T1.rp && T1.nr == ra.nrows && T1.nnz <= (1 << 18)) {
+        // r_{k+1} = P'r - (P'A) e: one launch instead of residual + restriction           :27
+        RrcArgs rc;
+        rc.p = ra;
+        rc.p.x = lv.r;
+        rc.p.L = pick_lanes(T1.nnz + h->L[k + 1].Pt.nnz, ra.nrows, cu);
+        rc.rp2 = T1.rp;
+        rc.ci2 = T1.ci;
+        rc.va2 = T1.va;
+        rc.e = lv.e;
+        const bool staged = 2 * (size_t)ra.ncols <= (size_t)STAGE_MAX && rn.staged;
+        const size_t dyn = staged ? 2 * sizeof(double) * (size_t)ra.ncols : 0;
         run_rows(ctx, st, 0, ra.nrows,
                  [&](int r0, int r1) {
-                     ra.row0 = r0;
-                     ra.row1 = r1;
-                     launch_xfer(ctx, ra, cu);
+                     rc.p.row0 = r0;
+                     rc.p.row1 = r1;
+                     const int grid = pick_blocks(r1 - r0, rc.p.L, cu);
+                     if (staged)
+                         hipLaunchKernelGGL(k_rrc<true>, dim3(grid), dim3(BT), dyn, ctx->stream, rc);
+                     else
+                         hipLaunchKernelGGL(k_rrc<false>, dim3(grid), dim3(BT), 0, ctx->stream, rc);
+                     IPD_KERNEL_CHECK();
                  },
                  {ra.y});
+    } else {
+        if (resid_small) {                                                              // :27
+            ResidDesc& rd = push_phase(ctx, st, PH_RESID, lv.N).u.r;
+            rd.lv = rn.dev;
+            rd.e = lv.e;
+            rd.row0 = 0;
+            rd.row1 = lv.N;
+        } else {
+            run_rows(ctx, st, 0, lv.N,
+                     [&](int r0, int r1) { launch_resid(ctx, rn, lv.e, r0, r1, cu); }, {lv.rr});
+        }
+        if (rest_small)
+            push_phase(ctx, st, PH_XFER, ra.ncols).u.x = ra;
+        else
+            run_rows(ctx, st, 0, ra.nrows,
+                     [&](int r0, int r1) {
+                         ra.row0 = r0;
+                         ra.row1 = r1;
+                         launch_xfer(ctx, ra, cu);
+                     },
+                     {ra.y});
     }
     amg_cycle(h, k + 1, isnsp, wcycle, false);                                   // :29
     // MG_Wcycle.m:30 -- the second correction; on the coarsest level it repeats the

@@ -471,6 +471,85 @@ __device__ __forceinline__ void phase_xfer(const XferArgs& a, int b, int G, Phas
 }
 
 // ---------------------------------------------------------------------------
+// fused residual + restriction:  r_c = P'(r - A e) = P'r - (P'A) e            MG_Vcycle.m:27
+// ---------------------------------------------------------------------------
+// T1 = P'A is the first product of the Galerkin triple (transfer.m:66) and is kept by the setup,
+// so the coarse right-hand side is ONE row walk over the rows of P' (against r) and of T1
+// (against e) instead of a residual launch followed by a restriction launch.
+struct RrcArgs {
+    XferArgs p;          // rows of P' (CSR), x = r (fine right-hand side), y = coarse right-hand side
+    const int* rp2;      // T1 = P'A (CSR, same rows)
+    const int* ci2;
+    const double* va2;
+    const double* e;     // fine iterate
+};
+
+template <bool STAGED>
+__device__ __forceinline__ void phase_rrc(const RrcArgs& a, int b, int G, PhaseLds* lds, double* xs) {
+    const int tid = threadIdx.x;
+    const int L = a.p.L, gpb = BT / L;
+    const int g = tid / L, gl = tid - g * L;
+    const bool uni = L >= 64;
+    const int ncols = a.p.ncols;
+    const int niter = (a.p.row1 - a.p.row0 + G * gpb - 1) / (G * gpb);
+    const double* __restrict__ r = a.p.x;
+    const double* __restrict__ e = a.e;
+    double* xe = xs + ncols;
+    auto rglobal = [&](int j) { return r[j]; };
+    auto eglobal = [&](int j) { return e[j]; };
+    auto rlds = [&](int j) { return xs[j]; };
+    auto elds = [&](int j) { return xe[j]; };
+    LevelDev lp, lt;   // only the CSR fields are used by row_open/row_finish<false>
+    lp.rp = a.p.rp;
+    lp.ci = a.p.ci;
+    lp.va = a.p.va;
+    lt.rp = a.rp2;
+    lt.ci = a.ci2;
+    lt.va = a.va2;
+    int row = uniform_if(a.p.row0 + b * gpb + g, uni);
+    bool valid = row < a.p.row1;
+    bool owner = valid && gl == 0;
+    RowCursor rcp, rct;
+    RowBatch btp, btt;
+    row_open<false>(lp, row, valid, owner, gl, L, rcp, btp);
+    row_open<false>(lt, row, valid, owner, gl, L, rct, btt);
+    if (STAGED) {
+        struct Q {
+            double r, e;
+        };
+        vec_pass(
+            ncols,
+            [&](int j) {
+                Q q;
+                q.r = r[j];
+                q.e = e[j];
+                return q;
+            },
+            [&](int j, const Q& q) {
+                xs[j] = q.r;
+                xe[j] = q.e;
+            });
+        __syncthreads();
+    }
+    for (int it = 0; it < niter; ++it) {
+        if (it > 0) {
+            row = uniform_if(a.p.row0 + (it * G + b) * gpb + g, uni);
+            valid = row < a.p.row1;
+            owner = valid && gl == 0;
+            row_open<false>(lp, row, valid, owner, gl, L, rcp, btp);
+            row_open<false>(lt, row, valid, owner, gl, L, rct, btt);
+        }
+        double s1 = STAGED ? row_finish<false>(lp, rcp, btp, gl, L, rlds)
+                           : row_finish<false>(lp, rcp, btp, gl, L, rglobal);
+        double s2 = STAGED ? row_finish<false>(lt, rct, btt, gl, L, elds)
+                           : row_finish<false>(lt, rct, btt, gl, L, eglobal);
+        double dummy;
+        s1 = reduce_rows(s1 - s2, L, false, 0.0, &dummy, lds);
+        if (owner) a.p.y[row] = s1;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // top of the Class_AMG loop: x_new = x + e ; r = b - A x_new  (k_conv then forms ||r||)
 // ---------------------------------------------------------------------------
 struct TopArgs {

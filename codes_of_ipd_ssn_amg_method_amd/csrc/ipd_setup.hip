@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void k_dense_compact2(int nr, int nc,
 }
 
 void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int level,
-                  ipd_rng* rng, Csr* Ac, Csr* Pout, Csr* Ptout, uint8_t* cmask) {
+                  ipd_rng* rng, Csr* Ac, Csr* Pout, Csr* Ptout, uint8_t* cmask, Csr* T1out) {
     IPD_REQUIRE(A.nr == A.nc, IPD_E_ARG, "transfer: A must be square");
     IPD_REQUIRE(&dst != ctx->scratch.get(), IPD_E_ARG, "transfer: dst must not be the scratch arena");
     CallScope scope(ctx);  // temporaries die with this call; results live in dst
@@ -790,8 +790,9 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
     // Ac = Pro'*A*Pro, evaluated left to right                               transfer.m:66
     Csr Pt, T1, C;
     csr_transpose(ctx, dst, P, &Pt);
-    csr_spgemm(ctx, tmp, Pt, A, &T1);
+    csr_spgemm(ctx, T1out ? dst : tmp, Pt, A, &T1);
     csr_spgemm(ctx, dst, T1, P, &C);
+    if (T1out) *T1out = T1;
     *Ac = C;
     *Pout = P;
     *Ptout = Pt;
@@ -870,6 +871,7 @@ ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng,
         nl.A = donor->L[2].A;
         nl.P = donor->L[2].P;
         nl.Pt = donor->L[2].Pt;
+        nl.T1 = donor->L[2].T1;
         nl.cmask = donor->L[2].cmask;
         nl.N = nl.A.nr;
         h->L.push_back(nl);
@@ -887,7 +889,7 @@ ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng,
         const Csr& Ak = h->L[h->J].A;
         Level nl;
         nl.cmask = h->arena->alloc<uint8_t>((size_t)Ak.nr);
-        amg_transfer(ctx, *h->arena, Ak, o, h->J, rng, &nl.A, &nl.P, &nl.Pt, nl.cmask);
+        amg_transfer(ctx, *h->arena, Ak, o, h->J, rng, &nl.A, &nl.P, &nl.Pt, nl.cmask, &nl.T1);
         nl.N = nl.A.nr;
         IPD_REQUIRE(nl.N < Ak.nr, IPD_E_NUMERIC,
                     "Class_AMG: coarsening made no progress (the reference would loop forever)");
