@@ -278,6 +278,23 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         sm[oE2 + j] = 0.0;
         sm[oAX2 + j] = D.L2.Axi[j];
     }
+    // One-row tail (the dense regimes): its transfer operator is one column, kept densely in the
+    // unused upper half of the RR2 slot (restriction and prolongation use the same numbers), and
+    // its operator is one number: the tail then costs two LDS passes instead of five dependent
+    // trips to L2 per visit.
+    const bool tail1 = Nt == 1 && N2 <= RES_NMAX / 2;
+    constexpr int oP3C = oRR2 + RES_NMAX / 2;
+    double h33 = 0.0;
+    if (tail1) {
+        for (int j = tid; j < N2; j += BT) {
+            double v = 0.0;
+            for (int t = D.P3.rp[j]; t < D.P3.rp[j + 1]; ++t)
+                if (D.P3.ci[t] == 0) v = D.P3.va[t];
+            sm[oP3C + j] = v;
+        }
+        for (int t = D.A3.rp[0]; t < D.A3.rp[1]; ++t)
+            if (D.A3.ci[t] == 0) h33 = D.A3.va[t];
+    }
     if (tid == 0) *fail = 0;
     __syncthreads();
 
@@ -446,6 +463,42 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // tail level: restriction, Jacobi-PCG (PCG.m:68-87, zero guess), prolongation -- all of it by
     // every workgroup on its own LDS copies, so no hand-off                     MG_Vcycle.m:27-31,43
     auto tail = [&]() {
+        if (tail1) {
+            double s = 0.0;
+            for (int j = tid; j < N2; j += BT) s += sm[oP3C + j] * sm[oRR2 + j];       // r_3 = P' rr
+            s = wave_sum(s);
+            if (lane == 0) red[w] = s;
+            __syncthreads();
+            // PCG.m:68-87 on the 1 x 1 system, by every thread (the arithmetic of pcg_single)
+            double r = res_red8(red);
+            double pp = r / h33, d = 0.0;
+            double delta_new = r * pp;
+            const double thresh = 1e-11 * 1e-11 * delta_new;
+            for (long long it = 0; it < D.pcg_maxit && delta_new > thresh; ++it) {
+                const double delta_old = delta_new;
+                const double q = h33 * pp;
+                const double alpha = delta_old / (q * pp);
+                d += alpha * pp;
+                r = r - alpha * q;
+                const double wi = r / h33;
+                delta_new = r * wi;
+                pp = wi + (delta_new / delta_old) * pp;
+            }
+            __syncthreads();   // red is rewritten below
+            double p0 = 0.0;
+            for (int j = tid; j < N2; j += BT) {                                       // e_2 += P e_3
+                const double en = sm[oE2 + j] + sm[oP3C + j] * d;
+                sm[oE2 + j] = en;
+                p0 += sm[oR2 + j] - sm[oAX2 + j] * en;
+            }
+            if (nsp) {
+                p0 = wave_sum(p0);
+                if (lane == 0) red[w] = p0;
+            }
+            __syncthreads();
+            if (nsp) c2s = res_red8(red) / xx2;
+            return;
+        }
         if (Nt == 1) {
             // one row: its entries are dealt to all the waves, the eight partial sums are added in
             // wave order (a single wave walking 1024 entries took four dependent trips)
