@@ -65,7 +65,7 @@ __device__ __forceinline__ v4u pack(double v, unsigned tag) {
 // PROTO 1: plain fp64 payload (sc1 stores by ONE wave, drained) + one flag word per producer;
 //          wave 0 polls the G flags (4 per lane), then every thread loads 16 bytes of payload
 // PROTO 2: no exchange at all (every workgroup keeps its stale LDS copy): the compute floor
-template <int PROTO, int PW, int SLEEP, int BT>
+template <int PROTO, int PW, int SLEEP, int BT, int LAUX = 16, int SAUX = 16, int PRESLEEP = 0>
 __global__ __launch_bounds__(BT) void k_xchg(const unsigned short* __restrict__ pci,
                                              const double* __restrict__ pva, const double* x0,
                                              unsigned char* gran0, unsigned char* gran1,
@@ -119,8 +119,9 @@ __global__ __launch_bounds__(BT) void k_xchg(const unsigned short* __restrict__ 
                 const int wpg = L >> 6;
                 for (int k = 0; k < wpg; ++k) t += red[tid * wpg + k];
                 __builtin_amdgcn_raw_buffer_store_b128(pack(t, (unsigned)step), rs,
-                                                       (b * rpw + tid) * 16, 0, 16);
+                                                       (b * rpw + tid) * 16, 0, SAUX);
             }
+            if (PRESLEEP) __builtin_amdgcn_s_sleep(PRESLEEP);
             if (w < PW) {
                 // granules of this wave: lane, lane+64*PW ... interleaved so that a pass is coalesced
                 constexpr int NJMAX = 2048 / (64 * PW);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(BT) void k_xchg(const unsigned short* __restrict__ 
                     for (int u = 0; u < NJMAX; ++u)
                         if (u < nj)
                             gq[u] = __builtin_amdgcn_raw_buffer_load_b128(
-                                rs, ((u * PW + w) * 64 + lane) * 16, 0, 16);
+                                rs, ((u * PW + w) * 64 + lane) * 16, 0, LAUX);
                     bool ok = true;
 #pragma unroll
                     for (int u = 0; u < NJMAX; ++u)
@@ -233,15 +234,19 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const Variant vars[] = {
-        {"512thr compute only        ", k_xchg<2, 1, 0, 512>, 2, 512},
-        {"512thr granules 8w sleep1  ", k_xchg<0, 8, 1, 512>, 0, 512},
-        {"1024thr compute only       ", k_xchg<2, 1, 0, 1024>, 2, 1024},
-        {"1024thr granules 16w sleep1", k_xchg<0, 16, 1, 1024>, 0, 1024},
-        {"1024thr granules 16w spin  ", k_xchg<0, 16, 0, 1024>, 0, 1024},
-        {"1024thr granules 8w sleep1 ", k_xchg<0, 8, 1, 1024>, 0, 1024},
+        {"512thr compute only            ", k_xchg<2, 1, 0, 512>, 2, 512},
+        {"512thr granules 8w sleep1      ", k_xchg<0, 8, 1, 512>, 0, 512},
+        {"512thr 8w sleep1 loads sc0sc1  ", k_xchg<0, 8, 1, 512, 17, 16>, 0, 512},
+        {"512thr 8w sleep1 stores sc0sc1 ", k_xchg<0, 8, 1, 512, 16, 17>, 0, 512},
+        {"512thr 8w sleep1 both sc0sc1   ", k_xchg<0, 8, 1, 512, 17, 17>, 0, 512},
+        {"512thr 8w sleep1 presleep 8    ", k_xchg<0, 8, 1, 512, 16, 16, 8>, 0, 512},
+        {"512thr 8w sleep1 presleep 16   ", k_xchg<0, 8, 1, 512, 16, 16, 16>, 0, 512},
+        {"512thr 8w sleep4               ", k_xchg<0, 8, 4, 512>, 0, 512},
+        {"512thr 4w sleep1               ", k_xchg<0, 4, 1, 512>, 0, 512},
+        {"512thr 8w sleep1 loads nt      ", k_xchg<0, 8, 1, 512, 18, 16>, 0, 512},
     };
-    for (int N : {1024, 2048})
-        for (int G : {64, 128, 256})
+    for (int N : {1024})
+        for (int G : {128})
             for (const Variant& v : vars) {
                 const int S = 1024;
                 const int BT = v.bt;
