@@ -123,7 +123,7 @@ EXPORTS = [
     "ipd_comm_init", "ipd_comm_finalize", "ipd_comm_stats", "ipd_ctx_set_component_order", "ipd_amg_bench_cycles_sharded",
     "ipd_apd_opts_init", "ipd_apd_create", "ipd_apd_destroy", "ipd_apd_dims", "ipd_apd_warmup",
     "ipd_apd_set_state", "ipd_apd_get_state", "ipd_apd_run", "ipd_apd_history",
-    "ipd_apd_records", "ipd_apd_begin", "ipd_apd_eval", "ipd_apd_bench_eval", "ipd_prof_read", "ipd_amg_bench_subcycle",
+    "ipd_apd_records", "ipd_apd_reuse_stats", "ipd_apd_begin", "ipd_apd_eval", "ipd_apd_bench_eval", "ipd_prof_read", "ipd_amg_bench_subcycle",
     "ipd_amg_attach_mask_operator", "ipd_twogrid_bigph", "ipd_twogrid", "ipd_hybrid_twogrid", "ipd_amg4pot_twogrid",
     "ipd_aug_pcg", "ipd_pcg4pot",
 ]

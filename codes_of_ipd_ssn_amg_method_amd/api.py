@@ -655,6 +655,13 @@ class APDWorkspace:
         keys = [f[0] for f in L.ipd_ssn_rec._fields_]
         return [{k: getattr(arr[i], k) for k in keys} for i in range(cnt.value)]
 
+    def reuse_stats(self):
+        """Row f3: (Newton steps solved with AMG, steps whose system repeated the previous one,
+        setups that shared the previous step's levels 1-2)."""
+        a, b, c = c_int64(0), c_int64(0), c_int64(0)
+        check(lib.ipd_apd_reuse_stats(self.handle, byref(a), byref(b), byref(c)))
+        return a.value, b.value, c.value
+
     # -- building blocks ------------------------------------------------------
     def begin(self, k: int):
         vals = (c_double * 3)()
@@ -709,7 +716,7 @@ def _run_script(ws: APDWorkspace, amg_opts: dict, rng, warm, opts) -> dict:
         out = ws.run(amg_opts, rng, **opts)
         u, v, lam, bk = ws.state()
         out.update(ws.history())
-        out.update(uk=u, vk=v, lk=lam, bk=bk, records=ws.records())
+        out.update(uk=u, vk=v, lk=lam, bk=bk, records=ws.records(), reuse_stats=ws.reuse_stats())
         out["xk"] = u[:ws.m * ws.n]
         return out
     finally:

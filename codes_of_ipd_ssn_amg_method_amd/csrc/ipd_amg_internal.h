@@ -99,14 +99,25 @@ struct HybridOut {
     double resamg = 0.0;
     long long num_comp = 0, it_num = 0;
 };
+// Row f3, reuse across Newton steps: the hierarchies of the previous Hybrid_AMG / AMG4POT call of
+// a driver, kept alive so that a step whose system is the SAME (same active set, T, bk1, tk: the
+// caller says so in `same`) shares their rand-independent levels 1-2 through amg_setup's donor
+// mechanism.  Guesses and levels >= 3 still draw the stream's next numbers, so results and the
+// count of consumed numbers are those of a full setup, bit for bit.
+struct StepDonors {
+    std::vector<std::shared_ptr<ipd_amg>> prev;   // in order of use (large components)
+    bool same = false;                            // set by the caller before each call
+    long long steps = 0, same_steps = 0, shared = 0;   // calls, calls with `same`, donated setups
+};
 // opts.twogrid selects Hybrid_twogrid.m (twogrid_bigph on every large component)
 void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
                     const double* q, int m, int n, double bk1, double tk, const double* z,
-                    const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out);
+                    const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out,
+                    StepDonors* step = nullptr);
 void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
                  const double* q, int m, int n, double bk1, double tk, const double* z,
                  const uint8_t* s, const double* phi, const AmgOpts& opts, ipd_rng* rng,
-                 double* zeta, HybridOut* out);
+                 double* zeta, HybridOut* out, StepDonors* step = nullptr);
 // aug_PCG.m / Class2/PCG4POT.m (inner_solver = 3): PCG on the kernel-augmented system
 void aug_pcg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p, const double* q,
                  int m, int n, double bk1, double tk, const double* z, double tol, long long maxit,

@@ -666,6 +666,23 @@ __global__ __launch_bounds__(BT) void k_merit_fin(const MeritFin a) {
     }
 }
 
+// Row f3: is this Newton step's system the previous one's?  Compares the active-set mask (and,
+// class 2, the 0/1 diagonal of T) with the copies kept from the last step, refreshes the copies
+// and raises *changed on any difference.  8-byte words; the caller pads the mask to a multiple.
+__global__ void k_words_changed(size_t nw, const unsigned long long* __restrict__ cur,
+                                unsigned long long* __restrict__ prev, int* __restrict__ changed) {
+    bool diff = false;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nw;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long c = cur[i];
+        if (c != prev[i]) {
+            diff = true;
+            prev[i] = c;
+        }
+    }
+    if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(changed, 1);
+}
+
 __global__ void k_negate(int n, const double* __restrict__ x, double* __restrict__ y) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         y[i] = -x[i];
@@ -953,6 +970,13 @@ struct ipd_apd {
     std::vector<ipd_ssn_rec> recs;
     long long sum_amg = 0, total_amg = 0, fail_amg = 0, max_amg = 0;
     int restarts = 0;
+    // row f3: hierarchies of the previous Newton step and what its system was built from
+    StepDonors step;
+    bool step_reuse = true, have_prev = false;
+    double prev_bk1 = 0.0, prev_tk = 0.0;
+    size_t s_words = 0;
+    unsigned long long *s_prev = nullptr, *t_prev = nullptr;
+    int* step_changed = nullptr;
     int nblk() const { return geo.nib * geo.njg; }
 };
 
@@ -1187,6 +1211,27 @@ void copy_dev(ipd_apd* h, double* dst, const double* src, size_t n) {
     IPD_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, h->ctx->stream));
 }
 
+// Row f3: true when the system of this Newton step (active set, class 2's T, bk1, tk; p and q
+// never change) is the one the previous step's hierarchies were built for.
+bool step_same_system(ipd_apd* h, double bk1, double tk) {
+    ipd_ctx* ctx = h->ctx;
+    IPD_HIP(hipMemsetAsync(h->step_changed, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_words_changed, dim3(std::max(1, std::min(cdiv((int)std::min<size_t>(h->s_words, 1u << 30), 256), 1024))),
+                       dim3(256), 0, ctx->stream, h->s_words,
+                       reinterpret_cast<const unsigned long long*>(h->s), h->s_prev, h->step_changed);
+    if (h->tmask)
+        hipLaunchKernelGGL(k_words_changed, dim3(cdiv(h->M, 256)), dim3(256), 0, ctx->stream,
+                           (size_t)h->M, reinterpret_cast<const unsigned long long*>(h->tmask),
+                           h->t_prev, h->step_changed);
+    IPD_KERNEL_CHECK();
+    const bool changed = ctx->fetch1(h->step_changed) != 0;
+    const bool same = h->have_prev && !changed && bk1 == h->prev_bk1 && tk == h->prev_tk;
+    h->have_prev = true;
+    h->prev_bk1 = bk1;
+    h->prev_tk = tk;
+    return same;
+}
+
 // one APD iteration                                       Class1 :101-275, Class2 :95-285
 void apd_iterate(ipd_apd* h, const ipd_apd_opts& o, const AmgOpts& amg, ipd_rng* rng) {
     const int solver = o.inner_solver;
@@ -1228,6 +1273,16 @@ void apd_iterate(ipd_apd* h, const ipd_apd_opts& o, const AmgOpts& amg, ipd_rng*
             hipLaunchKernelGGL(k_negate, dim3(cdiv(h->L, 256)), dim3(256), 0, ctx->stream, h->L,
                                (const double*)F_old, h->negF);                     // z = -Fk_old
             IPD_KERNEL_CHECK();
+            StepDonors* step = nullptr;
+            if (h->step_reuse && solver == 4) {
+                step = &h->step;
+                step->same = step_same_system(h, bk1, tk);
+                ++step->steps;
+                step->same_steps += step->same;
+            } else {
+                h->have_prev = false;
+                h->step.prev.clear();
+            }
             if (solver == 2) {                                     // :149-152  PCG(Jk,-Fk_old)
                 Csr Jk;
                 build_jk(ctx, *ctx->scratch, H0, nullptr, bk1, tk, &Jk);
@@ -1246,10 +1301,10 @@ void apd_iterate(ipd_apd* h, const ipd_apd_opts& o, const AmgOpts& amg, ipd_rng*
                                 o.pcg_retol, o.pcg_maxit, h->zeta, &ho);
             } else if (c2) {                                       // 4: 'amg', 5: 'twogrid'
                 amg4pot_dev(ctx, H0, h->tmask, h->p, h->q, h->m, h->n, bk1, tk, h->negF, h->s,
-                            h->phi, amg, rng, h->zeta, &ho);                       // Class2 :171
+                            h->phi, amg, rng, h->zeta, &ho, step);                 // Class2 :171
             } else {
                 hybrid_amg_dev(ctx, H0, nullptr, h->p, h->q, h->m, h->n, bk1, tk, h->negF, amg,
-                               rng, h->zeta, &ho);                                 // Class1 :161
+                               rng, h->zeta, &ho, step);                           // Class1 :161
             }
         }
         const int itpcg = ho.itamg;
@@ -1566,7 +1621,16 @@ extern "C" int ipd_apd_create(ipd_ctx* ctx, const ipd_apd_data* d, ipd_apd** out
         h->negF = A.alloc<double>((size_t)L);
         for (double* a : {h->lam, h->lam_a, h->lam_b, h->wlk, h->F_a, h->F_b, h->zeta, h->negF})
             IPD_HIP(hipMemsetAsync(a, 0, (size_t)L * sizeof(double), ctx->stream));
-        h->s = A.alloc<uint8_t>(mn);
+        h->s_words = (mn + 7) / 8;                      // compared in 8-byte words (row f3)
+        h->s = A.alloc<uint8_t>(h->s_words * 8);
+        IPD_HIP(hipMemsetAsync(h->s, 0, h->s_words * 8, ctx->stream));
+        h->s_prev = A.alloc<unsigned long long>(h->s_words);
+        if (d->cls == 2) h->t_prev = A.alloc<unsigned long long>((size_t)h->M);
+        h->step_changed = A.alloc<int>(1);
+        {
+            const char* e = getenv("IPD_NO_STEP_DONOR");
+            h->step_reuse = !(e && e[0] == '1');
+        }
         const Geo& g = h->geo;
         h->lpart = A.alloc<double>((size_t)g.njg * m);
         h->rpart = A.alloc<double>((size_t)g.nib * 4 * n);
@@ -1699,6 +1763,16 @@ extern "C" int ipd_apd_history(const ipd_apd* h, int32_t which, double* out, int
         if (out)
             for (int64_t i = 0; i < nn; ++i) out[i] = (*src)[(size_t)i];
         *count = (int64_t)src->size();
+    });
+}
+
+extern "C" int ipd_apd_reuse_stats(const ipd_apd* h, int64_t* steps, int64_t* same_system,
+                                   int64_t* donated) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h, IPD_E_ARG, "NULL handle");
+        if (steps) *steps = h->step.steps;
+        if (same_system) *same_system = h->step.same_steps;
+        if (donated) *donated = h->step.shared;
     });
 }
 

@@ -465,8 +465,10 @@ struct HybridCache {
     // donors (default path): the first call records its hierarchies, the second call's setups
     // share their rand-independent part (amg_setup's `donor`): bit-identical results
     bool record_donors = false, use_donors = false;
-    std::vector<std::shared_ptr<ipd_amg>> donors;
+    std::vector<std::shared_ptr<ipd_amg>> donors;     // offered to the setups of this call
+    std::vector<std::shared_ptr<ipd_amg>> recorded;   // set up by this call
     size_t next_donor = 0;
+    long long* shared_count = nullptr;                // setups that took a donor's levels
 };
 
 // Work postponed to the solve phase of a Hybrid_AMG call: AMG4POT's two calls set their
@@ -498,7 +500,8 @@ static std::function<void(int*, double*)> class_amg_prepare(
         own = std::shared_ptr<ipd_amg>(amg_setup(ctx, A, o, rng, donor), ipd_amg_destroy);
         h = own.get();
         if (mh.p && o.bigph) amg_attach_maskop(h, mh.p, mh.q, mh.m, mh.n, mh.tk, true);
-        if (cache->record_donors) cache->donors.push_back(own);
+        if (cache->record_donors) cache->recorded.push_back(own);
+        if (cache->shared_count && own->donor) ++*cache->shared_count;
     } else {
         ProfScope ps(ctx, PROF_AMG_SETUP);
         std::unique_ptr<ipd_amg, void (*)(ipd_amg*)> fresh(amg_setup(ctx, A, o, rng), ipd_amg_destroy);
@@ -564,8 +567,21 @@ static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, 
 
 void hybrid_amg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
                     const double* q, int m, int n, double bk1, double tk, const double* z,
-                    const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out) {
-    hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, z, opts, rng, zeta, out, nullptr);
+                    const AmgOpts& opts, ipd_rng* rng, double* zeta, HybridOut* out,
+                    StepDonors* step) {
+    if (!step) {
+        hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, z, opts, rng, zeta, out, nullptr);
+        return;
+    }
+    // consecutive Newton steps with the same system (Hybrid_AMG.m:40-41 sets up per call)
+    HybridCache cache;
+    cache.record_donors = true;
+    cache.use_donors = step->same;
+    if (step->same) cache.donors = step->prev;
+    cache.shared_count = &step->shared;
+    step->prev.clear();
+    hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, z, opts, rng, zeta, out, &cache);
+    step->prev = std::move(cache.recorded);
 }
 
 static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
@@ -815,13 +831,14 @@ static void pot_reduce(ipd_ctx* ctx, const Csr& H0, const double* p, const doubl
 void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
                  const double* q, int m, int n, double bk1, double tk, const double* z,
                  const uint8_t* s, const double* phi, const AmgOpts& opts, ipd_rng* rng,
-                 double* zeta, HybridOut* out) {
+                 double* zeta, HybridOut* out, StepDonors* step) {
     const char* re = getenv("IPD_REUSE_HIERARCHY");
     const bool reuse_env = re && re[0] == '1';
     const char* nc = getenv("IPD_NO_POT_CONCURRENT");
     const bool concurrent = !reuse_env && !(nc && nc[0] == '1');
     HybridCache cache;
     if (!concurrent) {
+        if (step) step->prev.clear();
         auto solve = [&](const double* rhs, double* x, HybridOut* o) {
             hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o,
                               reuse_env ? &cache : nullptr);
@@ -839,13 +856,22 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
     bool have_first = false;
     const char* nd = getenv("IPD_NO_DONOR");
     const bool donors = !(nd && nd[0] == '1');
+    if (step && !donors) step->prev.clear();
     auto solve = [&](const double* rhs, double* x, HybridOut* o) {
         if (!have_first) {
             cache.record_donors = donors;
+            if (step && donors && step->same) {   // the previous Newton step had this very system
+                cache.use_donors = true;
+                cache.donors = step->prev;
+                cache.shared_count = &step->shared;
+            }
             hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o,
                               donors ? &cache : nullptr, &first);
             cache.record_donors = false;
             cache.use_donors = donors;
+            cache.donors = cache.recorded;   // the second setup shares the first one's levels
+            cache.next_donor = 0;
+            cache.shared_count = nullptr;
             have_first = true;
             return;
         }
@@ -877,6 +903,10 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
         first.clear();    // releases the hierarchies
         second.clear();
         cache.donors.clear();
+        if (step && donors)
+            step->prev = std::move(cache.recorded);   // kept for the next Newton step
+        else
+            cache.recorded.clear();
         if (err0) std::rethrow_exception(err0);
         if (err) std::rethrow_exception(err);
     };

@@ -846,7 +846,10 @@ int amg_coarsest_threshold(int N) { return 1 + (int)std::floor(std::pow((double)
 // shared and the rest is built with the stream's next numbers exactly as a full setup would:
 // same bits, same rand consumption, without the most expensive product of the setup.
 ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng,
-                   const std::shared_ptr<ipd_amg>& donor) {
+                   const std::shared_ptr<ipd_amg>& donor_in) {
+    // a donor that itself took its levels 1-2 from another hierarchy: share with that root, so
+    // that a chain of Newton steps with the same system keeps two hierarchies alive, not all
+    const std::shared_ptr<ipd_amg> donor = donor_in && donor_in->donor ? donor_in->donor : donor_in;
     IPD_REQUIRE(A.nr == A.nc && A.nr > 0, IPD_E_ARG, "Class_AMG: A must be square and non-empty");
     if (o.bigph)  // Class_AMG.m:36-40
         IPD_REQUIRE(o.fnode > 0, IPD_E_ARG, "amg_options.bigph = 1 requires Nf > 0");

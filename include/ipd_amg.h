@@ -343,6 +343,13 @@ int ipd_apd_run(ipd_apd* h, const ipd_apd_opts* o, const ipd_amg_opts* amg, ipd_
  * 5 SsN_itnum (k entries).  Returns the number of entries written in *count.    */
 int ipd_apd_history(const ipd_apd* h, int32_t which, double* out, int64_t cap, int64_t* count);
 int ipd_apd_records(const ipd_apd* h, ipd_ssn_rec* out, int64_t cap, int64_t* count);
+/* Row f3 of SURVEY.md section 8 (hierarchy reuse across Newton steps).  The reference sets the
+ * hierarchy up at every Newton step (Hybrid_AMG.m:40-41, AMG/Class_AMG.m:41-85); when a step's
+ * system equals the previous step's (same active set, T, bk1, tk) its setups share the previous
+ * hierarchies' rand-independent levels 1-2, bit for bit the same result (IPD_NO_STEP_DONOR=1
+ * rebuilds everything).  *steps = Newton steps solved with AMG, *same_system = those whose system
+ * repeated, *donated = setups that took levels from the previous step.  NULLs are skipped.    */
+int ipd_apd_reuse_stats(const ipd_apd* h, int64_t* steps, int64_t* same_system, int64_t* donated);
 /* Building blocks of one APD iteration, exposed for parity tests and callers that
  * keep the outer loop: `begin` fixes k and forms ak, bk1, tk, wk, wlk (:113-126);
  * `eval` evaluates zk = (wk - H'*lam)/tk, s, Fk = bk1*lam - H*prox(zk) - wlk and the

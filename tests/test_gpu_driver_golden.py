@@ -71,3 +71,4 @@ def test_class2_bundled_problem():
     # the 2.4e-6 uncertainty of lk0 (above) is inherited by the first APD iterations and decays
     # from there (observed: 2e-6 at k = 1, 1e-7 at k = 5, 3e-11 at the end)
     compare(out, g, ("fxk", "KKT_xk", "KKT_lk", "KKT_yk", "KKT_zk"), rtol=2e-5)
+
