@@ -222,6 +222,18 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     D.maxit = h->opts.maxit;
     D.retol = h->opts.retol;
     D.pcg_maxit = h->opts.pcg_maxit;
+    // bigraph transfers P = [W; I]: the kernel adds the identity entries instead of walking them
+    D.wident = 0;
+    if (N2 == nc && !(std::getenv("IPD_RES_NO_IDENT") && std::getenv("IPD_RES_NO_IDENT")[0] == '1')) {
+        int* bad = h->ctx->scratch->alloc<int>(1);
+        IPD_HIP(hipMemsetAsync(bad, 0, sizeof(int), h->ctx->stream));
+        hipLaunchKernelGGL(k_res_check_ident, dim3(cdiv(N2, 256)), dim3(256), 0, h->ctx->stream, nf, N2,
+                           csr(l2.P), csr(l2.Pt), bad);
+        IPD_KERNEL_CHECK();
+        D.wident = h->ctx->fetch1(bad) == 0 ? 1 : 0;
+    }
+    D.presleep = 13;   // measured: 0 -> 0.0869, 8 -> 0.0796, 12..14 -> 0.0770, 16 -> 0.0784 ms per V cycle (a failing poll delays the publishes it waits for)
+    if (const char* e = std::getenv("IPD_RES_PRESLEEP")) D.presleep = std::max(0, std::min(64, std::atoi(e)));
     const size_t gbytes = (size_t)RES_GRAN_MAX * 16;
     st->res_block = reinterpret_cast<unsigned char*>(ar.alloc_bytes(2 * gbytes + 16));
     D.gran0 = st->res_block;

@@ -63,12 +63,14 @@ struct ResDesc {
     ResCsr Pt2, P2;   // level 1 <-> 2: restriction rows (N2 x N1), prolongation rows (N1 x N2)
     ResCsr Pt3, P3;   // level 2 <-> tail
     ResCsr A3;        // tail operator (CSR)
+    int wident;       // P = [W; I] verified (k_res_check_ident): identity entries are added, not walked
     int Nt;           // tail rows
     int nu, isnsp, wcycle, anycycle, maxit;
     double retol;
     long long pcg_maxit;
     unsigned char* gran0;
     unsigned char* gran1;
+    int presleep;       // s_sleep(1) repetitions between a publish and the first poll of its sweep
     unsigned* tmo;      // [0] != 0: a bounded spin gave up (value = step number)
     long long* dbg;     // optional stamps (diagnostic build of the bench): see k_resident
 };
@@ -178,9 +180,9 @@ __device__ __forceinline__ double res_rowdot(unsigned (&c)[KE / 2], const double
 
 // CSR row of a transfer operator (global, L2-resident) against an LDS vector, one wave per row
 __device__ __forceinline__ double res_csr_rowdot(const ResCsr& M, int row, bool valid, int lane,
-                                                 const double* sm, int off) {
+                                                 const double* sm, int off, int drop_last = 0) {
     const int e0 = M.rp[valid ? row : 0];
-    const int e1 = valid ? M.rp[row + 1] : e0;
+    const int e1 = valid ? M.rp[row + 1] - drop_last : e0;
     double s = 0.0;
     for (int t = e0 + lane; t < e1; t += 64 * 8) {   // 8 entries per lane in flight: a 1025-entry row = 3 trips
         int jj[8];
@@ -196,6 +198,20 @@ __device__ __forceinline__ double res_csr_rowdot(const ResCsr& M, int row, bool 
         for (int u = 0; u < 8; ++u) s += (t + 64 * u < e1) ? aa[u] * sm[off + jj[u]] : 0.0;
     }
     return wave_sum(s);
+}
+
+// *bad != 0 unless the level 1 <-> 2 transfers have the bigraph form P = [W; I] (AMG/transfer.m:19-25)
+// entry for entry: every row of P' (level-2 row c) ends with the identity entry (column nf + c, value
+// 1) and row nf + c of P is that identity entry alone.  The kernel then adds the identity parts
+// itself: a 1025-entry row of P' is two 512-entry trips instead of three, and the C rows of P cost
+// no trip at all.
+__global__ void k_res_check_ident(int nf, int N2, ResCsr P, ResCsr Pt, int* __restrict__ bad) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < N2; c += gridDim.x * blockDim.x) {
+        const int e1 = Pt.rp[c + 1], p0 = P.rp[nf + c];
+        const bool ok = e1 > Pt.rp[c] && Pt.ci[e1 - 1] == nf + c && Pt.va[e1 - 1] == 1.0 &&
+                        P.rp[nf + c + 1] - p0 == 1 && P.ci[p0] == c && P.va[p0] == 1.0;
+        if (!ok) atomicOr(bad, 1);
+    }
 }
 
 // Block sums of up to two per-thread partials through red[0..2*RES_WAVES): the caller has
@@ -331,6 +347,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
                 res_publish(rs, seq, (second_ ? (gB) : (gA)) + l8_, sm[oPUB + lane]);              \
         }                                                                                          \
         if (dbg) dbg_acc[0] -= __builtin_amdgcn_s_memtime();                                       \
+        for (int ps_ = 0; ps_ < D.presleep; ++ps_) __builtin_amdgcn_s_sleep(1);                    \
         if (res_sweep<NJ>(rs, seq, (n), dead, D.tmo, hv_)) {                                          \
             *fail = 1;                                                                             \
             if (lane == 0) __hip_atomic_store(D.tmo, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
@@ -602,7 +619,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         }
         {   // r_2 = P' rr ; E2 := 0 ; c for the zero start
             if (dbg) dbg_acc[6] -= __builtin_amdgcn_s_memtime();
-            const double s = res_csr_rowdot(D.Pt2, r2, v2, lane, sm, oRR1);
+            // row r2 of P' is [W(:,r2)' , 1 at nf + r2]; rowC == nf + row2 (level 2 = the C nodes)
+            const double s = res_csr_rowdot(D.Pt2, r2, v2, lane, sm, oRR1, D.wident) +
+                             (D.wident ? sm[oRR1 + rC] : 0.0);
             if (dbg) dbg_acc[6] += __builtin_amdgcn_s_memtime();
             if (lane == 0) sm[oPUB + w] = s;
             double sumr = 0.0;
@@ -613,8 +632,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         for (int leg = 0; leg < (D.wcycle ? 2 : 1); ++leg) visit2(leg == 1);      // MG_Wcycle.m:28-30
         {   // e_1 += P e_2                                                        MG_Vcycle.m:31
             if (dbg) dbg_acc[6] -= __builtin_amdgcn_s_memtime();
+            // F rows: W(rowF,:) against E2 (A's columns nf + i are level-2 indices i); C rows: identity
             const double sF = res_csr_rowdot(D.P2, rF, vF, lane, sm, oE2);
-            const double sC = res_csr_rowdot(D.P2, rC, vC, lane, sm, oE2);
+            const double sC = D.wident ? sm[oE2 + r2] : res_csr_rowdot(D.P2, rC, vC, lane, sm, oE2);
             if (dbg) dbg_acc[6] += __builtin_amdgcn_s_memtime();
             if (lane == 0) {
                 sm[oPUB + w] = sm[oE1 + rF] + sF;
