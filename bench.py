@@ -317,7 +317,10 @@ def main():
     # residual + restriction are ONE launch, r_c = P'r - (P'A)e
     fused_rrc = [h.level_dims(k)[1] * 2 <= (1 << 18) for k in (1, 2)] if h.J == 3 else None
     launches_classic = 4 * nu + 2 + visits2 * (2 * nu + 4) + 1 + 2
-    handoffs = 4 * nu + 3 + visits2 * (2 * nu + 1) + 1 if h.J == 3 else None
+    # hand-offs of the resident kernel per cycle: top, 2 per level-1 sweep, residual, restriction,
+    # per level-2 visit nu + nu sweeps and a residual, prolongation; the zero-start first sweeps of
+    # level 1 and of level 2's first visit need no matrix row and are formed locally (-2)
+    handoffs = (4 * nu + 3 + visits2 * (2 * nu + 1) + 1 - (2 if nu >= 1 else 0)) if h.J == 3 else None
     result = {
         "metric": "V-cycle throughput (DoF*cycles/sec), m=n=%d OT grid" % m,
         "value": value, "unit": "DoF*cycles/s", "n_gpus": world, "steps": args.steps,

@@ -41,7 +41,7 @@ static constexpr int RES_WAVES = BT / 64;     // row slots per block and workgro
 static constexpr int RES_TAIL_MAX = 64;       // rows of the redundantly solved tail level
 static constexpr int RES_NMAX = 4 * BT;        // rows per level (fixed LDS slots)
 static constexpr int RES_GRAN_MAX = RES_NMAX;  // granules per hand-off buffer
-static constexpr size_t RES_LDS_BYTES = sizeof(double) * ((size_t)9 * RES_NMAX + 3 * RES_TAIL_MAX + 12 * RES_WAVES + 12);
+static constexpr size_t RES_LDS_BYTES = sizeof(double) * ((size_t)9 * RES_NMAX + 3 * RES_TAIL_MAX + 16 * RES_WAVES + 12);
 static constexpr unsigned RES_SPIN_MAX = 1u << 18;
 
 struct ResLevelDesc {
@@ -63,6 +63,7 @@ struct ResDesc {
     ResCsr Pt2, P2;   // level 1 <-> 2: restriction rows (N2 x N1), prolongation rows (N1 x N2)
     ResCsr Pt3, P3;   // level 2 <-> tail
     ResCsr A3;        // tail operator (CSR)
+    int localfirst;   // zero-start first sweeps formed locally (see k_resident); 0: handed off like the rest
     int wident;       // P = [W; I] verified (k_res_check_ident): identity entries are added, not walked
     int Nt;           // tail rows
     int nu, isnsp, wcycle, anycycle, maxit;
@@ -179,10 +180,8 @@ __device__ __forceinline__ double res_rowdot(unsigned (&c)[KE / 2], const double
 }
 
 // CSR row of a transfer operator (global, L2-resident) against an LDS vector, one wave per row
-__device__ __forceinline__ double res_csr_rowdot(const ResCsr& M, int row, bool valid, int lane,
-                                                 const double* sm, int off, int drop_last = 0) {
-    const int e0 = M.rp[valid ? row : 0];
-    const int e1 = valid ? M.rp[row + 1] - drop_last : e0;
+__device__ __forceinline__ double res_csr_rowdot(const ResCsr& M, int e0, int e1, int lane,
+                                                 const double* sm, int off) {
     double s = 0.0;
     for (int t = e0 + lane; t < e1; t += 64 * 8) {   // 8 entries per lane in flight: a 1025-entry row = 3 trips
         int jj[8];
@@ -248,6 +247,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     constexpr int oOWN = oPUB + 2 * RES_WAVES;        // 8 scalars of each wave's rows
     int* fail = reinterpret_cast<int*>(sm + oOWN + 8 * RES_WAVES);
     long long* dbg_acc = reinterpret_cast<long long*>(sm + oOWN + 8 * RES_WAVES + 1);   // 8 words
+    // entry ranges of this wave's rows of P' (level-2 row) and P (F row, C row): read once, a walk
+    // then starts with its entries instead of a dependent trip for the row pointers
+    int* rowp = reinterpret_cast<int*>(sm + oOWN + 8 * RES_WAVES + 12);                  // 6 ints per wave
     double* red = sm + oRED;
 
     // ---- rows of this wave ------------------------------------------------------------------
@@ -274,6 +276,12 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         sm[oOWN + 5 * RES_WAVES + w] = bvec[rC];
         sm[oOWN + 6 * RES_WAVES + w] = D.L2.diag[r2];
         sm[oOWN + 7 * RES_WAVES + w] = D.L2.dinv[r2];
+        rowp[6 * w + 0] = D.Pt2.rp[r2];
+        rowp[6 * w + 1] = v2 ? D.Pt2.rp[r2 + 1] - D.wident : D.Pt2.rp[r2];
+        rowp[6 * w + 2] = D.P2.rp[rF];
+        rowp[6 * w + 3] = vF ? D.P2.rp[rF + 1] : D.P2.rp[rF];
+        rowp[6 * w + 4] = D.P2.rp[rC];
+        rowp[6 * w + 5] = vC ? D.P2.rp[rC + 1] : D.P2.rp[rC];
     }
 #define dgF sm[oOWN + 0 * RES_WAVES + w]
 #define dvF sm[oOWN + 1 * RES_WAVES + w]
@@ -300,6 +308,16 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // trips to L2 per visit.
     const bool tail1 = Nt == 1 && N2 <= RES_NMAX / 2;
     constexpr int oP3C = oRR2 + RES_NMAX / 2;
+    // First sweep of a visit (zero start): e = D^-1 (r - (A 1) c) needs no matrix row, so every
+    // workgroup forms ALL its entries itself from the r it has just received -- no hand-off.  The
+    // inverse diagonals of the F rows of level 1 and of level 2 sit in the unused upper halves of
+    // the R2 / E2 slots (same condition as tail1's column: at most RES_NMAX / 2 rows).
+    const bool lfirst = D.localfirst && D.nu >= 1 && N2 <= RES_NMAX / 2 && nf <= RES_NMAX / 2;
+    constexpr int oDV1 = oR2 + RES_NMAX / 2, oDV2 = oE2 + RES_NMAX / 2;
+    if (lfirst) {
+        for (int j = tid; j < nf; j += BT) sm[oDV1 + j] = D.L1.dinv[j];
+        for (int j = tid; j < N2; j += BT) sm[oDV2 + j] = D.L2.dinv[j];
+    }
     double h33 = 0.0;
     if (tail1) {
         for (int j = tid; j < N2; j += BT) {
@@ -406,6 +424,13 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         RES_HANDOFF(4, N1, loF, hiF - loF, loC, hiC - loC,
                     { sm[oR1 + j] = v; sm[oE1 + j] = 0.0; p0 += v * v; p1 += v; }, {}, 2, nrm2, sumr);
         c1 = nsp ? sumr / xx1 : 0.0;
+        if (lfirst) {   // first half (F rows) of the first pre-smoothing sweep: half1(true, true, true)
+            for (int j = tid; j < nf; j += BT) {
+                const double g_i = sm[oR1 + j] - sm[oAX1 + j] * c1;
+                sm[oE1 + j] = sm[oDV1 + j] * g_i;
+            }
+            __syncthreads();
+        }
         return sqrt(nrm2);
     };
 
@@ -450,7 +475,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         }
     };
     auto sweep1 = [&](bool post, bool ezero) {
-        half1(!post, true, ezero);    // pre: F rows first (Rk{1}); post: C rows first (Rk{1}')
+        if (!(lfirst && ezero && !post)) half1(!post, true, ezero);   // else: done by top()    // pre: F rows first (Rk{1}); post: C rows first (Rk{1}')
         half1(post, false, ezero);
     };
 
@@ -534,7 +559,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
             if (tid == 0) sm[oR3] = res_red8(red);
         } else {
             for (int i = w; i < Nt; i += RES_WAVES) {
-                const double s = res_csr_rowdot(D.Pt3, i, true, lane, sm, oRR2);
+                const double s = res_csr_rowdot(D.Pt3, D.Pt3.rp[i], D.Pt3.rp[i + 1], lane, sm, oRR2);
                 if (lane == 0) sm[oR3 + i] = s;
             }
         }
@@ -591,7 +616,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // one visit of level 2 and everything below it
     auto visit2 = [&](bool keep) {
         const int nu = D.nu;
-        for (int s = 0; s < nu; ++s) sweep2(!keep && s == 0);
+        for (int s = (lfirst && !keep) ? 1 : 0; s < nu; ++s) sweep2(!keep && s == 0);
         // rr = r - A e                                                           MG_Vcycle.m:27
         {
             const double s = wave_sum(res_rowdot<KE2, 8 * oE2>(c2, a2, smb)) + dg2 * sm[oE2 + r2];
@@ -620,7 +645,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         {   // r_2 = P' rr ; E2 := 0 ; c for the zero start
             if (dbg) dbg_acc[6] -= __builtin_amdgcn_s_memtime();
             // row r2 of P' is [W(:,r2)' , 1 at nf + r2]; rowC == nf + row2 (level 2 = the C nodes)
-            const double s = res_csr_rowdot(D.Pt2, r2, v2, lane, sm, oRR1, D.wident) +
+            const double s = res_csr_rowdot(D.Pt2, rowp[6 * w + 0], rowp[6 * w + 1], lane, sm, oRR1) +
                              (D.wident ? sm[oRR1 + rC] : 0.0);
             if (dbg) dbg_acc[6] += __builtin_amdgcn_s_memtime();
             if (lane == 0) sm[oPUB + w] = s;
@@ -628,13 +653,31 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
             RES_HANDOFF(4, N2, lo2, hi2 - lo2, 0, 0, { sm[oR2 + j] = v; sm[oE2 + j] = 0.0; p0 += v; }, {},
                         (nsp ? 1 : 0), sumr, dum1);
             c2s = nsp ? sumr / xx2 : 0.0;
+            if (lfirst) {   // sweep2(true) of the first visit, same thread-to-entry map and sums
+                const double cc = c2s;
+                double p0 = 0.0;
+                for (int j = tid; j < N2; j += BT) {
+                    const double g_i = sm[oR2 + j] - sm[oAX2 + j] * cc;
+                    const double en = sm[oDV2 + j] * g_i + cc;
+                    sm[oE2 + j] = en;
+                    p0 += sm[oR2 + j] - sm[oAX2 + j] * en;
+                }
+                if (nsp) {
+                    p0 = wave_sum(p0);
+                    if (lane == 0) red[w] = p0;
+                }
+                __syncthreads();
+                if (nsp) c2s = res_red8(red) / xx2;
+                __syncthreads();   // red is rewritten by the next hand-off
+            }
         }
         for (int leg = 0; leg < (D.wcycle ? 2 : 1); ++leg) visit2(leg == 1);      // MG_Wcycle.m:28-30
         {   // e_1 += P e_2                                                        MG_Vcycle.m:31
             if (dbg) dbg_acc[6] -= __builtin_amdgcn_s_memtime();
             // F rows: W(rowF,:) against E2 (A's columns nf + i are level-2 indices i); C rows: identity
-            const double sF = res_csr_rowdot(D.P2, rF, vF, lane, sm, oE2);
-            const double sC = D.wident ? sm[oE2 + r2] : res_csr_rowdot(D.P2, rC, vC, lane, sm, oE2);
+            const double sF = res_csr_rowdot(D.P2, rowp[6 * w + 2], rowp[6 * w + 3], lane, sm, oE2);
+            const double sC = D.wident ? sm[oE2 + r2]
+                                       : res_csr_rowdot(D.P2, rowp[6 * w + 4], rowp[6 * w + 5], lane, sm, oE2);
             if (dbg) dbg_acc[6] += __builtin_amdgcn_s_memtime();
             if (lane == 0) {
                 sm[oPUB + w] = sm[oE1 + rF] + sF;
