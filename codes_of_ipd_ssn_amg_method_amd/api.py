@@ -29,7 +29,7 @@ __all__ = [
     "Class_AMG", "AMGHierarchy", "MG_Vcycle", "MG_Wcycle", "PCG", "components", "Hybrid_AMG",
     "AMG4POT", "MatlabRand", "IpdError", "amg_options", "APDWorkspace", "warmup_class1",
     "warmup_class2", "APD_SsN_Class1", "APD_SsN_Class2", "twogrid_bigph", "twogrid", "Hybrid_twogrid",
-    "aug_PCG", "PCG4POT", "load_input", "sparse_multiply",
+    "aug_PCG", "PCG4POT", "load_input", "sparse_multiply", "spd_solve",
 ]
 
 
@@ -180,6 +180,24 @@ def sparse_multiply(A, B) -> sp.csc_matrix:
             if d:
                 lib.ipd_dmat_destroy(d)
     return csc_out_to_scipy(out)
+
+
+def spd_solve(A, B) -> np.ndarray:
+    """``X = A \\ B`` for sparse symmetric positive definite ``A`` and dense ``B`` -- the
+    reference's direct solves (``APD_SsN_Class1.m:148``, ``APD_SsN_Class2.m:155``,
+    ``AMG/transfer.m:58``), a blocked dense Cholesky on the device."""
+    a = CscIn(A)
+    B = np.asarray(B, dtype=np.float64)
+    one = B.ndim == 1
+    B2 = B.reshape(-1, 1) if one else B
+    n, nrhs = B2.shape
+    if n != a.struct.nrows:
+        raise ValueError("spd_solve: B must have as many rows as A")
+    Bf = np.asfortranarray(B2)
+    X = np.empty_like(Bf, order="F")
+    check(lib.ipd_spd_solve(_h(), a.ref(), Bf.ctypes.data_as(POINTER(c_double)), c_int64(nrhs),
+                            X.ctypes.data_as(POINTER(c_double))))
+    return X[:, 0].copy() if one else np.ascontiguousarray(X)
 
 
 def transfer(A, amg_options: dict, level: int = 2, rng: MatlabRand | None = None):

@@ -125,6 +125,18 @@ void aug_pcg_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
 void pcg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p, const double* q,
                  int m, int n, double bk1, double tk, const double* z, const uint8_t* s,
                  const double* phi, double tol, long long maxit, double* zeta, HybridOut* out);
+// Class 2, inner_solver = 1 / 2: direct solve resp. PCG on the bordered Jacobian itself
+// (APD_SsN_Class2.m:152-161)
+void direct_pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p, const double* q,
+                    int m, int n, double bk1, double tk, const double* z, const uint8_t* s,
+                    const double* phi, double* zeta);
+void pcg_pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p, const double* q,
+                 int m, int n, double bk1, double tk, const double* z, const uint8_t* s,
+                 const double* phi, double tol, long long maxit, double* zeta, HybridOut* out);
+// ipd_dense.hip: dense Cholesky (MATLAB's `\` on the cold paths' SPD systems)
+void dense_chol_factor(ipd_ctx* ctx, double* A, int n, int ld);              // lower triangle, in place
+void dense_chol_solve(ipd_ctx* ctx, const double* L, int n, int ld, double* B, int nrhs, int ldb);
+void spd_solve_dev(ipd_ctx* ctx, const Csr& A, const double* b, double* x);  // x = A \ b
 // Jk = bk1*I + (T + H0)/tk (APD_SsN_Class1.m:151, inner_solver = 2)
 void build_jk(ipd_ctx* ctx, Arena& dst, const Csr& H0, const double* tdiag, double bk1, double tk,
               Csr* J);

@@ -1283,7 +1283,21 @@ void apd_iterate(ipd_apd* h, const ipd_apd_opts& o, const AmgOpts& amg, ipd_rng*
                 h->have_prev = false;
                 h->step.prev.clear();
             }
-            if (solver == 2) {                                     // :149-152  PCG(Jk,-Fk_old)
+            if (solver == 1) {                                     // :146-148  zeta = Jk \ (-Fk_old)
+                if (c2) {                                          // Class2 :152-156
+                    direct_pot_dev(ctx, H0, h->tmask, h->p, h->q, h->m, h->n, bk1, tk, h->negF, h->s,
+                                   h->phi, h->zeta);
+                } else {
+                    Csr Jk;
+                    build_jk(ctx, *ctx->scratch, H0, nullptr, bk1, tk, &Jk);
+                    spd_solve_dev(ctx, Jk, h->negF, h->zeta);
+                }
+                ho.itamg = 1;                                      // itpcg = 1; respcg = 0; info = [0,0]
+                ho.resamg = 0.0;
+            } else if (solver == 2 && c2) {                        // Class2 :157-161  PCG on the bordered Jk
+                pcg_pot_dev(ctx, H0, h->tmask, h->p, h->q, h->m, h->n, bk1, tk, h->negF, h->s, h->phi,
+                            o.pcg_retol, o.pcg_maxit, h->zeta, &ho);
+            } else if (solver == 2) {                              // :149-152  PCG(Jk,-Fk_old)
                 Csr Jk;
                 build_jk(ctx, *ctx->scratch, H0, nullptr, bk1, tk, &Jk);
                 long long it2 = 0;
@@ -1731,10 +1745,8 @@ extern "C" int ipd_apd_run(ipd_apd* h, const ipd_apd_opts* o, const ipd_amg_opts
         IPD_REQUIRE(oo.maxit > 0 && oo.ssn_it > 0 && oo.ll_max >= 0 && oo.delta > 0.0 &&
                         oo.delta < 1.0,
                     IPD_E_ARG, "bad driver options");
-        IPD_REQUIRE(oo.inner_solver >= 2 && oo.inner_solver <= 5, IPD_E_UNSUPPORTED,
-                    "inner_solver must be 2, 3, 4 or 5 (1, the direct solve, is not built)");
-        IPD_REQUIRE(!(oo.inner_solver == 2 && h->cls == 2), IPD_E_UNSUPPORTED,
-                    "inner_solver = 2 (PCG on the bordered system) is not built for class 2");
+        IPD_REQUIRE(oo.inner_solver >= 1 && oo.inner_solver <= 5, IPD_E_ARG,
+                    "inner_solver must be 1 (direct), 2 (PCG), 3 (aug_PCG / PCG4POT), 4 (AMG) or 5 (two-grid)");
         const AmgOpts ao = oo.inner_solver == 5 ? amg_fill_twogrid_defaults(amg) : amg_fill_defaults(amg);
         h->ctx->set_device();
         ensure_kkt(h);

@@ -1108,6 +1108,89 @@ void build_jk(ipd_ctx* ctx, Arena& dst, const Csr& H0, const double* tdiag, doub
 }
 
 // ---------------------------------------------------------------------------
+// Class 2, inner_solver = 1 and 2: the bordered Jacobian itself      (APD_SsN_Class2.m:152-161)
+//   J = bk1*speye(M+1) + (cT + cH0)/tk,  cT = [T 0; 0 0],  cH0 = [H0 ss; ss' phi'*(s.*phi)],
+//   ss = Ax(s.*phi)
+// assembled densely ((M+1)^2 doubles: cold paths, bounded by the 2 GiB scratch limit)
+// ---------------------------------------------------------------------------
+__global__ void k_border(int M, int ld, const double* __restrict__ ss, double itk /* tk */, double corner,
+                         double* __restrict__ D) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= M; i += gridDim.x * blockDim.x) {
+        if (i < M) {
+            const double v = ss[i] / itk;            // (0 + ss)/tk
+            D[(size_t)i * ld + M] = v;
+            D[(size_t)M * ld + i] = v;
+        } else {
+            D[(size_t)M * ld + M] = corner;
+        }
+    }
+}
+
+static double* pot_jacobian_dense(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p,
+                                  const double* q, int m, int n, double bk1, double tk,
+                                  const uint8_t* s, const double* phi) {
+    const int M = m + n, N = M + 1;
+    const size_t mn = (size_t)m * n;
+    Arena& tmp = *ctx->scratch;
+    IPD_REQUIRE((size_t)N * N * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
+                "inner_solver 1/2 (class 2): dense Jacobian above 2 GiB");
+    double* sphi = tmp.alloc<double>(mn);
+    const int nb = (int)std::max<size_t>(1, std::min<size_t>((mn + 255) / 256, 1024));
+    double* part = tmp.alloc<double>((size_t)nb);
+    hipLaunchKernelGGL(k_mask_mul, dim3(nb), dim3(256), 0, ctx->stream, mn, s, phi, sphi, part);
+    IPD_KERNEL_CHECK();
+    const double pssp = host_sum(ctx, part, nb);                          // phi'*(s.*phi)
+    double* ss = tmp.alloc<double>((size_t)M);
+    kkt_ax(ctx, sphi, p, q, m, n, ss);                                    // ss = Ax(s.*phi)
+    Csr Jk;
+    build_jk(ctx, tmp, H0, tdiag, bk1, tk, &Jk);                          // bk1*I + (T + H0)/tk
+    double* D = tmp.alloc<double>((size_t)N * N);
+    IPD_HIP(hipMemsetAsync(D, 0, sizeof(double) * (size_t)N * N, ctx->stream));
+    csr_expand_dense(ctx, Jk, D, N);
+    hipLaunchKernelGGL(k_border, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, M, N, (const double*)ss,
+                       tk, bk1 + pssp / tk, D);
+    IPD_KERNEL_CHECK();
+    return D;
+}
+
+// zeta = J \ z                                                      (APD_SsN_Class2.m:155)
+void direct_pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p, const double* q,
+                    int m, int n, double bk1, double tk, const double* z, const uint8_t* s,
+                    const double* phi, double* zeta) {
+    const int N = m + n + 1;
+    double* D = pot_jacobian_dense(ctx, H0, tdiag, p, q, m, n, bk1, tk, s, phi);
+    dense_chol_factor(ctx, D, N, N);
+    if (zeta != z)
+        IPD_HIP(hipMemcpyAsync(zeta, z, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, ctx->stream));
+    dense_chol_solve(ctx, D, N, N, zeta, 1, 1);
+}
+
+// [zeta,itpcg,respcg] = PCG(J,z,pcg_options)                         (APD_SsN_Class2.m:161)
+void pcg_pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double* p, const double* q,
+                 int m, int n, double bk1, double tk, const double* z, const uint8_t* s,
+                 const double* phi, double tol, long long maxit, double* zeta, HybridOut* out) {
+    const int N = m + n + 1;
+    Arena& tmp = *ctx->scratch;
+    double* D = pot_jacobian_dense(ctx, H0, tdiag, p, q, m, n, bk1, tk, s, phi);
+    Csr J;
+    J.nr = J.nc = N;
+    int* cnt = tmp.alloc<int>((size_t)N + 1);
+    dense_rowcount(ctx, N, N, N, D, cnt);
+    J.rp = tmp.alloc<int>((size_t)N + 1);
+    J.nnz = exclusive_scan_total(ctx, cnt, J.rp, N);
+    J.ci = tmp.alloc<int>((size_t)J.nnz);
+    J.va = tmp.alloc<double>((size_t)J.nnz);
+    dense_compact(ctx, N, N, N, D, J);
+    long long it = 0;
+    double res = 0.0;
+    pcg_dev(ctx, J, z, nullptr, tol, maxit, 2, zeta, &it, &res, nullptr);
+    out->itamg = (int)std::min<long long>(it, 2147483647LL);
+    out->resamg = res;
+    out->num_comp = 0;
+    out->it_num = 0;
+}
+
+// ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
 extern "C" int ipd_components(ipd_ctx* ctx, const ipd_csc* A, int64_t* blocks, int64_t* sizes,

@@ -242,6 +242,7 @@ void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n);
 void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C);
 void csr_expand_dense(ipd_ctx* ctx, const Csr& A, double* dense, int ld);  // dense pre-zeroed
 void dense_rowcount(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, int* rowcnt);
+void dense_compact(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, const Csr& out);
 void csr_copy(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out);
 void csr_drop_zeros(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out);  // ipd_kkt.hip
 

@@ -671,6 +671,37 @@ __global__ __launch_bounds__(256) void k_dense_compact2(int nr, int nc,
     }
 }
 
+// ideal interpolation (transfer.m:57-58): Aff and Afc as dense row-major arrays, one wave per row
+__global__ __launch_bounds__(256) void k_ideal_split(int N, int Nf, int Nc, const int* __restrict__ rp,
+                                                     const int* __restrict__ ci,
+                                                     const double* __restrict__ va,
+                                                     const uint8_t* __restrict__ isF,
+                                                     const int* __restrict__ fidx,
+                                                     const int* __restrict__ cidx,
+                                                     double* __restrict__ Aff, double* __restrict__ Afc) {
+    WAVE_ROWS(i, N) {
+        if (!isF[i]) continue;
+        const size_t r = (size_t)fidx[i];
+        for (int t = rp[i] + lane; t < rp[i + 1]; t += 64) {
+            const int j = ci[t];
+            if (isF[j])
+                Aff[r * Nf + fidx[j]] = va[t];
+            else
+                Afc[r * Nc + cidx[j]] = va[t];
+        }
+    }
+}
+// rows of Pro in the original ordering: F rows = -(Aff \ Afc), C rows = identity (Pro(p,:) = P, :63)
+__global__ void k_ideal_rows(int N, int Nc, const uint8_t* __restrict__ isF, const int* __restrict__ fidx,
+                             const int* __restrict__ cidx, const double* __restrict__ X,
+                             double* __restrict__ dense) {
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < (size_t)N * Nc;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / Nc), c = (int)(e % Nc);
+        dense[e] = isF[i] ? -X[(size_t)fidx[i] * Nc + c] : (c == cidx[i] ? 1.0 : 0.0);
+    }
+}
+
 void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int level,
                   ipd_rng* rng, Csr* Ac, Csr* Pout, Csr* Ptout, uint8_t* cmask, Csr* T1out) {
     IPD_REQUIRE(A.nr == A.nc, IPD_E_ARG, "transfer: A must be square");
@@ -700,8 +731,6 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
                            o.isnsp, A.rp, A.ci, A.va, P.rp, P.ci, P.va, cmask);
         IPD_KERNEL_CHECK();
     } else {                                                                 // transfer.m:41-63
-        IPD_REQUIRE(o.inter < 2, IPD_E_UNSUPPORTED,
-                    "transfer: ideal interpolation (inter=2) is a cold path and not built");
         uint8_t* isC = cmask;
         uint8_t* isF = tmp.alloc<uint8_t>((size_t)N);
         uint8_t* strong = tmp.alloc<uint8_t>((size_t)std::max(A.nnz, 1));
@@ -737,7 +766,34 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         // long rows: the product form (see k_w_split_count); short rows: one kernel
         bool split = (double)A.nnz / std::max(N, 1) >= 64.0;
         if (const char* e = getenv("IPD_INTERP")) split = !strcmp(e, "split");
-        if (split) {
+        if (o.inter >= 2) {                                                  // :57-58  W = -Aff \ Afc
+            // MATLAB solves with the sparse Aff (CHOLMOD); here a dense Cholesky of the F-F block
+            // (a principal block of the SPD level matrix) with the Nc columns of Afc as right-hand
+            // sides (csrc/ipd_dense.hip).  Cold path.
+            const int Nf = N - Nc;
+            IPD_REQUIRE((size_t)Nf * Nf * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
+                        "transfer: dense Aff of the ideal interpolation above 2 GiB");
+            int* fflag = tmp.alloc<int>((size_t)N + 1);
+            int* fidx = tmp.alloc<int>((size_t)N + 1);
+            hipLaunchKernelGGL(k_u8_to_flag, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N, isF, fflag);
+            IPD_KERNEL_CHECK();
+            exclusive_scan_i32(ctx, fflag, fidx, N);
+            double* Aff = tmp.alloc<double>((size_t)std::max(Nf, 1) * std::max(Nf, 1));
+            double* Afc = tmp.alloc<double>((size_t)std::max(Nf, 1) * Nc);
+            IPD_HIP(hipMemsetAsync(Aff, 0, sizeof(double) * (size_t)Nf * Nf, ctx->stream));
+            IPD_HIP(hipMemsetAsync(Afc, 0, sizeof(double) * (size_t)Nf * Nc, ctx->stream));
+            if (Nf > 0) {
+                hipLaunchKernelGGL(k_ideal_split, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, Nf, Nc,
+                                   A.rp, A.ci, A.va, isF, fidx, cidx, Aff, Afc);
+                IPD_KERNEL_CHECK();
+                dense_chol_factor(ctx, Aff, Nf, Nf);
+                dense_chol_solve(ctx, Aff, Nf, Nf, Afc, Nc, Nc);
+            }
+            hipLaunchKernelGGL(k_ideal_rows, dim3((int)std::min<size_t>((dense_elems + 255) / 256, 8192)),
+                               dim3(256), 0, ctx->stream, N, Nc, isF, fidx, cidx, (const double*)Afc, dense);
+            IPD_KERNEL_CHECK();
+            dense_rowcount(ctx, N, Nc, Nc, dense, rowcnt);
+        } else if (split) {
             int* cnt1 = tmp.alloc<int>((size_t)N + 1);
             int* cntx = tmp.alloc<int>((size_t)N + 1);
             hipLaunchKernelGGL(k_w_split_count, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp,

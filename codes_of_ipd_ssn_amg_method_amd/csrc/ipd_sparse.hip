@@ -663,6 +663,15 @@ void dense_rowcount(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, i
     IPD_KERNEL_CHECK();
 }
 
+// dense rows -> the CSR arrays of `out` (row pointers from dense_rowcount + scan), exact zeros dropped
+void dense_compact(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, const Csr& out) {
+    if (nr == 0 || out.nnz == 0) return;
+    hipLaunchKernelGGL(k_dense_compact, dim3(std::max(1, std::min(cdiv(nr, 4), 4096))), dim3(256), 0,
+                       ctx->stream, nr, nc, ld, dense, (const unsigned long long*)nullptr, (const int*)out.rp,
+                       out.ci, out.va);
+    IPD_KERNEL_CHECK();
+}
+
 // ---------------------------------------------------------------------------
 // C ABI: device matrices
 // ---------------------------------------------------------------------------

@@ -263,6 +263,13 @@ int ipd_hybrid_amg_dev(ipd_ctx*, const ipd_dmat* H0, const double* t_dev, const 
                        const double* z_dev, const ipd_amg_opts* o, ipd_rng* rng,
                        double* zeta_dev, int32_t* itamg, double* resamg, int64_t info[2]);
 
+/* X = A \ B, MATLAB's mldivide for a sparse symmetric positive definite A (CSC, both triangles)
+ * and a dense column-major B (n x nrhs): the reference's cold-path direct solves
+ * `zeta = Jk \ (-Fk_old)` (Class1/APD_SsN_Class1.m:148, Class2/APD_SsN_Class2.m:155) and
+ * `W = -Aff \ Afc` (AMG/transfer.m:58).  MATLAB uses CHOLMOD (closed source); this is a blocked
+ * dense Cholesky on the device, n <= 16384.  IPD_E_NUMERIC when A is not positive definite.     */
+int ipd_spd_solve(ipd_ctx*, const ipd_csc* A, const double* B, int64_t nrhs, double* X);
+
 /* ---- L5: APD / semismooth-Newton drivers and A-ADMM warm starts ----------- */
 /* SURVEY.md section 8 rows f1/f2.  The reference's drivers are MATLAB *scripts*
  * (Class1/APD_SsN_Class1.m, Class2/APD_SsN_Class2.m): their boundary is the
@@ -296,7 +303,7 @@ typedef struct ipd_apd_opts {
     int32_t ll_max;       /* 500                                                       */
     int32_t prob;         /* class 1 only: `prob` of :19-23; 3 selects the merit of :186 */
     int32_t inner_solver; /* :66-71: 4 AMG (default), 5 two-grid, 3 aug_PCG / PCG4POT,
-                             2 plain PCG (class 1 only); 1 (direct) is not built         */
+                             2 plain PCG on Jk, 1 direct solve `Jk \ (-Fk_old)`           */
     double pcg_retol;     /* pcg_options of :81,84: 1e-11                               */
     int64_t pcg_maxit;    /*                        1e4                                 */
 } ipd_apd_opts;

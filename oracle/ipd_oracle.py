@@ -352,7 +352,11 @@ def transfer(A: sp.csr_matrix, opts: dict, J: int, rng: np.random.RandomState):
             # so W = W1 + 0.5*W2 regardless of `inter`.
             W = _csr(W1 + 0.5 * W2) if Nf > 0 else _csr(W1 + inter * W2)
         else:                                                             # :57-58 ideal interp.
-            W = _csr(spla.spsolve(sp.csc_matrix(-Aff), sp.csc_matrix(Afc)))
+            W = spla.spsolve(sp.csc_matrix(-Aff), sp.csc_matrix(Afc))
+            if not sp.issparse(W):                 # one coarse node: SciPy returns a 1-D array
+                W = np.asarray(W).reshape(Nf, Nc)
+            W = _csr(W)
+            W.eliminate_zeros()                    # MATLAB never stores explicit zeros
         if isnsp == 1:                                                    # :60-62
             rs = W @ np.ones(Nc)
             W = _row_scale_div(W, rs)

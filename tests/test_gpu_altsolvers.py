@@ -122,7 +122,7 @@ def test_pcg4pot_matches_oracle():
     assert np.linalg.norm(z - zr) <= 1e-7 * np.linalg.norm(zr)
 
 
-@pytest.mark.parametrize("solver", [2, 3, 5])
+@pytest.mark.parametrize("solver", [1, 2, 3, 5])
 def test_class1_driver_with_alternate_inner_solvers(solver):
     """All inner solvers solve the same Newton systems to 1e-11, so the APD histories agree."""
     from tests.test_gpu_driver import problem, ws_of
@@ -140,7 +140,7 @@ def test_class1_driver_with_alternate_inner_solvers(solver):
     ws.close()
 
 
-@pytest.mark.parametrize("solver", [3, 5])
+@pytest.mark.parametrize("solver", [1, 2, 3, 5])
 def test_class2_driver_with_alternate_inner_solvers(solver):
     from tests.test_gpu_driver import problem, ws_of
     pr = problem(2, 26, 30, seed=1)
@@ -155,15 +155,69 @@ def test_class2_driver_with_alternate_inner_solvers(solver):
     ws.close()
 
 
-def test_unsupported_inner_solvers_fail_loudly():
+def test_out_of_range_inner_solver_fails_loudly():
     from tests.test_gpu_driver import problem, ws_of
     pr = problem(2, 8, 8, seed=1)
     ws = ws_of(2, pr)
-    with pytest.raises(ipd().IpdError):
-        ws.run(OPTS, ipd().MatlabRand(5489), inner_solver=2)      # bordered PCG: not built
-    with pytest.raises(ipd().IpdError):
-        ws.run(OPTS, ipd().MatlabRand(5489), inner_solver=1)      # direct solve: not built
+    for bad in (0, 6):
+        with pytest.raises(ipd().IpdError):
+            ws.run(OPTS, ipd().MatlabRand(5489), inner_solver=bad)
     ws.close()
+
+
+@pytest.mark.parametrize("cls", [1, 2])
+def test_direct_inner_solver_matches_the_oracle_step_by_step(cls):
+    """inner_solver = 1 (`zeta = Jk \\ (-Fk_old)`, APD_SsN_Class1.m:146-148, Class2 :152-156) against
+    the restated driver with SciPy's sparse direct solve: same iteration count, Newton-step counts
+    and histories (1e-8: two exact solves of the same systems differ by rounding only)."""
+    from tests.test_gpu_driver import problem, ws_of
+    pr = problem(cls, 40, 33, seed=2)
+    if cls == 1:
+        start = D.warmup_class1(pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], np.inf, 100)
+        ref = D.apd_ssn_class1(pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], np.inf, inner="direct",
+                               start=start)
+    else:
+        start = D.warmup_class2(pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], pr["mu"], pr["phi"], 100)
+        ref = D.apd_ssn_class2(pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], pr["mu"], pr["phi"],
+                               inner="direct", start=start)
+    ws = ws_of(cls, pr)
+    ws.set_state(start[0], start[0], start[1], 1.0)
+    out = ws.run(OPTS, ipd().MatlabRand(5489), inner_solver=1)
+    hist = ws.history()
+    recs = ws.records()
+    ws.close()
+    assert out["converged"] and out["k"] == ref["k"]
+    assert abs(out["fval"] - ref["fval"]) <= 1e-9 * (1 + abs(ref["fval"]))
+    assert all(r["itamg"] == 1 and r["resamg"] == 0.0 and r["info0"] == 0 for r in recs)   # :148
+    for key in ("KKT_xk", "KKT_lk"):
+        a, b = hist[key], np.asarray(ref[key])
+        assert a.shape == b.shape and np.all(np.abs(a - b) <= 1e-8 * (1 + np.abs(b))), key
+    ssn, ssn_ref = hist["SsN_itnum"].astype(int), np.asarray(ref["SsN_itnum"]).astype(int)
+    half = len(ssn_ref) // 2
+    assert np.array_equal(ssn[:half], ssn_ref[:half]) and np.abs(ssn - ssn_ref).max() <= 1
+
+
+@pytest.mark.parametrize("n,nrhs", [(1, 1), (37, 1), (64, 3), (65, 70), (200, 1), (333, 129)])
+def test_spd_mldivide_matches_numpy(n, nrhs):
+    """`A \\ B` for sparse symmetric positive definite A (ipd_spd_solve: blocked dense Cholesky on
+    the device) against numpy; ragged sizes around the 64-row block."""
+    import scipy.sparse as sp
+    rs = np.random.RandomState(n + nrhs)
+    G = sp.random(n, n, density=min(1.0, 6.0 / n), random_state=rs, format="csr")
+    A = (G @ G.T + sp.identity(n) * (0.5 + rs.random_sample())).tocsc()
+    B = rs.standard_normal((n, nrhs))
+    X = ipd().spd_solve(A, B)
+    ref = np.linalg.solve(A.toarray(), B)
+    assert X.shape == ref.shape
+    assert np.linalg.norm(X - ref) <= 1e-11 * np.linalg.cond(A.toarray()) * np.linalg.norm(ref)
+    assert np.linalg.norm(A @ X - B) <= 1e-12 * (np.linalg.norm(A.toarray()) * np.linalg.norm(X) + np.linalg.norm(B))
+
+
+def test_spd_mldivide_rejects_an_indefinite_matrix():
+    import scipy.sparse as sp
+    A = sp.csc_matrix(np.array([[1.0, 2.0], [2.0, 1.0]]))
+    with pytest.raises(ipd().IpdError):
+        ipd().spd_solve(A, np.ones((2, 1)))
 
 
 def test_amg4pot_hierarchy_reuse_is_within_solver_tolerance(monkeypatch):

@@ -122,6 +122,43 @@ def test_transfer_standalone(ipd):
     assert csc_equal(gAc, Ac) and csc_equal(gPro, Pro) and np.array_equal(gC, info["isC"])
 
 
+@pytest.mark.parametrize("isnsp", [0, 1])
+def test_transfer_ideal_interpolation(ipd, isnsp):
+    """`inter = 2`: W = -Aff \\ Afc (AMG/transfer.m:57-58).  MATLAB and the oracle (SuperLU) solve
+    with sparse factorisations, the device with a dense Cholesky of Aff: the C/F split is the same
+    bits (it does not depend on `inter`), Pro and Ac agree to rounding, A_ff*W + A_fc = 0."""
+    A = PR.random_sym_graph_laplacian(260, deg=3, seed=7) + sp.identity(260) * 0.05
+    o = O.amg_options_class1("v"); o.update(bigph=0, isnsp=isnsp, inter=2)
+    Ac, Pro, info = O.transfer(A, o, 2, O.matlab_rng())
+    gAc, gPro, gC = ipd.transfer(A, o, 2, ipd.MatlabRand())
+    assert np.array_equal(gC, info["isC"])
+    assert gPro.shape == Pro.shape and gAc.shape == Ac.shape
+    assert abs(gPro - Pro).max() <= 1e-11 * abs(Pro).max()
+    assert abs(gAc - Ac).max() <= 1e-10 * abs(Ac).max()
+    if isnsp == 0:      # the defining equation of the ideal interpolation, on the device result
+        isC = info["isC"]
+        F, C = np.flatnonzero(~isC), np.flatnonzero(isC)
+        Ad = A.toarray()
+        W = gPro.toarray()[F, :]
+        assert np.abs(Ad[np.ix_(F, F)] @ W + Ad[np.ix_(F, C)]).max() <= 1e-12 * np.abs(Ad).max() * max(1.0, np.abs(W).max())
+    else:
+        assert np.allclose(gPro.toarray().sum(axis=1), 1.0, atol=1e-12)
+
+
+def test_class_amg_with_ideal_interpolation(ipd):
+    """Class_AMG with inter = 2 on the non-bigraph path: same level sizes as the oracle, same
+    iteration count (+-1), residual history to 1e-8."""
+    A = PR.random_sym_graph_laplacian(400, deg=4, seed=3) + sp.identity(400) * 0.02
+    b = np.random.RandomState(1).standard_normal(400)
+    o = dict(retol=1e-10, bigph=0, maxit=40, theta=0.25, smoth=2, cycle="v", isnsp=0, inter=2)
+    xr, itr, rrr, relk, rhok = O.Class_AMG(A, b, dict(o, guess=None), O.matlab_rng())
+    x, it, rr, relkd, _ = ipd.Class_AMG(A, b, dict(o, guess=None), ipd.MatlabRand())
+    assert abs(it - itr) <= 1
+    k = min(len(relk), len(relkd))
+    assert np.all(np.abs(np.asarray(relkd[:k]) - np.asarray(relk[:k])) <= 1e-8 + 1e-5 * np.asarray(relk[:k]))
+    assert np.linalg.norm(A @ x - b) <= 1e-9 * np.linalg.norm(b)
+
+
 def test_setup_errors(ipd):
     A = PR.random_sym_graph_laplacian(50, seed=1)
     with pytest.raises(ipd.IpdError) as ei:
