@@ -317,7 +317,72 @@ struct PcgGenArgs {
     PcgArgs a;
     int nf;          // precd 5: size of the F block
     double* tmp;     // 2*N doubles
+    double* lva;     // precd 4: the incomplete Cholesky factor on H's pattern (nnz doubles; entries
+                     // above the diagonal unused), its diagonal in ldg (N doubles)
+    double* ldg;
 };
+
+// precd 4: P = ichol(H) with MATLAB's defaults -- IC(0): type 'nofill', no drop tolerance, no
+// diagonal compensation (PCG.m:44-46).  L has the pattern of tril(H) and
+//   L(i,k) = (H(i,k) - sum_{j<k} L(i,j) L(k,j)) / L(k,k),  L(i,i) = sqrt(H(i,i) - sum_{j<i} L(i,j)^2),
+// the sums running over the common pattern.  MATLAB's kernel is closed source, so the order of the
+// sums (here: ascending j) is this build's; a nonpositive pivot is MATLAB's error
+// "Encountered nonpositive pivot" (*fail = 1 + row).  Rows are sequential: one wave, the current
+// row scattered into the LDS array `wrow` (N doubles, all zero on entry and on exit).
+__device__ __forceinline__ void pcg_ichol0(const PcgGenArgs& g, double* wrow, int* fail) {
+    const PcgArgs& a = g.a;
+    const int lane = threadIdx.x, N = a.N;
+    for (int i = 0; i < N; ++i) {
+        const int b = a.rp[i], e = a.rp[i + 1];
+        double hii = 0.0;
+        bool has_diag = false;
+        for (int t = b; t < e; ++t) {            // entries of the row in ascending column order
+            const int k = a.ci[t];
+            if (k > i) break;
+            if (k == i) {
+                hii = a.va[t];
+                has_diag = true;
+                break;
+            }
+            double sdot = 0.0;
+            for (int u = a.rp[k] + lane; u < a.rp[k + 1]; u += 64) {
+                const int j = a.ci[u];
+                if (j < k) sdot += g.lva[u] * wrow[j];
+            }
+            sdot = wave_sum(sdot);
+            const double lik = (a.va[t] - sdot) / g.ldg[k];
+            if (lane == 0) {
+                g.lva[t] = lik;
+                wrow[k] = lik;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        double sq = 0.0;
+        for (int t = b + lane; t < e; t += 64) {
+            const int j = a.ci[t];
+            if (j < i) {
+                const double l = wrow[j];
+                sq += l * l;
+            }
+        }
+        sq = wave_sum(sq);
+        const double d = hii - sq;
+        if (!has_diag || !(d > 0.0)) {
+            if (lane == 0) *fail = 1 + i;
+            return;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int t = b + lane; t < e; t += 64) {   // leave wrow zero for the next row
+            const int j = a.ci[t];
+            if (j < i) wrow[j] = 0.0;
+            if (j == i) g.lva[t] = sqrt(d);
+        }
+        if (lane == 0) g.ldg[i] = sqrt(d);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 __device__ __forceinline__ void pcg_gen_prec(const PcgGenArgs& g, const double* r, double* w,
                                              double* sol /*LDS, N*/, double* red) {
@@ -345,6 +410,36 @@ __device__ __forceinline__ void pcg_gen_prec(const PcgGenArgs& g, const double* 
         }
         __syncthreads();
         for (int i = nf + tid; i < N; i += BT) w[i] = c * w[i];
+        __syncthreads();
+        return;
+    }
+    if (a.precd == 4) {   // p = P \ r ; p = P' \ p                                PCG.m:100-101
+        if (tid < 64) {
+            for (int i = 0; i < N; ++i) {   // forward, rows of L
+                double sdot = 0.0;
+                for (int t = a.rp[i] + tid; t < a.rp[i + 1]; t += 64) {
+                    const int j = a.ci[t];
+                    if (j < i) sdot += g.lva[t] * sol[j];
+                }
+                sdot = wave_sum(sdot);
+                if (tid == 0) sol[i] = (r[i] - sdot) / g.ldg[i];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            for (int i = N - 1; i >= 0; --i) {   // backward with L': row i of L is column i of L'
+                const double xi = sol[i] / g.ldg[i];
+                __builtin_amdgcn_wave_barrier();
+                for (int t = a.rp[i] + tid; t < a.rp[i + 1]; t += 64) {
+                    const int j = a.ci[t];
+                    if (j < i) sol[j] -= g.lva[t] * xi;
+                }
+                if (tid == 0) sol[i] = xi;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < N; i += BT) w[i] = sol[i];
         __syncthreads();
         return;
     }
@@ -405,6 +500,21 @@ __global__ __launch_bounds__(BT) void k_pcg_gen(const PcgGenArgs g) {
         a.d[row] = a.guess ? a.guess[row] : 0.0;
     }
     __syncthreads();
+    if (a.precd == 4) {                                                         // :44-46
+        __shared__ int ic_fail;
+        if (tid == 0) ic_fail = 0;
+        for (int i = tid; i < N; i += BT) sol[i] = 0.0;
+        __syncthreads();
+        if (tid < 64) pcg_ichol0(g, sol, &ic_fail);
+        __syncthreads();
+        if (ic_fail) {
+            if (tid == 0 && a.out) {
+                a.out[0] = -(double)ic_fail;   // nonpositive pivot at row ic_fail - 1
+                a.out[1] = NAN;
+            }
+            return;
+        }
+    }
     pcg_gen_prec(g, r, w, sol, red);                                            // :69
     double acc = 0.0;
     for (int row = tid; row < N; row += BT) {
@@ -565,10 +675,7 @@ void pcg_dev(ipd_ctx* ctx, const Csr& H, const double* e, const double* guess, d
              long long maxit, int precd, double* d, long long* it, double* res,
              double* resk_host, long long nf) {
     IPD_REQUIRE(H.nr == H.nc, IPD_E_ARG, "PCG: H must be square");
-    IPD_REQUIRE(precd != 4, IPD_E_UNSUPPORTED,
-                "PCG: precd 4 (MATLAB's ichol) is not built; use 1, 2, 3 or 5");
-    IPD_REQUIRE(precd == 1 || precd == 2 || precd == 3 || precd == 5, IPD_E_ARG,
-                "PCG: precd must be 1..5");
+    IPD_REQUIRE(precd >= 1 && precd <= 5, IPD_E_ARG, "PCG: precd must be 1..5");
     if (precd == 5)
         IPD_REQUIRE(nf > 0 && nf < H.nr, IPD_E_ARG,
                     "SSOR for bigraph requires pcg_options.nf!!!");              // PCG.m:64
@@ -589,21 +696,25 @@ void pcg_dev(ipd_ctx* ctx, const Csr& H, const double* e, const double* guess, d
     a.precd = precd;
     a.out = tmp.alloc<double>((size_t)(2 + nresk));
     a.nresk = nresk;
-    if (precd == 3 || precd == 5) {
-        IPD_REQUIRE(H.nr <= 7000, IPD_E_LIMIT, "PCG precd 3/5: at most 7000 rows (LDS-resident solve)");
+    if (precd == 3 || precd == 4 || precd == 5) {
+        IPD_REQUIRE(H.nr <= 7000, IPD_E_LIMIT, "PCG precd 3/4/5: at most 7000 rows (LDS-resident solve)");
         PcgGenArgs g;
         g.a = a;
         g.nf = (int)nf;
         g.tmp = tmp.alloc<double>(2 * (size_t)H.nr);
+        g.lva = precd == 4 ? tmp.alloc<double>((size_t)std::max(H.nnz, 1)) : nullptr;
+        g.ldg = precd == 4 ? tmp.alloc<double>((size_t)H.nr) : nullptr;
         IPD_OPTIN_LDS(ctx, k_pcg_gen, 60 * 1024);
         hipLaunchKernelGGL(k_pcg_gen, dim3(1), dim3(BT), sizeof(double) * (size_t)H.nr, ctx->stream, g);
     } else {
         hipLaunchKernelGGL(k_pcg, dim3(1), dim3(BT), 0, ctx->stream, a);
     }
     IPD_KERNEL_CHECK();
-    if (it || res || resk_host) {
+    if (it || res || resk_host || precd == 4) {
         double head[2];
         ctx->fetch(a.out, head, 2);
+        IPD_REQUIRE(!(head[0] < 0.0), IPD_E_NUMERIC,
+                    "PCG: ichol encountered a nonpositive pivot (PCG.m:46)");
         if (it) *it = (long long)head[0];
         if (res) *res = head[1];
         if (resk_host && head[0] > 0)

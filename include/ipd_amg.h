@@ -89,8 +89,8 @@ typedef struct ipd_amg_opts {
 typedef struct ipd_pcg_opts {
     double retol;   /* default 1e-11 */
     int64_t maxit;  /* default 10000 */
-    int32_t precd;  /* 1 none, 2 Jacobi, 3 SSOR (w = 1.5), 5 SSOR on the bigraph blocks;
-                       4 (MATLAB's ichol) -> IPD_E_UNSUPPORTED                     */
+    int32_t precd;  /* 1 none, 2 Jacobi, 3 SSOR (w = 1.5), 4 ichol(H) with MATLAB's defaults
+                       (IC(0), PCG.m:46), 5 SSOR on the bigraph blocks              */
     int64_t nf;     /* precd 5: size of the F block (pcg_options.nf, PCG.m:55)      */
 } ipd_pcg_opts;
 

@@ -453,10 +453,49 @@ def amg_setup(A: sp.csr_matrix, opts: dict, rng: np.random.RandomState,
     return h
 
 
+def ichol0(H):
+    """``ichol(H)`` with MATLAB's default options (``PCG.m:46``): zero-fill incomplete Cholesky,
+    ``type = 'nofill'``, no drop tolerance, ``michol = 'off'``, ``diagcomp = 0``, lower factor.
+    ``L`` has the pattern of ``tril(H)`` and
+    ``L(i,k) = (H(i,k) - sum_{j<k} L(i,j) L(k,j)) / L(k,k)``,
+    ``L(i,i) = sqrt(H(i,i) - sum_{j<i} L(i,j)^2)`` (sums over the common pattern, ascending j).
+    The algorithm is the published IC(0); MATLAB's implementation is closed source, so rounding
+    order is this restatement's.  Raises like MATLAB on a nonpositive pivot."""
+    Hl = sp.tril(_csr(H), 0, format="csr")
+    Hl.sort_indices()
+    N = Hl.shape[0]
+    rp, ci, va = Hl.indptr, Hl.indices, Hl.data.astype(float).copy()
+    ldg = np.zeros(N)
+    wrow = np.zeros(N)
+    for i in range(N):
+        b, e = rp[i], rp[i + 1]
+        if e == b or ci[e - 1] != i:
+            raise ValueError("Encountered nonpositive pivot.")
+        for t in range(b, e - 1):
+            k = ci[t]
+            kb, ke = rp[k], rp[k + 1] - 1            # row k without its diagonal
+            sdot = 0.0
+            for u in range(kb, ke):
+                sdot += va[u] * wrow[ci[u]]
+            va[t] = (va[t] - sdot) / ldg[k]
+            wrow[k] = va[t]
+        sq = 0.0
+        for t in range(b, e - 1):
+            sq += va[t] * va[t]
+        d = va[e - 1] - sq
+        if not d > 0.0:
+            raise ValueError("Encountered nonpositive pivot.")
+        ldg[i] = math.sqrt(d)
+        va[e - 1] = ldg[i]
+        wrow[ci[b:e - 1]] = 0.0
+    return sp.csr_matrix((va, ci.copy(), rp.copy()), shape=Hl.shape)
+
+
 def PCG(H, e, pcg_options: Optional[dict] = None):
     """``PCG.m:18-88`` (Shewchuk B3).  Preconditioners 1 (none), 2 (Jacobi),
-    3 (SSOR w=1.5) and 5 (bigraph SSOR) are restated; 4 (ichol) is a cold path
-    that is not restated.  Returns ``d, it, res, resk``."""
+    3 (SSOR w=1.5) and 5 (bigraph SSOR) are restated; 4 is ``ichol(H)`` with MATLAB's
+    defaults, i.e. IC(0) (``ichol0`` below; MATLAB's kernel is closed source: parity unpinned).
+    Returns ``d, it, res, resk``."""
     e = np.asarray(e, float)
     if pcg_options is None:
         pcg_options = dict(guess=np.zeros_like(e), retol=1e-11, maxit=1e4, precd=2)
@@ -505,8 +544,16 @@ def PCG(H, e, pcg_options: Optional[dict] = None):
             [[invV + w ** 2 * (invV @ U @ invT @ U.T @ invV), -w * (invV @ U @ invT)],
              [-w * (invT @ U.T @ invV), invT]], format="csr")
         prec = lambda r: Pm @ r
+    elif ii == 4:                                                         # PCG.m:44-50
+        if not sp.issparse(H):
+            raise ValueError("iC requires H is sparse!")
+        Lc = ichol0(H)
+        Lt = _csr(Lc.T)
+
+        def prec(r):                                                      # :100-101  P\r ; P'\p
+            return spla.spsolve_triangular(Lt, spla.spsolve_triangular(Lc, r, lower=True), lower=False)
     else:
-        raise NotImplementedError("precd=4 (ichol) is a cold path and not restated")
+        raise ValueError("precd must be 1..5")
 
     it = 0
     r = e - H @ d0                                                        # :68

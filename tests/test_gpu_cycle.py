@@ -36,7 +36,41 @@ def test_pcg(ipd):
     d, it, res, _ = ipd.PCG(A, np.zeros(200))
     assert it == 0 and np.isnan(res) and not d.any()
     with pytest.raises(ipd.IpdError):
-        ipd.PCG(A, b, dict(precd=4))        # MATLAB's ichol: not built
+        ipd.PCG(A, b, dict(precd=6))
+
+
+def test_pcg_incomplete_cholesky_preconditioner(ipd):
+    """precd 4: P = ichol(H) with MATLAB's defaults = IC(0) (PCG.m:44-50,100-101), built and applied
+    on the device, against the oracle's restatement (`ichol0`): iteration counts, solution, residual
+    history; on a dense matrix IC(0) is the exact factor and PCG stops after one step; an
+    indefinite matrix raises like MATLAB's "nonpositive pivot"."""
+    import scipy.sparse as sp
+    A = PR.random_sym_graph_laplacian(300, seed=10, eps=0.5)
+    b = np.random.RandomState(11).randn(300)
+    o = dict(guess=0.1 * np.random.RandomState(3).randn(300), retol=1e-11, maxit=1000, precd=4)
+    d, it, res, resk = ipd.PCG(A, b, o)
+    do, ito, reso, resko = O.PCG(A, b, o)
+    assert abs(it - ito) <= 1 and it < O.PCG(A, b, dict(o, precd=2))[1]
+    assert np.linalg.norm(A @ d - b) <= 1e-9 * np.linalg.norm(b)
+    assert np.allclose(d, do, rtol=1e-8, atol=1e-10)
+    k = min(it, ito) - 2
+    assert np.allclose(resk[:k], resko[:k], rtol=1e-6)
+    m, n = 40, 30                                   # a Newton operator of the drivers (Jk-like)
+    s = PR.mask_bernoulli(m, n, 0.3, seed=3)
+    pd = PR.make_prob(m, n, s, pq_random=True)
+    Ae = O.build_Ae(O.ASAt(s, pd["p"], pd["q"]), pd["T"], pd["p"], pd["q"], pd["bk1"], pd["tk"])[0]
+    f = np.random.RandomState(5).randn(m + n)
+    o4 = dict(guess=None, retol=1e-11, maxit=5000, precd=4)
+    d, it, res, _ = ipd.PCG(Ae, f, o4)
+    do, ito, reso, _ = O.PCG(Ae, f, o4)
+    assert abs(it - ito) <= 2
+    assert np.linalg.norm(d - do) <= 1e-7 * np.linalg.norm(do)
+    G = np.random.RandomState(2).randn(50, 50)
+    Hd = sp.csc_matrix(G @ G.T + 50 * np.eye(50))
+    d, it, res, _ = ipd.PCG(Hd, np.ones(50), dict(guess=None, retol=1e-11, maxit=100, precd=4))
+    assert it <= 2 and np.linalg.norm(Hd @ d - 1.0) <= 1e-10 * np.sqrt(50)
+    with pytest.raises(ipd.IpdError, match="nonpositive pivot"):
+        ipd.PCG(sp.csc_matrix(np.array([[1.0, 2.0], [2.0, 1.0]])), np.ones(2), dict(precd=4))
 
 
 def test_pcg_ssor_preconditioners(ipd):

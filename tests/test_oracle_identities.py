@@ -238,3 +238,28 @@ def test_amg4pot_matches_bordered_direct():
     He = eps * sp.identity(m + n + 1) + sg * Hfull
     ref = spla.spsolve(sp.csc_matrix(He), pd["z"])
     assert np.linalg.norm(zeta - ref) <= 1e-6 * np.linalg.norm(ref)
+
+
+def test_ichol0_is_the_cholesky_factor_when_nothing_is_dropped():
+    """IC(0) (oracle `ichol0`, the restatement of MATLAB's default `ichol`, PCG.m:46) equals the
+    complete Cholesky factor when tril(H) already holds all of its fill: a dense SPD matrix and an
+    arrowhead matrix; on a general sparse SPD matrix L*L' matches H on H's pattern."""
+    import scipy.sparse as sp
+    rs = np.random.RandomState(3)
+    G = rs.standard_normal((12, 12))
+    Hd = G @ G.T + 12 * np.eye(12)
+    L = O.ichol0(sp.csr_matrix(Hd)).toarray()
+    assert np.allclose(L, np.linalg.cholesky(Hd), rtol=1e-12, atol=1e-12)
+    n = 9
+    Ha = np.diag(2.0 + rs.random_sample(n))
+    Ha[-1, :-1] = Ha[:-1, -1] = 0.3 * rs.random_sample(n - 1)
+    Ha[-1, -1] = 4.0
+    assert np.allclose(O.ichol0(sp.csr_matrix(Ha)).toarray(), np.linalg.cholesky(Ha), atol=1e-13)
+    S = sp.random(40, 40, density=0.08, random_state=rs, format="csr")
+    Hs = (S + S.T + sp.identity(40) * 6.0).tocsr()
+    Ls = O.ichol0(Hs)
+    R = (Ls @ Ls.T - Hs).toarray()
+    mask = Hs.toarray() != 0
+    assert np.abs(R[mask]).max() <= 1e-13 * np.abs(Hs).max()
+    with pytest.raises(ValueError):
+        O.ichol0(sp.csr_matrix(np.array([[1.0, 2.0], [2.0, 1.0]])))
