@@ -47,6 +47,8 @@ struct CycleState {
     // level-resident solve kernel (ipd_resident.h): the whole Class_AMG loop in one launch of
     // res_G co-resident workgroups that keep the matrices of levels 1-2 in registers
     bool res_ok = false;
+    bool res_remote = false;   // levels >= 3 served by a tail workgroup (see ResDesc::remote)
+    size_t res_block_bytes = 0;
     ResDesc res_desc{};
     int res_G = 0;
     int res_ke = 0;          // entries per lane of a padded row (template argument)
@@ -167,15 +169,29 @@ static int pick_blocks(int nrows, int L, int cu) {
 static void plan_resident(ipd_amg* h, CycleState* st) {
     st->res_ok = false;
     if (const char* e = std::getenv("IPD_NO_RESIDENT"); e && e[0] == '1') return;
-    if (st->small_ok || h->J != 3 || h->opts.twogrid) return;
+    if (st->small_ok || h->J < 3 || h->opts.twogrid) return;
     const Level& l1 = h->L[1];
     const Level& l2 = h->L[2];
     const Level& l3 = h->L[3];
     const LevelDev& d1 = st->run[1].dev;
     const LevelDev& d2 = st->run[2].dev;
     const int N1 = l1.A.nr, N2 = l2.A.nr, Nt = l3.A.nr, nf = l1.nf, nc = N1 - nf;
+    if (const char* dbg = std::getenv("IPD_DEBUG_LEVELS"); dbg && dbg[0] == '1')
+        std::fprintf(stderr, "[ipd] resident plan: J=%d nf=%d nc=%d S1=%d S2=%d Nt=%d k_sub=%d sub_lds=%zu\n", h->J,
+                     nf, nc, d1.S, d2.S, Nt, st->k_sub, st->sub_lds);
     if (nf <= 0 || nc <= 0 || d1.S <= 0 || d2.S <= 0) return;
-    if (N1 > 4 * BT || N2 > 4 * BT || nf > 2 * BT || nc > 2 * BT || Nt > RES_TAIL_MAX || Nt < 1) return;
+    if (N1 > 4 * BT || N2 > 4 * BT || nf > 2 * BT || nc > 2 * BT || Nt < 1) return;
+    // everything below level 2: a tail of <= 64 rows solved redundantly by every workgroup (three
+    // levels), or -- deeper hierarchies -- the single-workgroup sub-cycle rooted at level 3 run by ONE
+    // extra workgroup out of its LDS image (the image the multi-launch path launches k_subcycle with)
+    const bool local_tail = h->J == 3 && Nt <= RES_TAIL_MAX;
+    bool remote = false;
+    if (!local_tail) {
+        const char* nr = std::getenv("IPD_NO_RESIDENT_REMOTE");
+        remote = !(nr && nr[0] == '1') && h->J >= 4 && st->k_sub == 3 && st->d_sub && Nt <= BT &&
+                 (h->opts.cycle == 'w' || h->opts.cycle == 'v');
+        if (!remote) return;
+    }
     const int smax = std::max(d1.S, d2.S);
     int ke = 4;
     while (64 * ke < smax) ke <<= 1;
@@ -183,8 +199,10 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     int G = std::max(cdiv(std::max(nf, nc), RES_WAVES), cdiv(N2, RES_WAVES));
     if (const char* e = std::getenv("IPD_RESIDENT_G")) G = std::max(G, std::atoi(e));
     // every workgroup owns at least one row of every block (the hand-off protocol needs it)
-    if (G > st->num_cu || G > std::min(std::min(nf, nc), N2)) return;
-    const size_t lds = RES_LDS_BYTES;
+    if (G + (remote ? 1 : 0) > st->num_cu || G > std::min(std::min(nf, nc), N2)) return;
+    if (remote && Nt > RES_WAVES * G) return;   // one row of P3' per wave
+    const size_t lds = remote ? std::max<size_t>(RES_LDS_BYTES, st->sub_lds) : RES_LDS_BYTES;
+    if (lds > 156 * 1024) return;
     Arena& ar = *h->arena;
     ResDesc D{};
     auto lev = [](const LevelDev& d) {
@@ -236,12 +254,19 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     D.presleep = 13;   // measured: 0 -> 0.0869, 8 -> 0.0796, 12..14 -> 0.0770, 16 -> 0.0784 ms per V cycle (a failing poll delays the publishes it waits for)
     if (const char* e = std::getenv("IPD_RES_PRESLEEP")) D.presleep = std::max(0, std::min(64, std::atoi(e)));
     const size_t gbytes = (size_t)RES_GRAN_MAX * 16;
-    st->res_block = reinterpret_cast<unsigned char*>(ar.alloc_bytes(2 * gbytes + 16));
+    st->res_block_bytes = 2 * gbytes + 16 + (remote ? 4 * gbytes + 16 : 0);
+    st->res_block = reinterpret_cast<unsigned char*>(ar.alloc_bytes(st->res_block_bytes));
     D.gran0 = st->res_block;
     D.gran1 = st->res_block + gbytes;
     D.tmo = reinterpret_cast<unsigned*>(st->res_block + 2 * gbytes);
+    D.remote = remote ? 1 : 0;
+    D.sub = remote ? st->d_sub : nullptr;
+    D.tin = remote ? st->res_block + 2 * gbytes + 16 : st->res_block;        // never touched without
+    D.tout = remote ? st->res_block + 4 * gbytes + 16 : st->res_block;       // a remote tail
+    D.tctl = remote ? reinterpret_cast<unsigned*>(st->res_block + 6 * gbytes + 16) : D.tmo;
     D.dbg = nullptr;
     st->res_desc = D;
+    st->res_remote = remote;
     st->res_G = G;
     st->res_ke = ke;
     st->res_lds = lds;
@@ -260,10 +285,10 @@ struct ResidentSlots {
     std::mutex mu;
     std::condition_variable cv;
     int used[64] = {0};
-    bool acquire(int device, int workgroups, int cus) {
+    bool acquire(int device, int workgroups, int cus, int wait_ms) {
         std::unique_lock<std::mutex> lock(mu);
         if (workgroups > cus) return false;
-        const bool got = cv.wait_for(lock, std::chrono::milliseconds(50),
+        const bool got = cv.wait_for(lock, std::chrono::milliseconds(wait_ms),
                                      [&] { return used[device & 63] + workgroups <= cus; });
         if (!got) return false;
         used[device & 63] += workgroups;
@@ -284,7 +309,8 @@ static ResidentSlots& resident_slots() {
 struct ResidentLease {
     int device, wgs;
     bool ok;
-    ResidentLease(int d, int w, int cus) : device(d), wgs(w), ok(resident_slots().acquire(d, w, cus)) {}
+    ResidentLease(int d, int w, int cus, int wait_ms)
+        : device(d), wgs(w), ok(resident_slots().acquire(d, w, cus, wait_ms)) {}
     ~ResidentLease() {
         if (ok) resident_slots().release(device, wgs);
     }
@@ -297,11 +323,16 @@ struct ResidentLease {
 static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double* x, int fixed_cycles,
                          std::vector<double>* out_host, float* ms, long long* dbg_dev = nullptr) {
     ipd_ctx* ctx = h->ctx;
-    ResidentLease lease(ctx->device, st->res_G, st->num_cu);
+    const int grid = st->res_G + (st->res_remote ? 1 : 0);
+    // A remote-tail launch is 129 workgroups at M = 2048: two of them do not fit side by side, and a
+    // realistic solve is a few milliseconds of mostly serial sub-cycle work -- waiting for the other
+    // solve (AMG4POT's two right-hand sides) would serialise them, so the loser runs as launches
+    // beside it at once.  The dense three-level launches (128 workgroups, two fit) keep waiting.
+    ResidentLease lease(ctx->device, grid, st->num_cu, st->res_remote ? 0 : 50);
     if (!lease.ok) return false;
     ResDesc D = st->res_desc;
     D.dbg = dbg_dev;
-    IPD_HIP(hipMemsetAsync(st->res_block, 0, 2 * (size_t)RES_GRAN_MAX * 16 + 16, ctx->stream));
+    IPD_HIP(hipMemsetAsync(st->res_block, 0, st->res_block_bytes, ctx->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ms) {
         IPD_HIP(hipEventCreate(&e0));
@@ -311,7 +342,7 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
 #define IPD_RES_LAUNCH(KE)                                                                          \
     do {                                                                                            \
         IPD_OPTIN_LDS(ctx, (k_resident<KE, KE>), 156 * 1024);                                       \
-        hipLaunchKernelGGL((k_resident<KE, KE>), dim3(st->res_G), dim3(BT), st->res_lds, ctx->stream, \
+        hipLaunchKernelGGL((k_resident<KE, KE>), dim3(grid), dim3(BT), st->res_lds, ctx->stream, \
                            D, b_dev, x, st->res_out, fixed_cycles);                                 \
     } while (0)
     if (st->res_ke == 4)
@@ -579,11 +610,13 @@ void amg_prepare_levels(ipd_amg* h) {
     // bottom run of levels with <= 32 rows (k >= 2): candidates for the wave-level sub-cycle
     // (33..64 rows run faster block-wide with 16 lanes per row than in one wave)
     int tiny_lo = h->J + 1;
+    int tiny_rows_max = 32;
+    if (const char* e = std::getenv("IPD_TINY_ROWS")) tiny_rows_max = std::max(1, std::min(64, std::atoi(e)));
     {
         const char* nt = std::getenv("IPD_NO_TINY");
         if (!(nt && nt[0] == '1'))
             for (int k = h->J; k >= 2; --k) {
-                if (h->L[k].A.nr > 32) break;
+                if (h->L[k].A.nr > tiny_rows_max) break;
                 tiny_lo = k;
             }
     }
@@ -1717,7 +1750,7 @@ extern "C" int ipd_amg_solve_mode(const ipd_amg* h, int32_t* mode, int32_t* grid
     const CycleState* st = h->cyc.get();
     if (!st) return IPD_E_ARG;
     *mode = st->small_ok ? 1 : (st->res_ok ? 2 : (st->mid_ok ? 3 : 0));
-    if (grid) *grid = st->res_ok ? st->res_G : (st->small_ok ? 1 : 0);
+    if (grid) *grid = st->res_ok ? st->res_G + (st->res_remote ? 1 : 0) : (st->small_ok ? 1 : 0);
     if (timeouts) *timeouts = st->res_timeouts;
     return IPD_OK;
 }

@@ -63,6 +63,15 @@ struct ResDesc {
     ResCsr Pt2, P2;   // level 1 <-> 2: restriction rows (N2 x N1), prolongation rows (N1 x N2)
     ResCsr Pt3, P3;   // level 2 <-> tail
     ResCsr A3;        // tail operator (CSR)
+    // Remote tail (hierarchies with more than three levels): workgroup gridDim.x - 1 holds the LDS
+    // image of the single-workgroup sub-cycle rooted at level 3 (k_subcycle's code and data) and
+    // serves the visits of everything below level 2: the other workgroups hand it r_3 = P3' rr_2
+    // (tin, Nt granules) and receive the prolongated correction P3 e_3 (tout, N2 granules).
+    int remote;
+    const SolveDesc* sub;     // image of levels 3..J (build_image), NULL without remote tail
+    unsigned char* tin;       // 2 x RES_GRAN_MAX granules by visit parity
+    unsigned char* tout;
+    unsigned* tctl;           // [0] != 0: the solve is over, the tail workgroup leaves
     int localfirst;   // zero-start first sweeps formed locally (see k_resident); 0: handed off like the rest
     int wident;       // P = [W; I] verified (k_res_check_ident): identity entries are added, not walked
     int Nt;           // tail rows
@@ -130,6 +139,39 @@ __device__ __forceinline__ bool res_sweep(__amdgpu_buffer_rsrc_t rs, unsigned se
         }
     }
     return bad;
+}
+
+// The same sweep for the slow hand-offs of the remote tail (tens of microseconds): long sleeps
+// between polls, no give-up count -- it ends when every tag carries `seq` (returns 0), when the
+// time-out word is raised (1) or when the exit word is (2; tail workgroup only, ctl may be NULL).
+template <int NJ>
+__device__ __forceinline__ int res_wait_slow(__amdgpu_buffer_rsrc_t rs, unsigned seq, int n,
+                                             const unsigned* tmo, const unsigned* ctl, double (&v)[NJ]) {
+    const int base = (int)(seq & 1) * (RES_GRAN_MAX * 16);
+    const int j0 = threadIdx.x;
+    for (unsigned spins = 0;; ++spins) {
+        res_v4u gq[NJ];
+#pragma unroll
+        for (int u = 0; u < NJ; ++u) {
+            const int j = j0 + u * BT;
+            gq[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (j < n ? j : 0) * 16, 0, 16 /* sc1 */);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < NJ; ++u) {
+            const int j = j0 + u * BT;
+            ok &= (j >= n) | ((gq[u].y == seq) & (gq[u].w == seq));
+            v[u] = __hiloint2double((int)gq[u].z, (int)gq[u].x);
+        }
+        if (__all(ok)) return 0;
+        if ((spins & 15) == 15) {
+            if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 1;
+            if (ctl && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 2;
+            if (spins > (1u << 24)) return 1;
+        }
+        __builtin_amdgcn_s_sleep(16);
+        asm volatile("" ::: "memory");
+    }
 }
 
 // lane-strided slice of one padded row: entries lane, lane+64, ... ; the 16-bit columns are kept
@@ -222,6 +264,57 @@ __device__ __forceinline__ double res_red8(const double* red) {
     return t;
 }
 
+// The tail workgroup of a remote-tail launch: k_subcycle's body as a server.  It loads the LDS
+// image of levels 3..J once, then for every visit waits for r_3 (D.Nt <= BT granules in tin), runs
+// the V or W sub-cycle rooted at level 3 out of LDS (both legs of MG_Wcycle.m:28-30 when level 3 is
+// not the coarsest), and publishes P3 * e_3 for all rows of level 2 (tout).  It leaves when the
+// other workgroups raise the exit word (end of the solve) or the time-out word.
+__device__ __forceinline__ void res_tail_workgroup(const ResDesc& D, char* dyn_raw, PhaseLds* lds,
+                                                   double* red, double* blkpart, int* stat) {
+    const int tid = threadIdx.x, w = tid >> 6;
+    SolveDesc* LD = sol_load_image(D.sub, dyn_raw);
+    SolveCtx c;
+    c.D = LD;
+    c.lds = lds;
+    c.red = red;
+    c.xs = reinterpret_cast<double*>(dyn_raw);
+    c.swapmask = 0;
+    c.zeromask = 0;
+    c.part = blkpart;
+    c.sumr = blkpart + 48;
+    c.dbg = nullptr;
+    const int k0 = 3, N3 = D.Nt, N2 = D.L2.N;
+    const bool two_legs = D.wcycle && k0 < LD->J;
+    const auto rin = __builtin_amdgcn_make_buffer_rsrc(D.tin, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
+    const auto rout = __builtin_amdgcn_make_buffer_rsrc(D.tout, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
+    for (unsigned tseq = 1;; ++tseq) {
+        double v[1];
+        const int st = res_wait_slow<1>(rin, tseq, N3, D.tmo, D.tctl, v);
+        if ((tid & 63) == 0) stat[w] = st;
+        __syncthreads();
+        int any = 0;
+#pragma unroll
+        for (int k = 0; k < RES_WAVES; ++k) any |= stat[k];
+        if (any) return;                       // uniform: every wave reads the same eight words
+        if (tid < N3) LD->L[k0].lv.r[tid] = v[0];
+        __syncthreads();
+        sol_cycle(c, k0, false);
+        __syncthreads();
+        if (two_legs) {
+            sol_cycle(c, k0, true);
+            __syncthreads();
+        }
+        const double* e3 = sol_e(c, k0);
+        const int base = (int)(tseq & 1) * (RES_GRAN_MAX * 16);
+        for (int j = tid; j < N2; j += BT) {   // e_2 += P e_3 is finished by the receivers     MG_Vcycle.m:31
+            double sd = 0.0;
+            for (int t = D.P3.rp[j]; t < D.P3.rp[j + 1]; ++t) sd += D.P3.va[t] * e3[D.P3.ci[t]];
+            __builtin_amdgcn_raw_buffer_store_b128(res_pack(sd, tseq), rout, base + j * 16, 0, 16 /* sc1 */);
+        }
+        __syncthreads();                       // stat and e3 are rewritten by the next visit
+    }
+}
+
 // out[0] = it, out[1] = rel_res, out[2] = res0; rel_resk at out[4 ..], rhok at out[4+maxit+2 ..]
 // (the layout of k_solve_small).  fixed_cycles > 0: exactly that many loop bodies, no stopping
 // rules (bench hook).  dbg (optional, 16 words): [0] shader clocks spent waiting in sweeps by
@@ -234,8 +327,16 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     double* sm = reinterpret_cast<double*>(res_smem);
     const char* smb = res_smem;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int b = blockIdx.x, G = gridDim.x;
+    const int b = blockIdx.x, G = gridDim.x - (D.remote ? 1 : 0);   // G: workgroups of levels 1-2
     const int N1 = D.L1.N, N2 = D.L2.N, nf = D.L1.nf, nc = N1 - nf, Nt = D.Nt;
+    if (D.remote && b == G) {   // the tail workgroup
+        __shared__ PhaseLds tail_lds;
+        __shared__ double tail_red[16];
+        __shared__ double tail_part[48 + SOLVE_ML + 1];
+        __shared__ int tail_stat[RES_WAVES];
+        res_tail_workgroup(D, res_smem, &tail_lds, tail_red, tail_part, tail_stat);
+        return;
+    }
     // LDS map (doubles): fixed slots of RES_NMAX entries, the gather targets in the first 64 KB so
     // that a gather is one ds_read_b64 with an immediate offset (no address arithmetic to hoist)
     constexpr int oX = 0, oE1 = RES_NMAX, oE2 = 2 * RES_NMAX, oRR1 = 3 * RES_NMAX;
@@ -249,7 +350,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     long long* dbg_acc = reinterpret_cast<long long*>(sm + oOWN + 8 * RES_WAVES + 1);   // 8 words
     // entry ranges of this wave's rows of P' (level-2 row) and P (F row, C row): read once, a walk
     // then starts with its entries instead of a dependent trip for the row pointers
-    int* rowp = reinterpret_cast<int*>(sm + oOWN + 8 * RES_WAVES + 12);                  // 6 ints per wave
+    int* rowp = reinterpret_cast<int*>(sm + oOWN + 8 * RES_WAVES + 12);                  // 8 ints per wave
     double* red = sm + oRED;
 
     // ---- rows of this wave ------------------------------------------------------------------
@@ -276,12 +377,16 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         sm[oOWN + 5 * RES_WAVES + w] = bvec[rC];
         sm[oOWN + 6 * RES_WAVES + w] = D.L2.diag[r2];
         sm[oOWN + 7 * RES_WAVES + w] = D.L2.dinv[r2];
-        rowp[6 * w + 0] = D.Pt2.rp[r2];
-        rowp[6 * w + 1] = v2 ? D.Pt2.rp[r2 + 1] - D.wident : D.Pt2.rp[r2];
-        rowp[6 * w + 2] = D.P2.rp[rF];
-        rowp[6 * w + 3] = vF ? D.P2.rp[rF + 1] : D.P2.rp[rF];
-        rowp[6 * w + 4] = D.P2.rp[rC];
-        rowp[6 * w + 5] = vC ? D.P2.rp[rC + 1] : D.P2.rp[rC];
+        rowp[8 * w + 0] = D.Pt2.rp[r2];
+        rowp[8 * w + 1] = v2 ? D.Pt2.rp[r2 + 1] - D.wident : D.Pt2.rp[r2];
+        rowp[8 * w + 2] = D.P2.rp[rF];
+        rowp[8 * w + 3] = vF ? D.P2.rp[rF + 1] : D.P2.rp[rF];
+        rowp[8 * w + 4] = D.P2.rp[rC];
+        rowp[8 * w + 5] = vC ? D.P2.rp[rC + 1] : D.P2.rp[rC];
+        // remote tail: row b + G*w of P3' (restriction to level 3), if there is one
+        const int r3 = b + G * w;
+        rowp[8 * w + 6] = (D.remote && r3 < Nt) ? D.Pt3.rp[r3] : 0;
+        rowp[8 * w + 7] = (D.remote && r3 < Nt) ? D.Pt3.rp[r3 + 1] : 0;
     }
 #define dgF sm[oOWN + 0 * RES_WAVES + w]
 #define dvF sm[oOWN + 1 * RES_WAVES + w]
@@ -413,7 +518,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     (void)dum1;
 
     // r = b - A x (rows of this wave), ||r||, c1 for a zero start; E1 := 0        Class_AMG.m:89,96,103
-    auto top = [&]() {
+    auto top = [&]() __attribute__((always_inline)) {
         const double sF = wave_sum(res_rowdot<KE1, 8 * oX>(cF, aF, smb));
         const double sC = wave_sum(res_rowdot<KE1, 8 * oX>(cC, aC, smb));
         if (lane == 0) {
@@ -437,7 +542,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // one half of a bigraph Gauss-Seidel sweep on level 1.  `first`: rows of the first half (the
     // other half still holds the old iterate); second half: + the shift by c of both halves and
     // the scalar of the next sweep.                         MG_Vcycle.m:15-21,34-38; Class_AMG.m:56-59
-    auto half1 = [&](bool frows, bool first, bool ezero) {
+    auto half1 = [&](bool frows, bool first, bool ezero) __attribute__((always_inline)) {
         double s = 0.0, eo = 0.0;
         const int row = frows ? rowF : rowC;
         const bool valid = frows ? vF : vC;
@@ -474,13 +579,13 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
             c1 = nsp ? xig / xx1 : 0.0;
         }
     };
-    auto sweep1 = [&](bool post, bool ezero) {
+    auto sweep1 = [&](bool post, bool ezero) __attribute__((always_inline)) {
         if (!(lfirst && ezero && !post)) half1(!post, true, ezero);   // else: done by top()    // pre: F rows first (Rk{1}); post: C rows first (Rk{1}')
         half1(post, false, ezero);
     };
 
     // weighted-Jacobi sweep on level 2                                   MG_Vcycle.m:15-21; Class_AMG.m:84
-    auto sweep2 = [&](bool ezero) {
+    auto sweep2 = [&](bool ezero) __attribute__((always_inline)) {
         double s = 0.0, eo = 0.0;
         if (!ezero) {
             s = wave_sum(res_rowdot<KE2, 8 * oE2>(c2, a2, smb));
@@ -504,7 +609,48 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 
     // tail level: restriction, Jacobi-PCG (PCG.m:68-87, zero guess), prolongation -- all of it by
     // every workgroup on its own LDS copies, so no hand-off                     MG_Vcycle.m:27-31,43
-    auto tail = [&]() {
+    const auto rtin = __builtin_amdgcn_make_buffer_rsrc(D.tin, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
+    const auto rtout = __builtin_amdgcn_make_buffer_rsrc(D.tout, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
+    unsigned tseq = 0;      // number of the last visit of the remote tail
+    auto tail = [&]() __attribute__((always_inline)) {
+        if (D.remote) {
+            // r_3 = P3' rr_2: row i by wave i / G of workgroup i % G (Nt <= BT <= 8 G rows), straight
+            // into the tail workgroup's inbox; then everybody waits for P3 e_3 and finishes e_2 += P e_3
+            ++tseq;
+            const int r3 = b + G * w;
+            if (r3 < Nt) {
+                const double s3 = res_csr_rowdot(D.Pt3, rowp[8 * w + 6], rowp[8 * w + 7], lane, sm, oRR2);
+                if (lane == 0)
+                    __builtin_amdgcn_raw_buffer_store_b128(res_pack(s3, tseq), rtin,
+                                                           (int)(tseq & 1) * (RES_GRAN_MAX * 16) + r3 * 16, 0,
+                                                           16 /* sc1 */);
+            }
+            double hv[4];
+            int st = 0;
+            if (!dead) st = res_wait_slow<4>(rtout, tseq, N2, D.tmo, nullptr, hv);
+            if (st) {
+                *fail = 1;
+                if (lane == 0) __hip_atomic_store(D.tmo, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            double p0 = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = tid + u * BT;
+                if (j < N2 && !dead && !st) {
+                    const double en = sm[oE2 + j] + hv[u];
+                    sm[oE2 + j] = en;
+                    p0 += sm[oR2 + j] - sm[oAX2 + j] * en;
+                }
+            }
+            if (nsp) {
+                p0 = wave_sum(p0);
+                if (lane == 0) red[w] = p0;
+            }
+            __syncthreads();
+            if (nsp) c2s = res_red8(red) / xx2;
+            if (*fail) dead = true;
+            return;
+        }
         if (tail1) {
             double s = 0.0;
             for (int j = tid; j < N2; j += BT) s += sm[oP3C + j] * sm[oRR2 + j];       // r_3 = P' rr
@@ -614,7 +760,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     };
 
     // one visit of level 2 and everything below it
-    auto visit2 = [&](bool keep) {
+    auto visit2 = [&](bool keep) __attribute__((always_inline)) {
         const int nu = D.nu;
         for (int s = (lfirst && !keep) ? 1 : 0; s < nu; ++s) sweep2(!keep && s == 0);
         // rr = r - A e                                                           MG_Vcycle.m:27
@@ -630,7 +776,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     };
 
     // MG_Vcycle / MG_Wcycle from level 1 down; the correction ends in E1
-    auto cycle = [&]() {
+    auto cycle = [&]() __attribute__((always_inline)) {
         const int nu = D.nu;
         for (int s = 0; s < nu; ++s) sweep1(false, s == 0);
         {   // rr = r - A e on both blocks
@@ -645,7 +791,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         {   // r_2 = P' rr ; E2 := 0 ; c for the zero start
             if (dbg) dbg_acc[6] -= __builtin_amdgcn_s_memtime();
             // row r2 of P' is [W(:,r2)' , 1 at nf + r2]; rowC == nf + row2 (level 2 = the C nodes)
-            const double s = res_csr_rowdot(D.Pt2, rowp[6 * w + 0], rowp[6 * w + 1], lane, sm, oRR1) +
+            const double s = res_csr_rowdot(D.Pt2, rowp[8 * w + 0], rowp[8 * w + 1], lane, sm, oRR1) +
                              (D.wident ? sm[oRR1 + rC] : 0.0);
             if (dbg) dbg_acc[6] += __builtin_amdgcn_s_memtime();
             if (lane == 0) sm[oPUB + w] = s;
@@ -675,9 +821,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         {   // e_1 += P e_2                                                        MG_Vcycle.m:31
             if (dbg) dbg_acc[6] -= __builtin_amdgcn_s_memtime();
             // F rows: W(rowF,:) against E2 (A's columns nf + i are level-2 indices i); C rows: identity
-            const double sF = res_csr_rowdot(D.P2, rowp[6 * w + 2], rowp[6 * w + 3], lane, sm, oE2);
+            const double sF = res_csr_rowdot(D.P2, rowp[8 * w + 2], rowp[8 * w + 3], lane, sm, oE2);
             const double sC = D.wident ? sm[oE2 + r2]
-                                       : res_csr_rowdot(D.P2, rowp[6 * w + 4], rowp[6 * w + 5], lane, sm, oE2);
+                                       : res_csr_rowdot(D.P2, rowp[8 * w + 4], rowp[8 * w + 5], lane, sm, oE2);
             if (dbg) dbg_acc[6] += __builtin_amdgcn_s_memtime();
             if (lane == 0) {
                 sm[oPUB + w] = sm[oE1 + rF] + sF;
@@ -691,7 +837,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         for (int s = 0; s < nu; ++s) sweep1(true, false);
     };
 
-    auto add_correction = [&]() {   // x += e                                       Class_AMG.m:98,101
+    auto add_correction = [&]() __attribute__((always_inline)) {   // x += e                                       Class_AMG.m:98,101
         for (int j = tid; j < N1; j += BT) sm[oX + j] = sm[oX + j] + sm[oE1 + j];
         __syncthreads();
     };
@@ -752,6 +898,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         it = fixed_cycles;
     else if (res0 != 0.0)
         it -= 1;                                                                  // :108
+    if (D.remote && b == 0 && tid == 0)   // release the tail workgroup
+        __hip_atomic_store(D.tctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (b == 0)
         for (int j = tid; j < N1; j += BT) xg[j] = sm[oX + j];
     if (writer) {
