@@ -41,9 +41,11 @@ def test_mid_kernel_matches_multilaunch(ipd, m, n, extra, cycle):
         pytest.skip("mask not connected")
     f = np.concatenate([pd["q"], -pd["p"]]) * pd["z"]
     opts = options(cycle, n)
-    with env(IPD_MID=1):
+    # (the level-resident kernel with a remote tail would take the first hierarchy ahead of both)
+    with env(IPD_MID=1, IPD_NO_RESIDENT_REMOTE=1):
         h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
-    hc = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    with env(IPD_NO_RESIDENT_REMOTE=1):
+        hc = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
     if solve_mode(h)[0] != 3:
         pytest.skip("hierarchy %s (nnz %s) is not taken by the single-workgroup kernel" % (
             h.level_sizes(), [h.level_dims(k)[1] for k in range(1, h.J + 1)]))
