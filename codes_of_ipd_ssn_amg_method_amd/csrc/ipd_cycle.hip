@@ -1120,6 +1120,29 @@ __device__ __forceinline__ int lanes_per_row(int rows) {
 #define IPD_LDS_ROW_U 2
 #endif
 static constexpr int LDS_ROW_U = IPD_LDS_ROW_U;   // entries per lane and trip of the LDS row walk
+// (entry range given: the sweeps of a visit read a row's pointers once, not once per sweep)
+__device__ __forceinline__ double lds_rowdot_range(AS3 const int* ci, AS3 const double* va, int beg,
+                                                   int end, int sub, int Lr, AS3 const double* x) {
+    double s = 0.0;
+    for (int t = beg + sub; t < end; t += LDS_ROW_U * Lr) {
+        int c[LDS_ROW_U];
+        double v[LDS_ROW_U], xv[LDS_ROW_U];
+        bool k[LDS_ROW_U];
+#pragma unroll
+        for (int u = 0; u < LDS_ROW_U; ++u) {
+            const int tu = t + u * Lr;
+            k[u] = tu < end;
+            c[u] = ci[k[u] ? tu : t];
+            v[u] = va[k[u] ? tu : t];
+        }
+#pragma unroll
+        for (int u = 0; u < LDS_ROW_U; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < LDS_ROW_U; ++u)
+            if (k[u]) s += v[u] * xv[u];
+    }
+    return subwave_sum(s, Lr);
+}
 __device__ __forceinline__ double lds_rowdot_split(AS3 const int* rp, AS3 const int* ci,
                                                    AS3 const double* va, int row, int sub, int Lr,
                                                    bool valid, AS3 const double* x) {
@@ -1403,6 +1426,11 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
     const double sumr = isnsp ? as_lds(c.sumr)[k] : 0.0;
     SemiRow R;
     if (L.semi) R = semi_row_load(L, i, valid);
+    int rbeg = 0, rend = 0;            // entry range of the row: the same for every sweep of the visit
+    if (!L.semi && valid) {
+        rbeg = L.rp[i];
+        rend = L.rp[i + 1];
+    }
     for (int s = 0; s < nu; ++s) {
         const bool ez = (c.zeromask >> k) & 1u;
         const long long q0 = c.dbg ? wall_clock64() : 0;
@@ -1412,8 +1440,7 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
         const long long q1 = c.dbg ? wall_clock64() : 0;
         double sd = 0.0;
         if (!ez)
-            sd = L.semi ? semi_row_dot(L, R, L.e)
-                        : lds_rowdot_split(L.rp, L.ci, L.va, i, sub, Lr, valid, L.e);
+            sd = L.semi ? semi_row_dot(L, R, L.e) : lds_rowdot_range(L.ci, L.va, rbeg, rend, sub, Lr, L.e);
         const double v = eo + dv * (rv - sd - ax * cc) + cc;
         if (owner) L.e2[i] = v;
         const long long q2 = c.dbg ? wall_clock64() : 0;
