@@ -251,6 +251,8 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
         D.wident = h->ctx->fetch1(bad) == 0 ? 1 : 0;
     }
     D.localfirst = (std::getenv("IPD_RES_NO_LOCALFIRST") && std::getenv("IPD_RES_NO_LOCALFIRST")[0] == '1') ? 0 : 1;
+    D.pollsleep = 1;
+    if (const char* e = std::getenv("IPD_RES_POLLSLEEP")) D.pollsleep = std::max(0, std::min(64, std::atoi(e)));
     D.presleep = 13;   // measured: 0 -> 0.0869, 8 -> 0.0796, 12..14 -> 0.0770, 16 -> 0.0784 ms per V cycle (a failing poll delays the publishes it waits for)
     if (const char* e = std::getenv("IPD_RES_PRESLEEP")) D.presleep = std::max(0, std::min(64, std::atoi(e)));
     const size_t gbytes = (size_t)RES_GRAN_MAX * 16;

@@ -81,6 +81,7 @@ struct ResDesc {
     unsigned char* gran0;
     unsigned char* gran1;
     int presleep;       // s_sleep(1) repetitions between a publish and the first poll of its sweep
+    int pollsleep;      // ... and between two polls
     unsigned* tmo;      // [0] != 0: a bounded spin gave up (value = step number)
     long long* dbg;     // optional stamps (diagnostic build of the bench): see k_resident
 };
@@ -107,7 +108,7 @@ __device__ __forceinline__ void res_publish(__amdgpu_buffer_rsrc_t rs, unsigned 
 // reads of the vectors that are about to change).
 template <int NJ>
 __device__ __forceinline__ bool res_sweep(__amdgpu_buffer_rsrc_t rs, unsigned seq, int n, bool dead,
-                                          unsigned* tmo, double (&v)[NJ]) {
+                                          unsigned* tmo, double (&v)[NJ], int pollsleep = 1) {
     const int base = (int)(seq & 1) * (RES_GRAN_MAX * 16);
     const int j0 = threadIdx.x;
     unsigned spins = 0;
@@ -134,7 +135,7 @@ __device__ __forceinline__ bool res_sweep(__amdgpu_buffer_rsrc_t rs, unsigned se
                 bad = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            for (int ps = 0; ps < pollsleep; ++ps) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
         }
     }
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         }                                                                                          \
         if (dbg) dbg_acc[0] -= __builtin_amdgcn_s_memtime();                                       \
         for (int ps_ = 0; ps_ < D.presleep; ++ps_) __builtin_amdgcn_s_sleep(1);                    \
-        if (res_sweep<NJ>(rs, seq, (n), dead, D.tmo, hv_)) {                                          \
+        if (res_sweep<NJ>(rs, seq, (n), dead, D.tmo, hv_, D.pollsleep)) {                             \
             *fail = 1;                                                                             \
             if (lane == 0) __hip_atomic_store(D.tmo, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
         }                                                                                          \
