@@ -1121,8 +1121,10 @@ __device__ __forceinline__ int lanes_per_row(int rows) {
 #endif
 static constexpr int LDS_ROW_U = IPD_LDS_ROW_U;   // entries per lane and trip of the LDS row walk
 // (entry range given: the sweeps of a visit read a row's pointers once, not once per sweep)
+template <int U = LDS_ROW_U>
 __device__ __forceinline__ double lds_rowdot_range(AS3 const int* ci, AS3 const double* va, int beg,
                                                    int end, int sub, int Lr, AS3 const double* x) {
+    constexpr int LDS_ROW_U = U;
     double s = 0.0;
     for (int t = beg + sub; t < end; t += LDS_ROW_U * Lr) {
         int c[LDS_ROW_U];
@@ -1431,6 +1433,9 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
         rbeg = L.rp[i];
         rend = L.rp[i + 1];
     }
+    // more than two entries per lane on average: four per trip (one dependent LDS round trip less per
+    // sweep on such levels; with two or fewer the masked slots of a wider batch only cost issue slots)
+    const bool wide = !L.semi && L.rp[N] > 2 * N * Lr;
     for (int s = 0; s < nu; ++s) {
         const bool ez = (c.zeromask >> k) & 1u;
         const long long q0 = c.dbg ? wall_clock64() : 0;
@@ -1440,7 +1445,9 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
         const long long q1 = c.dbg ? wall_clock64() : 0;
         double sd = 0.0;
         if (!ez)
-            sd = L.semi ? semi_row_dot(L, R, L.e) : lds_rowdot_range(L.ci, L.va, rbeg, rend, sub, Lr, L.e);
+            sd = L.semi ? semi_row_dot(L, R, L.e)
+                 : wide ? lds_rowdot_range<4>(L.ci, L.va, rbeg, rend, sub, Lr, L.e)
+                        : lds_rowdot_range<2>(L.ci, L.va, rbeg, rend, sub, Lr, L.e);
         const double v = eo + dv * (rv - sd - ax * cc) + cc;
         if (owner) L.e2[i] = v;
         const long long q2 = c.dbg ? wall_clock64() : 0;

@@ -398,8 +398,10 @@ int ipd_amg_bench_subcycle(ipd_amg* h, int reps, double* total_ms, int32_t* k_su
 int ipd_amg_cycle_bytes(const ipd_amg* h, double* bytes_per_cycle);
 /* How the solve phase of this hierarchy (AMG/Class_AMG.m:86-109) runs: *mode = 0 one launch
  * per phase, 1 the whole solve in one workgroup (small hierarchies), 2 the whole solve in ONE
- * launch of *grid co-resident workgroups that keep levels 1-2 in registers (dense regimes,
- * csrc/ipd_resident.h); *timeouts = launches of mode 2 that gave up and were redone in mode 0. */
+ * launch of *grid co-resident workgroups that keep levels 1-2 in registers (csrc/ipd_resident.h:
+ * three-level hierarchies of the dense regimes, and hierarchies of 4+ levels whose levels >= 3 fit
+ * one workgroup's LDS -- then *grid counts that tail workgroup too); *timeouts = launches of mode 2
+ * that gave up and were redone in mode 0.                                                      */
 int ipd_amg_solve_mode(const ipd_amg* h, int32_t* mode, int32_t* grid, int32_t* timeouts);
 /* Mode 2 only: `cycles` loop bodies in one launch with in-kernel stamps of workgroup 0:
  * stamps[0] shader clocks spent waiting in hand-off sweeps, [1] shader clocks of the launch,
