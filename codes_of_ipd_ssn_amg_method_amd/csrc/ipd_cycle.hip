@@ -1108,9 +1108,12 @@ __device__ __forceinline__ double lds_rowdot(AS3 const int* rp, AS3 const int* c
 // thread per row the whole block waits for them at every barrier (measured: 70 % of a sweep).
 // So a row is walked by Lr consecutive lanes (Lr = largest power of two with rows*Lr <= 1024,
 // at most 16), entries strided over the lanes, partial sums combined with DPP row operations.
+#ifndef IPD_BLK_LANES
+#define IPD_BLK_LANES BT
+#endif
 __device__ __forceinline__ int lanes_per_row(int rows) {
     int L = 1;
-    while (L < 16 && rows * (L * 2) <= BT) L <<= 1;
+    while (L < 16 && rows * (L * 2) <= IPD_BLK_LANES) L <<= 1;
     return L;
 }
 // every lane of the group returns the full sum.  Entries go four at a time with the last batch
@@ -1438,11 +1441,9 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
     const bool wide = !L.semi && L.rp[N] > 2 * N * Lr;
     for (int s = 0; s < nu; ++s) {
         const bool ez = (c.zeromask >> k) & 1u;
-        const long long q0 = c.dbg ? wall_clock64() : 0;
         const double eo = (valid && !ez) ? L.e[i] : 0.0;
         double cc = 0.0;
         if (isnsp) cc = (sumr - (ez ? 0.0 : blk_total(part + 16 * cur))) / L.xx;
-        const long long q1 = c.dbg ? wall_clock64() : 0;
         double sd = 0.0;
         if (!ez)
             sd = L.semi ? semi_row_dot(L, R, L.e)
@@ -1450,17 +1451,11 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
                         : lds_rowdot_range<2>(L.ci, L.va, rbeg, rend, sub, Lr, L.e);
         const double v = eo + dv * (rv - sd - ax * cc) + cc;
         if (owner) L.e2[i] = v;
-        const long long q2 = c.dbg ? wall_clock64() : 0;
         if (isnsp) blk_publish(owner ? ax * v : 0.0, part + 16 * (cur ^ 1));
-        const long long q3 = c.dbg ? wall_clock64() : 0;
+        // (per-sweep stamps stood here: c 0.14 | row walk + update 0.53 | publish 0.12 | barrier 0.17 us
+        // on a 324/102/34/11 sub-hierarchy; four uniform branches per sweep in a loop that is bound by
+        // instruction issue -- ~250 instructions per wave and sweep -- so they were taken out again)
         __syncthreads();
-        if (c.dbg && threadIdx.x == 0) {
-            c.dbg[9] += q1 - q0;
-            c.dbg[10] += q2 - q1;
-            c.dbg[11] += q3 - q2;
-            c.dbg[12] += wall_clock64() - q3;
-            c.dbg[13] += 1;
-        }
         cur ^= 1;
         AS3 double* t = L.e;
         L.e = L.e2;

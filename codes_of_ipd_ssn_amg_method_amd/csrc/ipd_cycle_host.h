@@ -1954,10 +1954,6 @@ extern "C" int ipd_amg_bench_subcycle(ipd_amg* h, int reps, double* total_ms, in
         ctx->fetch(dbg, hs, 16);
         if (stamps && hs[3] > hs[2])   // shader clock (MHz) seen by the cycle: s_memtime ticks / 10 ns
             stamps[0] = hs[8] * 100 / (hs[3] - hs[2]), hs[0] = stamps[0];
-        if (const char* e = std::getenv("IPD_DEBUG_SUBCYCLE"); e && e[0] == '1' && hs[13] > 0)
-            std::fprintf(stderr, "[ipd] blk sweeps of the last launch: %lld sweeps; per sweep (us): c %.3f | row walk + update %.3f | "
-                         "publish (wave sum) %.3f | barrier %.3f\n", hs[13], hs[9] / 100.0 / hs[13], hs[10] / 100.0 / hs[13],
-                         hs[11] / 100.0 / hs[13], hs[12] / 100.0 / hs[13]);
         if (stamps)
             for (int i = 0; i < 8; ++i) stamps[i] = hs[i];
         if (const char* e = std::getenv("IPD_DEBUG_SWEEP"); e && e[0] == '1')
