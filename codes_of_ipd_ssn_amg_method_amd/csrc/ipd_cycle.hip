@@ -1196,6 +1196,30 @@ __device__ __forceinline__ double glb_rowdot_split(const int* __restrict__ rp,
     }
     return subwave_sum(s, Lr);
 }
+// Semi-cached level with LONG rows (a level 3 of a few hundred rows with 40-100 entries each, too big
+// for LDS beside the deeper levels): Lr lanes per row, eight entries per lane and trip in flight
+// (a trip is a round trip to L2), the row's entry range read once per visit.
+__device__ __forceinline__ double glb_rowdot_range(const int* __restrict__ ci, const double* __restrict__ va,
+                                                   int beg, int end, int sub, int Lr, AS3 const double* x) {
+    constexpr int U = 8;
+    double s = 0.0;
+    for (int t = beg + sub; t < end; t += U * Lr) {
+        int c[U];
+        double v[U];
+        bool k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int tu = t + u * Lr;
+            k[u] = tu < end;
+            c[u] = ci[k[u] ? tu : t];
+            v[u] = va[k[u] ? tu : t];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k[u]) s += v[u] * x[c[u]];
+    }
+    return subwave_sum(s, Lr);
+}
 // A semi-cached level walks its rows thread-per-row; the first SEMI_RC entries of the row stay in
 // registers for all sweeps of a visit (a global round trip per sweep would cost more than the
 // launch the kernel replaces), longer rows read the rest from global memory.
@@ -1421,7 +1445,12 @@ __device__ __forceinline__ void blk_publish(double v, AS3 double* part) {
 // cur: index (0/1) of the partial-sum buffer that describes the current iterate
 __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int nu, int isnsp,
                                            int& cur) {
-    const int N = L.N, Lr = L.semi ? 1 : lanes_per_row(N);
+    const int N = L.N;
+    // semi-cached level: short rows (<= 12 entries on average: level 2 of a realistic hierarchy) stay
+    // thread-per-row with the first entries in registers, long rows are walked from L2 by Lr lanes
+    const bool semi_long = L.semi && L.grp[N] > 12 * N;
+    const bool semi_regs = L.semi && !semi_long;
+    const int Lr = semi_regs ? 1 : lanes_per_row(N);
     const int i = threadIdx.x / Lr, sub = threadIdx.x % Lr;
     const bool valid = i < N, owner = valid && sub == 0;
     AS3 double* part = as_lds(c.part);
@@ -1430,11 +1459,15 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
     const double dv = valid ? lvl_dinv(L, i) : 0.0;
     const double sumr = isnsp ? as_lds(c.sumr)[k] : 0.0;
     SemiRow R;
-    if (L.semi) R = semi_row_load(L, i, valid);
+    if (semi_regs) R = semi_row_load(L, i, valid);
     int rbeg = 0, rend = 0;            // entry range of the row: the same for every sweep of the visit
     if (!L.semi && valid) {
         rbeg = L.rp[i];
         rend = L.rp[i + 1];
+    }
+    if (semi_long && valid) {
+        rbeg = L.grp[i];
+        rend = L.grp[i + 1];
     }
     // more than two entries per lane on average: four per trip (one dependent LDS round trip less per
     // sweep on such levels; with two or fewer the masked slots of a wider batch only cost issue slots)
@@ -1446,9 +1479,10 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
         if (isnsp) cc = (sumr - (ez ? 0.0 : blk_total(part + 16 * cur))) / L.xx;
         double sd = 0.0;
         if (!ez)
-            sd = L.semi ? semi_row_dot(L, R, L.e)
-                 : wide ? lds_rowdot_range<4>(L.ci, L.va, rbeg, rend, sub, Lr, L.e)
-                        : lds_rowdot_range<2>(L.ci, L.va, rbeg, rend, sub, Lr, L.e);
+            sd = semi_regs   ? semi_row_dot(L, R, L.e)
+                 : semi_long ? glb_rowdot_range(L.gci, L.gva, rbeg, rend, sub, Lr, L.e)
+                 : wide      ? lds_rowdot_range<4>(L.ci, L.va, rbeg, rend, sub, Lr, L.e)
+                             : lds_rowdot_range<2>(L.ci, L.va, rbeg, rend, sub, Lr, L.e);
         const double v = eo + dv * (rv - sd - ax * cc) + cc;
         if (owner) L.e2[i] = v;
         if (isnsp) blk_publish(owner ? ax * v : 0.0, part + 16 * (cur ^ 1));
@@ -1532,7 +1566,8 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
                     const int Lr = lanes_per_row(L.N), row = i / Lr, sub = i % Lr;
                     const bool rvld = row < L.N;
                     const double sd =
-                        L.semi ? glb_rowdot_split(L.grp, L.gci, L.gva, row, sub, Lr, rvld, L.e)
+                        L.semi ? glb_rowdot_range(L.gci, L.gva, rvld ? L.grp[row] : 0, rvld ? L.grp[row + 1] : 0,
+                                                  sub, Lr, L.e)
                                : lds_rowdot_split(L.rp, L.ci, L.va, row, sub, Lr, rvld, L.e);
                     if (rvld && sub == 0) L.e2[row] = L.r[row] - sd;   // e2 is free between the sweeps
                 }

@@ -897,11 +897,29 @@ void amg_prepare_levels(ipd_amg* h) {
                     const size_t stage = lean_vectors ? 16 : r16(sizeof(double) * (size_t)h->L[kroot].A.nr);
                     size_t used = 0;
                     const int k_lds = plan_lds(stage, &used);
-                    if (k_lds > kroot) continue;
+                    // the root itself does not fit beside the deeper levels but has at most BT rows (a
+                    // level 3 of 170-310 rows with 40-100 entries each in the m=n=1024 runs): it becomes a
+                    // semi-cached root -- vectors in LDS, rows walked from L2 by several lanes each
+                    // (glb_rowdot_range), 2-3 us per sweep against 5 us for the launch it replaces
+                    bool semi_root = false;
+                    // (only with short rows, <= 12 entries on average like the semi-cached level 2: measured on
+                    // the Newton systems of the m=n=1024 Class 1 run, a level 3 of 2-3 k entries gains 5-9 % per W
+                    // cycle as launches and opens the hierarchy to the resident kernel's remote tail, -15...-23 %;
+                    // with 4 k entries it loses 12 %, with 9-17 k entries a sweep from L2 through one CU costs
+                    // more than the launch: 0.72 -> 1.09 ms, 0.54 -> 1.21 ms per W cycle)
+                    if (k_lds == kroot + 1 && kroot >= 3 && lean_vectors && h->L[kroot].A.nr <= BT &&
+                        (double)h->L[kroot].A.nnz <= 12.0 * h->L[kroot].A.nr &&
+                        (double)h->L[kroot + 1].P.nnz <= 12.0 * h->L[kroot].A.nr &&
+                        used + 3 * r16(8 * (size_t)h->L[kroot].A.nr) <= 150 * 1024) {
+                        const char* ns3 = std::getenv("IPD_NO_SEMI_ROOT");
+                        semi_root = !(ns3 && ns3[0] == '1');
+                    }
+                    if (k_lds > kroot && !semi_root) continue;
                     std::unique_ptr<SolveDesc> sd(new SolveDesc());
                     fill_desc(sd.get());
                     sd->k_lds = kroot;
-                    sd->k_tiny = tiny_from(kroot);
+                    if (semi_root) sd->k_semi = kroot;
+                    sd->k_tiny = tiny_from(kroot + (semi_root ? 1 : 0));
                     sd->k_blk = blk_from(kroot);
                     sd->stage_bytes = (int)stage;
                     sd->root_r = h->L[kroot].r;
