@@ -263,3 +263,25 @@ def test_ichol0_is_the_cholesky_factor_when_nothing_is_dropped():
     assert np.abs(R[mask]).max() <= 1e-13 * np.abs(Hs).max()
     with pytest.raises(ValueError):
         O.ichol0(sp.csr_matrix(np.array([[1.0, 2.0], [2.0, 1.0]])))
+
+
+def test_ideal_interpolation_identity_and_single_coarse_node():
+    """`inter = 2`, W = -Aff \\ Afc (AMG/transfer.m:57-58): A_ff*W + A_fc = 0 on the oracle's result, and a
+    hierarchy whose last transfer has ONE coarse node (SciPy's spsolve returns a 1-D array there)
+    still builds and converges."""
+    import scipy.sparse as sp
+    A = PR.random_sym_graph_laplacian(200, deg=3, seed=7) + sp.identity(200) * 0.05
+    o = O.amg_options_class1("v")
+    o.update(bigph=0, isnsp=0, inter=2)
+    Ac, Pro, info = O.transfer(A, o, 2, O.matlab_rng())
+    isC = info["isC"]
+    F, C = np.flatnonzero(~isC), np.flatnonzero(isC)
+    Ad = A.toarray()
+    W = Pro.toarray()[F, :]
+    assert np.abs(Ad[np.ix_(F, F)] @ W + Ad[np.ix_(F, C)]).max() <= 1e-12 * np.abs(Ad).max() * max(1.0, np.abs(W).max())
+    assert np.array_equal(Pro.toarray()[C, :], np.eye(len(C)))
+    A2 = PR.random_sym_graph_laplacian(400, deg=4, seed=3) + sp.identity(400) * 0.02
+    b = np.random.RandomState(1).standard_normal(400)
+    opts = dict(retol=1e-10, bigph=0, maxit=40, theta=0.25, smoth=2, cycle="v", isnsp=0, inter=2, guess=None)
+    x, it, rr, relk, rhok, h = O.Class_AMG(A2, b, opts, O.matlab_rng(), return_hierarchy=True)
+    assert h.level_sizes()[-1] == 1 and rr <= 1e-10 and np.linalg.norm(A2 @ x - b) <= 1e-9 * np.linalg.norm(b)
