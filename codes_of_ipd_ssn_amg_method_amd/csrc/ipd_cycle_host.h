@@ -9,6 +9,7 @@ struct LevelRun {  // per-level run state kept next to Level
     LevelDev dev;
     bool e_zero = true;      // the iterate is identically zero and is not materialised
     int staged = 0;          // N <= STAGE_MAX: gather vectors go through LDS
+    int maxoff = 0;          // longest off-diagonal row (k_level_prepare)
     XferArgs restrict_args;  // r_{k+1} = P' rr_k   (stored on level k)
     XferArgs prolong_args;   // e_k += P e_{k+1}
     PcgArgs pcg;             // coarsest only
@@ -41,6 +42,9 @@ struct CycleState {
     MaskOp maskop{};
     // single-workgroup sub-cycle rooted at level k_sub (0 = none), see k_subcycle
     SolveDesc* d_sub = nullptr;
+    bool sub_semi_root = false;    // d_sub's root level is semi-cached (rows from L2)
+    SolveDesc* d_sub4 = nullptr;   // image rooted at level 4 for the resident kernel's `three` mode
+    size_t sub4_lds = 0;           // (packed beside d_sub when that one is rooted at level 3)
     int k_sub = 0;
     size_t sub_lds = 0;
     double* x2 = nullptr;
@@ -48,6 +52,7 @@ struct CycleState {
     // res_G co-resident workgroups that keep the matrices of levels 1-2 in registers
     bool res_ok = false;
     bool res_remote = false;   // levels >= 3 served by a tail workgroup (see ResDesc::remote)
+    int res_ke3 = 0;           // > 0: level 3 resident as well (entries per lane of its rows), tail rooted at 4
     size_t res_block_bytes = 0;
     ResDesc res_desc{};
     int res_G = 0;
@@ -177,31 +182,60 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     const LevelDev& d2 = st->run[2].dev;
     const int N1 = l1.A.nr, N2 = l2.A.nr, Nt = l3.A.nr, nf = l1.nf, nc = N1 - nf;
     if (const char* dbg = std::getenv("IPD_DEBUG_LEVELS"); dbg && dbg[0] == '1')
-        std::fprintf(stderr, "[ipd] resident plan: J=%d nf=%d nc=%d S1=%d S2=%d Nt=%d k_sub=%d sub_lds=%zu\n", h->J,
-                     nf, nc, d1.S, d2.S, Nt, st->k_sub, st->sub_lds);
+        std::fprintf(stderr, "[ipd] resident plan: J=%d nf=%d nc=%d S1=%d S2=%d S3=%d N4=%d Nt=%d k_sub=%d sub_lds=%zu\n", h->J,
+                     nf, nc, d1.S, d2.S, st->run[3].dev.S, h->J >= 4 ? h->L[4].A.nr : 0, Nt, st->k_sub, st->sub_lds);
     if (nf <= 0 || nc <= 0 || d1.S <= 0 || d2.S <= 0) return;
     if (N1 > 4 * BT || N2 > 4 * BT || nf > 2 * BT || nc > 2 * BT || Nt < 1) return;
     // everything below level 2: a tail of <= 64 rows solved redundantly by every workgroup (three
     // levels), or -- deeper hierarchies -- the single-workgroup sub-cycle rooted at level 3 run by ONE
     // extra workgroup out of its LDS image (the image the multi-launch path launches k_subcycle with)
     const bool local_tail = h->J == 3 && Nt <= RES_TAIL_MAX;
-    bool remote = false;
+    bool remote = false, three = false;
+    int ke3 = 0;
+    const SolveDesc* tail_img = nullptr;   // the remote tail's LDS image and its dynamic LDS size
+    size_t tail_lds = 0;
     if (!local_tail) {
         const char* nr = std::getenv("IPD_NO_RESIDENT_REMOTE");
-        remote = !(nr && nr[0] == '1') && h->J >= 4 && st->k_sub == 3 && st->d_sub && Nt <= BT &&
-                 (h->opts.cycle == 'w' || h->opts.cycle == 'v');
+        const bool cyc = h->opts.cycle == 'w' || h->opts.cycle == 'v';
+        remote = !(nr && nr[0] == '1') && h->J >= 4 && st->k_sub == 3 && st->d_sub && Nt <= BT && cyc;
+        // Level 3 in the registers of the resident workgroups as well, the tail rooted at level 4: for
+        // a level 3 too big for the tail's LDS (a few hundred rows of 15-100 entries), and preferred to
+        // the tail rooted at level 3 whenever an image rooted at level 4 exists (the tail's legs are the
+        // serial part of a cycle: ~22 us each from level 4, ~100 us from level 3).
+        const char* n3 = std::getenv("IPD_NO_RESIDENT_THREE");
+        tail_img = st->d_sub;
+        tail_lds = st->sub_lds;
+        const bool img4 = (st->k_sub == 4 && st->d_sub) || (st->k_sub == 3 && st->d_sub4);
+        if (!(nr && nr[0] == '1') && !(n3 && n3[0] == '1') && h->J >= 5 && img4 && cyc) {
+            // (its rows are usually too uneven for the launches' padded copy -- hubs -- but in registers
+            // the stride is only a layout: a private copy with the longest row as stride, below)
+            const int S3 = st->run[3].dev.S > 0 ? st->run[3].dev.S : (st->run[3].maxoff + 3) / 4 * 4;
+            const int N4 = h->L[4].A.nr;
+            if (S3 > 0 && S3 <= 512 && Nt <= BT && N4 <= BT && N2 <= RES_NMAX / 2 &&
+                std::max(d1.S, d2.S) <= 512 && Nt + std::max(cdiv(std::max(nf, nc), RES_WAVES), cdiv(N2, RES_WAVES)) <= 2 * BT) {
+                three = remote = true;
+                ke3 = S3 <= 256 ? 4 : 8;
+                if (st->k_sub == 3) {
+                    tail_img = st->d_sub4;
+                    tail_lds = st->sub4_lds;
+                }
+            }
+        }
         if (!remote) return;
     }
     const int smax = std::max(d1.S, d2.S);
     int ke = 4;
     while (64 * ke < smax) ke <<= 1;
     if (ke > 16) return;
+    if (three && ke > 8) return;   // (the third row slice does not fit beside two 16-entry ones)
     int G = std::max(cdiv(std::max(nf, nc), RES_WAVES), cdiv(N2, RES_WAVES));
     if (const char* e = std::getenv("IPD_RESIDENT_G")) G = std::max(G, std::atoi(e));
     // every workgroup owns at least one row of every block (the hand-off protocol needs it)
     if (G + (remote ? 1 : 0) > st->num_cu || G > std::min(std::min(nf, nc), N2)) return;
-    if (remote && Nt > RES_WAVES * G) return;   // one row of P3' per wave
-    const size_t lds = remote ? std::max<size_t>(RES_LDS_BYTES, st->sub_lds) : RES_LDS_BYTES;
+    const int Nin = three ? h->L[4].A.nr : Nt;   // rows of the remote tail's root level
+    if (remote && Nin > RES_WAVES * G) return;   // one row of the restriction to it per wave
+    if (three && Nt + G > 2 * BT) return;        // level-3 hand-offs: N3 + G granules, two per thread
+    const size_t lds = remote ? std::max<size_t>(RES_LDS_BYTES, tail_lds) : RES_LDS_BYTES;
     if (lds > 156 * 1024) return;
     Arena& ar = *h->arena;
     ResDesc D{};
@@ -232,7 +266,33 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     D.Pt3 = csr(l3.Pt);
     D.P3 = csr(l3.P);
     D.A3 = csr(l3.A);
-    D.Nt = Nt;
+    D.Nt = Nin;
+    D.three = three ? 1 : 0;
+    D.tail_root = three ? 4 : 3;
+    if (three) {
+        LevelDev d3 = st->run[3].dev;
+        if (d3.S <= 0) {   // private padded copy of level 3 (k_pad_build), stride = its longest row
+            const Csr& A3 = l3.A;
+            const int S3 = (st->run[3].maxoff + 3) / 4 * 4;
+            unsigned short* pci = ar.alloc<unsigned short>((size_t)A3.nr * S3);
+            double* pva = ar.alloc<double>((size_t)A3.nr * S3);
+            double* dg = ar.alloc<double>((size_t)A3.nr);
+            hipLaunchKernelGGL(k_pad_build, dim3(std::max(1, std::min(cdiv(A3.nr, 4), 4096))), dim3(256), 0,
+                               h->ctx->stream, A3.nr, S3, A3.rp, A3.ci, A3.va, pci, pva, dg);
+            IPD_KERNEL_CHECK();
+            d3.S = S3;
+            d3.pci = pci;
+            d3.pva = pva;
+            d3.diag = dg;
+        }
+        D.L3 = lev(d3);
+        D.Pt4 = csr(h->L[4].Pt);
+        D.P4 = csr(h->L[4].P);
+    } else {
+        D.L3 = lev(d2);   // unused
+        D.Pt4 = csr(l3.Pt);
+        D.P4 = csr(l3.P);
+    }
     D.nu = h->opts.smoth;
     D.isnsp = h->opts.isnsp;
     D.wcycle = h->opts.cycle == 'w';
@@ -262,13 +322,14 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     D.gran1 = st->res_block + gbytes;
     D.tmo = reinterpret_cast<unsigned*>(st->res_block + 2 * gbytes);
     D.remote = remote ? 1 : 0;
-    D.sub = remote ? st->d_sub : nullptr;
+    D.sub = remote ? tail_img : nullptr;
     D.tin = remote ? st->res_block + 2 * gbytes + 16 : st->res_block;        // never touched without
     D.tout = remote ? st->res_block + 4 * gbytes + 16 : st->res_block;       // a remote tail
     D.tctl = remote ? reinterpret_cast<unsigned*>(st->res_block + 6 * gbytes + 16) : D.tmo;
     D.dbg = nullptr;
     st->res_desc = D;
     st->res_remote = remote;
+    st->res_ke3 = ke3;
     st->res_G = G;
     st->res_ke = ke;
     st->res_lds = lds;
@@ -341,18 +402,30 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
         IPD_HIP(hipEventCreate(&e1));
         IPD_HIP(hipEventRecord(e0, ctx->stream));
     }
-#define IPD_RES_LAUNCH(KE)                                                                          \
+#define IPD_RES_LAUNCH(KE, KE3)                                                                     \
     do {                                                                                            \
-        IPD_OPTIN_LDS(ctx, (k_resident<KE, KE>), 156 * 1024);                                       \
-        hipLaunchKernelGGL((k_resident<KE, KE>), dim3(grid), dim3(BT), st->res_lds, ctx->stream, \
+        IPD_OPTIN_LDS(ctx, (k_resident<KE, KE, KE3>), 156 * 1024);                                  \
+        hipLaunchKernelGGL((k_resident<KE, KE, KE3>), dim3(grid), dim3(BT), st->res_lds, ctx->stream, \
                            D, b_dev, x, st->res_out, fixed_cycles);                                 \
     } while (0)
-    if (st->res_ke == 4)
-        IPD_RES_LAUNCH(4);
-    else if (st->res_ke == 8)
-        IPD_RES_LAUNCH(8);
-    else
-        IPD_RES_LAUNCH(16);
+    if (st->res_ke3 == 0) {
+        if (st->res_ke == 4)
+            IPD_RES_LAUNCH(4, 0);
+        else if (st->res_ke == 8)
+            IPD_RES_LAUNCH(8, 0);
+        else
+            IPD_RES_LAUNCH(16, 0);
+    } else if (st->res_ke == 4) {
+        if (st->res_ke3 == 4)
+            IPD_RES_LAUNCH(4, 4);
+        else
+            IPD_RES_LAUNCH(4, 8);
+    } else {
+        if (st->res_ke3 == 4)
+            IPD_RES_LAUNCH(8, 4);
+        else
+            IPD_RES_LAUNCH(8, 8);
+    }
 #undef IPD_RES_LAUNCH
     IPD_KERNEL_CHECK();
     if (ms) IPD_HIP(hipEventRecord(e1, ctx->stream));
@@ -488,6 +561,7 @@ void amg_prepare_levels(ipd_amg* h) {
             lv.lanes = donor->L[k].lanes;
         } else {
             build_padded(ctx, ar, lv.A, rows_per_launch, cu, hmax[(size_t)k], &rn.dev);
+        rn.maxoff = hmax[(size_t)k];
         }
     }
     for (int k = 1; k < h->J; ++k) {
@@ -925,10 +999,36 @@ void amg_prepare_levels(ipd_amg* h) {
                     sd->root_r = h->L[kroot].r;
                     sd->root_e = h->L[kroot].e;
                     st->k_sub = kroot;
+                    st->sub_semi_root = semi_root;
                     st->d_sub = build_image(sd.get(), kroot, stage, &st->sub_lds);
                     break;
                 }
             }
+        }
+    }
+    // (b2) Where level 3 is only a semi-cached root (its rows come from L2), the level-resident kernel
+    // does better with level 3 in registers and its tail rooted at level 4 (plan_resident, `three`:
+    // 0.50-0.51 against 0.57-0.61 ms per W cycle on the Newton systems of the m=n=1024 Class 1 run), so a
+    // second image rooted at level 4 is packed for it.  (Where levels 3..J fit the image as they are,
+    // the tail rooted at level 3 stays 3-6 % ahead: 0.49-0.51 against 0.51-0.54 ms.)
+    if (st->k_sub == 3 && st->sub_semi_root && st->d_sub && h->J >= 5 && h->J <= SOLVE_ML && h->L[3].A.nr <= BT &&
+        h->L[4].A.nr <= BT && st->run[3].maxoff <= 512 && h->L[1].nf > 0 &&
+        !(std::getenv("IPD_NO_RESIDENT_THREE") && std::getenv("IPD_NO_RESIDENT_THREE")[0] == '1') &&
+        !(std::getenv("IPD_NO_RESIDENT") && std::getenv("IPD_NO_RESIDENT")[0] == '1')) {
+        const size_t stage = 16;
+        size_t used = 0;
+        bool ok = lean_vectors;
+        for (int k = 4; k <= h->J && ok; ++k) ok = small_level(k);
+        if (ok && plan_lds(stage, &used) <= 4) {
+            std::unique_ptr<SolveDesc> sd(new SolveDesc());
+            fill_desc(sd.get());
+            sd->k_lds = 4;
+            sd->k_tiny = tiny_from(4);
+            sd->k_blk = blk_from(4);
+            sd->stage_bytes = (int)stage;
+            sd->root_r = h->L[4].r;
+            sd->root_e = h->L[4].e;
+            st->d_sub4 = build_image(sd.get(), 4, stage, &st->sub4_lds);
         }
     }
     // (c) realistic hierarchies whose levels 1-2 are too big for (a) and too small to need many

@@ -60,9 +60,13 @@ struct ResCsr {
 };
 struct ResDesc {
     ResLevelDesc L1, L2;
+    ResLevelDesc L3;  // third resident level (Jacobi, <= BT rows), `three` != 0 only
     ResCsr Pt2, P2;   // level 1 <-> 2: restriction rows (N2 x N1), prolongation rows (N1 x N2)
-    ResCsr Pt3, P3;   // level 2 <-> tail
-    ResCsr A3;        // tail operator (CSR)
+    ResCsr Pt3, P3;   // level 2 <-> 3 (the tail level of a three-level hierarchy)
+    ResCsr Pt4, P4;   // level 3 <-> 4 (`three` only: the remote tail is rooted at level 4)
+    ResCsr A3;        // tail operator (CSR), local tail only
+    int three;        // levels 1-3 resident (hierarchies whose level 3 does not fit the tail's LDS)
+    int tail_root;    // remote tail: 3 or 4
     // Remote tail (hierarchies with more than three levels): workgroup gridDim.x - 1 holds the LDS
     // image of the single-workgroup sub-cycle rooted at level 3 (k_subcycle's code and data) and
     // serves the visits of everything below level 2: the other workgroups hand it r_3 = P3' rr_2
@@ -74,7 +78,7 @@ struct ResDesc {
     unsigned* tctl;           // [0] != 0: the solve is over, the tail workgroup leaves
     int localfirst;   // zero-start first sweeps formed locally (see k_resident); 0: handed off like the rest
     int wident;       // P = [W; I] verified (k_res_check_ident): identity entries are added, not walked
-    int Nt;           // tail rows
+    int Nt;           // rows of the tail level (local tail) or of the remote tail's root level
     int nu, isnsp, wcycle, anycycle, maxit;
     double retol;
     long long pcg_maxit;
@@ -284,7 +288,8 @@ __device__ __forceinline__ void res_tail_workgroup(const ResDesc& D, char* dyn_r
     c.part = blkpart;
     c.sumr = blkpart + 48;
     c.dbg = nullptr;
-    const int k0 = 3, N3 = D.Nt, N2 = D.L2.N;
+    const int k0 = D.tail_root, N3 = D.Nt, N2 = k0 == 3 ? D.L2.N : D.L3.N;   // inbox / outbox rows
+    const ResCsr& Pout = k0 == 3 ? D.P3 : D.P4;
     const bool two_legs = D.wcycle && k0 < LD->J;
     const auto rin = __builtin_amdgcn_make_buffer_rsrc(D.tin, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
     const auto rout = __builtin_amdgcn_make_buffer_rsrc(D.tout, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
@@ -309,7 +314,7 @@ __device__ __forceinline__ void res_tail_workgroup(const ResDesc& D, char* dyn_r
         const int base = (int)(tseq & 1) * (RES_GRAN_MAX * 16);
         for (int j = tid; j < N2; j += BT) {   // e_2 += P e_3 is finished by the receivers     MG_Vcycle.m:31
             double sd = 0.0;
-            for (int t = D.P3.rp[j]; t < D.P3.rp[j + 1]; ++t) sd += D.P3.va[t] * e3[D.P3.ci[t]];
+            for (int t = Pout.rp[j]; t < Pout.rp[j + 1]; ++t) sd += Pout.va[t] * e3[Pout.ci[t]];
             __builtin_amdgcn_raw_buffer_store_b128(res_pack(sd, tseq), rout, base + j * 16, 0, 16 /* sc1 */);
         }
         __syncthreads();                       // stat and e3 are rewritten by the next visit
@@ -321,9 +326,11 @@ __device__ __forceinline__ void res_tail_workgroup(const ResDesc& D, char* dyn_r
 // rules (bench hook).  dbg (optional, 16 words): [0] shader clocks spent waiting in sweeps by
 // workgroup 0, [1] clocks of the whole loop, [2] number of hand-offs, [3] 100 MHz ticks of the loop,
 // [4] clocks in the barrier before the publish, [5] in the store phase, [6] in the closing barrier.
-template <int KE1, int KE2>
+template <int KE1, int KE2, int KE3 = 0>
 __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const double* __restrict__ bvec,
                                                     double* xg, double* out, int fixed_cycles) {
+    constexpr bool THREE = KE3 > 0;
+    constexpr int K3 = THREE ? KE3 : 2;
     extern __shared__ __attribute__((aligned(16))) char res_smem[];
     double* sm = reinterpret_cast<double*>(res_smem);
     const char* smb = res_smem;
@@ -346,12 +353,17 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     constexpr int oR3 = 9 * RES_NMAX, oE3 = oR3 + RES_TAIL_MAX, oP3 = oE3 + RES_TAIL_MAX;
     constexpr int oRED = oP3 + RES_TAIL_MAX;          // 2*RES_WAVES doubles
     constexpr int oPUB = oRED + 2 * RES_WAVES;        // values the waves publish this step (2 blocks)
-    constexpr int oOWN = oPUB + 2 * RES_WAVES;        // 8 scalars of each wave's rows
-    int* fail = reinterpret_cast<int*>(sm + oOWN + 8 * RES_WAVES);
-    long long* dbg_acc = reinterpret_cast<long long*>(sm + oOWN + 8 * RES_WAVES + 1);   // 8 words
-    // entry ranges of this wave's rows of P' (level-2 row) and P (F row, C row): read once, a walk
-    // then starts with its entries instead of a dependent trip for the row pointers
-    int* rowp = reinterpret_cast<int*>(sm + oOWN + 8 * RES_WAVES + 12);                  // 8 ints per wave
+    constexpr int oOWN = oPUB + 2 * RES_WAVES;        // 10 scalars of each wave's rows
+    int* fail = reinterpret_cast<int*>(sm + oOWN + 10 * RES_WAVES);
+    long long* dbg_acc = reinterpret_cast<long long*>(sm + oOWN + 10 * RES_WAVES + 1);   // 8 words
+    // entry ranges of this wave's rows of the transfer operators: read once, a walk then starts
+    // with its entries instead of a dependent trip for the row pointers
+    int* rowp = reinterpret_cast<int*>(sm + oOWN + 10 * RES_WAVES + 12);                 // 12 ints per wave
+    // third resident level (THREE): its vectors sit in the upper halves of level 2's slots (N2 <= 1024,
+    // N3 <= 512); E3 is a gather target and must lie below 64 KB
+    constexpr int oE3L = oE2 + RES_NMAX / 2, oR3L = oRR2 + RES_NMAX / 2, oRR3L = oRR2 + 3 * RES_NMAX / 4;
+    constexpr int oAX3L = oAX2 + RES_NMAX / 2;
+    const int N3 = THREE ? D.L3.N : 0;
     double* red = sm + oRED;
 
     // ---- rows of this wave ------------------------------------------------------------------
@@ -361,6 +373,10 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     const int rowF = loF + w, rowC = loC + w, row2 = lo2 + w;
     const bool vF = rowF < hiF, vC = rowC < hiC, v2 = row2 < hi2;
     const int rF = vF ? rowF : 0, rC = vC ? rowC : 0, r2 = v2 ? row2 : 0;
+    const int lo3 = THREE ? (int)(((long long)b * N3) / G) : 0, hi3 = THREE ? (int)(((long long)(b + 1) * N3) / G) : 0;
+    const int row3 = lo3 + w;
+    const bool v3 = THREE && row3 < hi3;
+    const int r3 = v3 ? row3 : 0;
 
     // ---- matrix slices -> registers (the only read of the matrices in the whole solve) --------
     unsigned cF[KE1 / 2], cC[KE1 / 2], c2[KE2 / 2];
@@ -368,6 +384,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     res_load_slice<KE1>(D.L1, rF, vF, lane, cF, aF);
     res_load_slice<KE1>(D.L1, rC, vC, lane, cC, aC);
     res_load_slice<KE2>(D.L2, r2, v2, lane, c2, a2);
+    unsigned c3[K3 / 2];
+    double a3[K3];
+    if (THREE) res_load_slice<K3>(D.L3, r3, v3, lane, c3, a3);
     // the rows' own scalars live in LDS (a register pair each would stay live for the whole solve)
     if (lane == 0) {
         sm[oOWN + 0 * RES_WAVES + w] = D.L1.diag[rF];
@@ -378,16 +397,24 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         sm[oOWN + 5 * RES_WAVES + w] = bvec[rC];
         sm[oOWN + 6 * RES_WAVES + w] = D.L2.diag[r2];
         sm[oOWN + 7 * RES_WAVES + w] = D.L2.dinv[r2];
-        rowp[8 * w + 0] = D.Pt2.rp[r2];
-        rowp[8 * w + 1] = v2 ? D.Pt2.rp[r2 + 1] - D.wident : D.Pt2.rp[r2];
-        rowp[8 * w + 2] = D.P2.rp[rF];
-        rowp[8 * w + 3] = vF ? D.P2.rp[rF + 1] : D.P2.rp[rF];
-        rowp[8 * w + 4] = D.P2.rp[rC];
-        rowp[8 * w + 5] = vC ? D.P2.rp[rC + 1] : D.P2.rp[rC];
-        // remote tail: row b + G*w of P3' (restriction to level 3), if there is one
-        const int r3 = b + G * w;
-        rowp[8 * w + 6] = (D.remote && r3 < Nt) ? D.Pt3.rp[r3] : 0;
-        rowp[8 * w + 7] = (D.remote && r3 < Nt) ? D.Pt3.rp[r3 + 1] : 0;
+        sm[oOWN + 8 * RES_WAVES + w] = THREE ? D.L3.diag[r3] : 0.0;
+        sm[oOWN + 9 * RES_WAVES + w] = THREE ? D.L3.dinv[r3] : 0.0;
+        rowp[12 * w + 0] = D.Pt2.rp[r2];
+        rowp[12 * w + 1] = v2 ? D.Pt2.rp[r2 + 1] - D.wident : D.Pt2.rp[r2];
+        rowp[12 * w + 2] = D.P2.rp[rF];
+        rowp[12 * w + 3] = vF ? D.P2.rp[rF + 1] : D.P2.rp[rF];
+        rowp[12 * w + 4] = D.P2.rp[rC];
+        rowp[12 * w + 5] = vC ? D.P2.rp[rC + 1] : D.P2.rp[rC];
+        // remote tail: row b + G*w of the restriction to its root level, if there is one
+        const int rin = b + G * w;
+        const ResCsr& Pin = D.tail_root == 4 ? D.Pt4 : D.Pt3;
+        rowp[12 * w + 6] = (D.remote && rin < Nt) ? Pin.rp[rin] : 0;
+        rowp[12 * w + 7] = (D.remote && rin < Nt) ? Pin.rp[rin + 1] : 0;
+        // third resident level: its own row of P3' (restriction 2 -> 3), this wave's level-2 row of P3
+        rowp[12 * w + 8] = v3 ? D.Pt3.rp[r3] : 0;
+        rowp[12 * w + 9] = v3 ? D.Pt3.rp[r3 + 1] : 0;
+        rowp[12 * w + 10] = (THREE && v2) ? D.P3.rp[r2] : 0;
+        rowp[12 * w + 11] = (THREE && v2) ? D.P3.rp[r2 + 1] : 0;
     }
 #define dgF sm[oOWN + 0 * RES_WAVES + w]
 #define dvF sm[oOWN + 1 * RES_WAVES + w]
@@ -397,8 +424,11 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 #define bC sm[oOWN + 5 * RES_WAVES + w]
 #define dg2 sm[oOWN + 6 * RES_WAVES + w]
 #define dv2 sm[oOWN + 7 * RES_WAVES + w]
+#define dg3 sm[oOWN + 8 * RES_WAVES + w]
+#define dv3 sm[oOWN + 9 * RES_WAVES + w]
     const bool nsp = D.isnsp != 0;
     const double xx1 = nsp ? D.L1.xx[0] : 1.0, xx2 = nsp ? D.L2.xx[0] : 1.0;
+    const double xx3 = (THREE && nsp) ? D.L3.xx[0] : 1.0;
     for (int j = tid; j < N1; j += BT) {
         sm[oX + j] = xg[j];
         sm[oE1 + j] = 0.0;
@@ -408,6 +438,11 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         sm[oE2 + j] = 0.0;
         sm[oAX2 + j] = D.L2.Axi[j];
     }
+    if (THREE)
+        for (int j = tid; j < N3; j += BT) {
+            sm[oE3L + j] = 0.0;
+            sm[oAX3L + j] = D.L3.Axi[j];
+        }
     // One-row tail (the dense regimes): its transfer operator is one column, kept densely in the
     // unused upper half of the RR2 slot (restriction and prolongation use the same numbers), and
     // its operator is one number: the tail then costs two LDS passes instead of five dependent
@@ -419,10 +454,12 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // inverse diagonals of the F rows of level 1 and of level 2 sit in the unused upper halves of
     // the R2 / E2 slots (same condition as tail1's column: at most RES_NMAX / 2 rows).
     const bool lfirst = D.localfirst && D.nu >= 1 && N2 <= RES_NMAX / 2 && nf <= RES_NMAX / 2;
+    const bool lfirst2 = lfirst && !THREE;   // (DV2 shares the upper half of the E2 slot with E3)
     constexpr int oDV1 = oR2 + RES_NMAX / 2, oDV2 = oE2 + RES_NMAX / 2;
     if (lfirst) {
         for (int j = tid; j < nf; j += BT) sm[oDV1 + j] = D.L1.dinv[j];
-        for (int j = tid; j < N2; j += BT) sm[oDV2 + j] = D.L2.dinv[j];
+        if (lfirst2)
+            for (int j = tid; j < N2; j += BT) sm[oDV2 + j] = D.L2.dinv[j];
     }
     double h33 = 0.0;
     if (tail1) {
@@ -613,43 +650,50 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     const auto rtin = __builtin_amdgcn_make_buffer_rsrc(D.tin, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
     const auto rtout = __builtin_amdgcn_make_buffer_rsrc(D.tout, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
     unsigned tseq = 0;      // number of the last visit of the remote tail
+    // Remote tail: the residual of the level above the tail's root (LDS offset oRRs) is restricted row
+    // by row -- row i of the restriction by wave i / G of workgroup i % G (Nt <= BT <= 8 G rows) --
+    // straight into the tail workgroup's inbox; then everybody waits for the prolongated correction
+    // (Nout granules) and finishes e += P e_tail on its copy (offsets oEd, oRd, oAXd), with the scalar
+    // of the next sweep.
+    auto remote_tail = [&](const ResCsr& Pin, int oRRs, int oEd, int oRd, int oAXd, double xxd, int Nout,
+                           double& cnext) __attribute__((always_inline)) {
+        ++tseq;
+        const int rin = b + G * w;
+        if (rin < Nt) {
+            const double s3 = res_csr_rowdot(Pin, rowp[12 * w + 6], rowp[12 * w + 7], lane, sm, oRRs);
+            if (lane == 0)
+                __builtin_amdgcn_raw_buffer_store_b128(res_pack(s3, tseq), rtin,
+                                                       (int)(tseq & 1) * (RES_GRAN_MAX * 16) + rin * 16, 0,
+                                                       16 /* sc1 */);
+        }
+        double hv[4];
+        int st = 0;
+        if (!dead) st = res_wait_slow<4>(rtout, tseq, Nout, D.tmo, nullptr, hv);
+        if (st) {
+            *fail = 1;
+            if (lane == 0) __hip_atomic_store(D.tmo, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        double p0 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = tid + u * BT;
+            if (j < Nout && !dead && !st) {
+                const double en = sm[oEd + j] + hv[u];
+                sm[oEd + j] = en;
+                p0 += sm[oRd + j] - sm[oAXd + j] * en;
+            }
+        }
+        if (nsp) {
+            p0 = wave_sum(p0);
+            if (lane == 0) red[w] = p0;
+        }
+        __syncthreads();
+        if (nsp) cnext = res_red8(red) / xxd;
+        if (*fail) dead = true;
+    };
     auto tail = [&]() __attribute__((always_inline)) {
         if (D.remote) {
-            // r_3 = P3' rr_2: row i by wave i / G of workgroup i % G (Nt <= BT <= 8 G rows), straight
-            // into the tail workgroup's inbox; then everybody waits for P3 e_3 and finishes e_2 += P e_3
-            ++tseq;
-            const int r3 = b + G * w;
-            if (r3 < Nt) {
-                const double s3 = res_csr_rowdot(D.Pt3, rowp[8 * w + 6], rowp[8 * w + 7], lane, sm, oRR2);
-                if (lane == 0)
-                    __builtin_amdgcn_raw_buffer_store_b128(res_pack(s3, tseq), rtin,
-                                                           (int)(tseq & 1) * (RES_GRAN_MAX * 16) + r3 * 16, 0,
-                                                           16 /* sc1 */);
-            }
-            double hv[4];
-            int st = 0;
-            if (!dead) st = res_wait_slow<4>(rtout, tseq, N2, D.tmo, nullptr, hv);
-            if (st) {
-                *fail = 1;
-                if (lane == 0) __hip_atomic_store(D.tmo, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            double p0 = 0.0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = tid + u * BT;
-                if (j < N2 && !dead && !st) {
-                    const double en = sm[oE2 + j] + hv[u];
-                    sm[oE2 + j] = en;
-                    p0 += sm[oR2 + j] - sm[oAX2 + j] * en;
-                }
-            }
-            if (nsp) {
-                p0 = wave_sum(p0);
-                if (lane == 0) red[w] = p0;
-            }
-            __syncthreads();
-            if (nsp) c2s = res_red8(red) / xx2;
-            if (*fail) dead = true;
+            remote_tail(D.Pt3, oRR2, oE2, oR2, oAX2, xx2, N2, c2s);
             return;
         }
         if (tail1) {
@@ -760,10 +804,57 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         if (nsp) c2s = res_red8(red) / xx2;
     };
 
+    // ---- third resident level (THREE): Jacobi like level 2, N3 <= BT rows dealt in contiguous runs to the
+    // workgroups (0-4 rows each).  A workgroup without a row still has to say that it has finished a
+    // step (the two-buffer protocol lets a buffer be rewritten once everybody has published the step in
+    // between), so every workgroup publishes one extra "ack" granule, N3 + b, with its rows.
+    double c3s = 0.0;
+#define RES_HANDOFF3(STORE3, want_sums, t0)                                                              \
+    do {                                                                                                 \
+        if (w == 0 && lane == 0) sm[oPUB + RES_WAVES] = 0.0;                                             \
+        RES_HANDOFF(2, N3 + G, lo3, hi3 - lo3, N3 + b, 1, { if (j < N3) { STORE3; } }, {}, want_sums, t0, dum1); \
+    } while (0)
+    auto sweep3 = [&](bool ezero) __attribute__((always_inline)) {
+        if (THREE) {
+            double s = 0.0, eo = 0.0;
+            if (!ezero) {
+                s = wave_sum(res_rowdot<K3, 8 * oE3L>(c3, a3, smb));
+                eo = sm[oE3L + r3];
+                s += dg3 * eo;
+            }
+            const double g_i = sm[oR3L + r3] - s - sm[oAX3L + r3] * c3s;
+            const double wv = eo + dv3 * g_i;
+            if (lane == 0) sm[oPUB + w] = wv;
+            const double cc = c3s;
+            double xig = 0.0;
+            RES_HANDOFF3({
+                             const double en = v + cc;
+                             sm[oE3L + j] = en;
+                             p0 += sm[oR3L + j] - sm[oAX3L + j] * en;
+                         },
+                         (nsp ? 1 : 0), xig);
+            c3s = nsp ? xig / xx3 : 0.0;
+        }
+    };
+    // one visit of level 3 and, through the remote tail rooted at level 4, of everything below it
+    auto visit3 = [&](bool keep) __attribute__((always_inline)) {
+        if (THREE) {
+            const int nu = D.nu;
+            for (int s = 0; s < nu; ++s) sweep3(!keep && s == 0);
+            {   // rr = r - A e                                                       MG_Vcycle.m:27
+                const double s = wave_sum(res_rowdot<K3, 8 * oE3L>(c3, a3, smb)) + dg3 * sm[oE3L + r3];
+                if (lane == 0) sm[oPUB + w] = sm[oR3L + r3] - s;
+                RES_HANDOFF3({ sm[oRR3L + j] = v; }, 0, dum0);
+            }
+            remote_tail(D.Pt4, oRR3L, oE3L, oR3L, oAX3L, xx3, N3, c3s);
+            for (int s = 0; s < nu; ++s) sweep3(false);
+        }
+    };
+
     // one visit of level 2 and everything below it
     auto visit2 = [&](bool keep) __attribute__((always_inline)) {
         const int nu = D.nu;
-        for (int s = (lfirst && !keep) ? 1 : 0; s < nu; ++s) sweep2(!keep && s == 0);
+        for (int s = (lfirst2 && !keep) ? 1 : 0; s < nu; ++s) sweep2(!keep && s == 0);
         // rr = r - A e                                                           MG_Vcycle.m:27
         {
             const double s = wave_sum(res_rowdot<KE2, 8 * oE2>(c2, a2, smb)) + dg2 * sm[oE2 + r2];
@@ -771,7 +862,26 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
             RES_HANDOFF(4, N2, lo2, hi2 - lo2, 0, 0, { sm[oRR2 + j] = v; }, {}, 0, dum0, dum1);
         }
         if (dbg) dbg_acc[7] -= __builtin_amdgcn_s_memtime();
-        tail();
+        if (THREE) {
+            {   // r_3 = P3' rr_2 ; E3 := 0 ; c for the zero start
+                const double s = res_csr_rowdot(D.Pt3, rowp[12 * w + 8], rowp[12 * w + 9], lane, sm, oRR2);
+                if (lane == 0) sm[oPUB + w] = s;
+                double sumr = 0.0;
+                RES_HANDOFF3({ sm[oR3L + j] = v; sm[oE3L + j] = 0.0; p0 += v; }, (nsp ? 1 : 0), sumr);
+                c3s = nsp ? sumr / xx3 : 0.0;
+            }
+            for (int leg = 0; leg < (D.wcycle ? 2 : 1); ++leg) visit3(leg == 1);   // MG_Wcycle.m:28-30
+            {   // e_2 += P3 e_3                                                     MG_Vcycle.m:31
+                const double sP = res_csr_rowdot(D.P3, rowp[12 * w + 10], rowp[12 * w + 11], lane, sm, oE3L);
+                if (lane == 0) sm[oPUB + w] = sm[oE2 + r2] + sP;
+                double xig = 0.0;
+                RES_HANDOFF(4, N2, lo2, hi2 - lo2, 0, 0,
+                            { sm[oE2 + j] = v; p0 += sm[oR2 + j] - sm[oAX2 + j] * v; }, {}, (nsp ? 1 : 0), xig, dum1);
+                c2s = nsp ? xig / xx2 : 0.0;
+            }
+        } else {
+            tail();
+        }
         if (dbg) dbg_acc[7] += __builtin_amdgcn_s_memtime();
         for (int s = 0; s < nu; ++s) sweep2(false);
     };
@@ -792,7 +902,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         {   // r_2 = P' rr ; E2 := 0 ; c for the zero start
             if (dbg) dbg_acc[6] -= __builtin_amdgcn_s_memtime();
             // row r2 of P' is [W(:,r2)' , 1 at nf + r2]; rowC == nf + row2 (level 2 = the C nodes)
-            const double s = res_csr_rowdot(D.Pt2, rowp[8 * w + 0], rowp[8 * w + 1], lane, sm, oRR1) +
+            const double s = res_csr_rowdot(D.Pt2, rowp[12 * w + 0], rowp[12 * w + 1], lane, sm, oRR1) +
                              (D.wident ? sm[oRR1 + rC] : 0.0);
             if (dbg) dbg_acc[6] += __builtin_amdgcn_s_memtime();
             if (lane == 0) sm[oPUB + w] = s;
@@ -800,7 +910,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
             RES_HANDOFF(4, N2, lo2, hi2 - lo2, 0, 0, { sm[oR2 + j] = v; sm[oE2 + j] = 0.0; p0 += v; }, {},
                         (nsp ? 1 : 0), sumr, dum1);
             c2s = nsp ? sumr / xx2 : 0.0;
-            if (lfirst) {   // sweep2(true) of the first visit, same thread-to-entry map and sums
+            if (lfirst2) {   // sweep2(true) of the first visit, same thread-to-entry map and sums
                 const double cc = c2s;
                 double p0 = 0.0;
                 for (int j = tid; j < N2; j += BT) {
@@ -822,9 +932,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         {   // e_1 += P e_2                                                        MG_Vcycle.m:31
             if (dbg) dbg_acc[6] -= __builtin_amdgcn_s_memtime();
             // F rows: W(rowF,:) against E2 (A's columns nf + i are level-2 indices i); C rows: identity
-            const double sF = res_csr_rowdot(D.P2, rowp[8 * w + 2], rowp[8 * w + 3], lane, sm, oE2);
+            const double sF = res_csr_rowdot(D.P2, rowp[12 * w + 2], rowp[12 * w + 3], lane, sm, oE2);
             const double sC = D.wident ? sm[oE2 + r2]
-                                       : res_csr_rowdot(D.P2, rowp[8 * w + 4], rowp[8 * w + 5], lane, sm, oE2);
+                                       : res_csr_rowdot(D.P2, rowp[12 * w + 4], rowp[12 * w + 5], lane, sm, oE2);
             if (dbg) dbg_acc[6] += __builtin_amdgcn_s_memtime();
             if (lane == 0) {
                 sm[oPUB + w] = sm[oE1 + rF] + sF;
@@ -920,6 +1030,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         D.dbg[7] = dbg_acc[6];
         D.dbg[8] = dbg_acc[7];
     }
+#undef RES_HANDOFF3
 #undef RES_HANDOFF
 #undef dgF
 #undef dvF
@@ -929,4 +1040,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 #undef bC
 #undef dg2
 #undef dv2
+#undef dg3
+#undef dv3
 }
