@@ -1865,6 +1865,19 @@ extern "C" int ipd_amg_cycle_bytes(const ipd_amg* h, double* bytes_per_cycle) {
     return IPD_OK;
 }
 
+// Mode 2 only: how many levels the resident workgroups keep in registers (2 or 3) and the level
+// the tail is rooted at (3: the local tail of a three-level hierarchy or the remote tail workgroup's
+// sub-cycle root; 4: remote tail below a resident level 3); zeros otherwise.
+extern "C" int ipd_amg_resident_levels(const ipd_amg* h, int32_t* levels, int32_t* tail_root) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h, IPD_E_ARG, "NULL handle");
+        const CycleState* st = h->cyc.get();
+        const bool on = st && st->res_ok;
+        if (levels) *levels = on ? (st->res_ke3 > 0 ? 3 : 2) : 0;
+        if (tail_root) *tail_root = on ? (st->res_ke3 > 0 ? 4 : 3) : 0;
+    });
+}
+
 extern "C" int ipd_amg_solve_mode(const ipd_amg* h, int32_t* mode, int32_t* grid, int32_t* timeouts) {
     if (!h || !mode) return IPD_E_ARG;
     const CycleState* st = h->cyc.get();

@@ -403,6 +403,9 @@ int ipd_amg_cycle_bytes(const ipd_amg* h, double* bytes_per_cycle);
  * one workgroup's LDS -- then *grid counts that tail workgroup too); *timeouts = launches of mode 2
  * that gave up and were redone in mode 0.                                                      */
 int ipd_amg_solve_mode(const ipd_amg* h, int32_t* mode, int32_t* grid, int32_t* timeouts);
+/* Mode 2 only: *levels = levels kept in the registers of the resident workgroups (2 or 3),
+ * *tail_root = level at which the rest starts (3, or 4 below a resident level 3); zeros otherwise. */
+int ipd_amg_resident_levels(const ipd_amg* h, int32_t* levels, int32_t* tail_root);
 /* Mode 2 only: `cycles` loop bodies in one launch with in-kernel stamps of workgroup 0:
  * stamps[0] shader clocks spent waiting in hand-off sweeps, [1] shader clocks of the launch,
  * [2] hand-offs, [3] 100 MHz ticks of the launch, [4] clocks in the barrier ahead of the

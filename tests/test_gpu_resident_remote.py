@@ -27,12 +27,14 @@ def ipd():
     return m
 
 
-@pytest.fixture(scope="module", params=[20, 30], ids=["k21-semi-root", "k31"])
+@pytest.fixture(scope="module", params=[9, 20, 30], ids=["k10-long-level3", "k21-semi-root", "k31"])
 def newton_system(ipd, request):
-    """Ae, f of the Newton step the device driver reaches after 20 / 30 APD iterations: at k = 21
-    level 3 (about 310 rows, 2 k entries) does not fit the LDS image beside the deeper levels and is
-    its semi-cached root (vectors in LDS, rows from L2), at k = 31 everything from level 3 down fits."""
+    """Ae, f of the Newton step the device driver reaches after 9 / 20 / 30 APD iterations: at k = 10
+    level 3 (about 260 rows of 60 entries) is far too big for the tail's LDS, at k = 21 (about 310
+    rows, 2 k entries) it would only be its semi-cached root -- both keep level 3 in registers with the
+    tail rooted at level 4 -- and at k = 31 everything from level 3 down fits the tail's LDS image."""
     N, kcap = 1024, request.param
+    want = {9: 3, 20: 3, 30: 2}[kcap]      # levels expected in the resident workgroups' registers
     rs = np.random.RandomState(1)
     c, r, l = rs.random_sample(N * N), rs.random_sample(N), rs.random_sample(N)
     l = l * r.sum() / l.sum()
@@ -53,13 +55,13 @@ def newton_system(ipd, request):
     if ncomp > 1:      # Hybrid_AMG.m:55-70: the large component, F side (indices < n) first
         pk = np.flatnonzero(lab == np.argmax(np.bincount(lab)))
         assert len(pk) > 1500
-        return sp.csr_matrix(Ae[pk, :][:, pk]), f[pk], int((pk < N).sum())
-    return Ae, f, N
+        return sp.csr_matrix(Ae[pk, :][:, pk]), f[pk], int((pk < N).sum()), want
+    return Ae, f, N, want
 
 
 @pytest.mark.parametrize("cycle", ["v", "w"])
 def test_remote_tail_matches_the_multi_launch_path(ipd, newton_system, cycle):
-    Ae, f, n = newton_system
+    Ae, f, n, want_levels = newton_system
     x0 = np.zeros(Ae.shape[0])
     h = ipd.AMGHierarchy(Ae, options(cycle, n), ipd.MatlabRand(5489))
     mode, grid, _ = solve_mode(h)
@@ -68,6 +70,11 @@ def test_remote_tail_matches_the_multi_launch_path(ipd, newton_system, cycle):
         pytest.skip("hierarchy %s not taken by the resident kernel (level 3 does not fit the "
                     "sub-cycle's LDS image, or rows are not padded)" % h.level_sizes())
     assert grid == -(-max(n, Ae.shape[0] - n) // 8) + 1       # 8 rows of each block per workgroup + the tail
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    lev, root = c_int32(), c_int32()
+    _lib.check(_lib.lib.ipd_amg_resident_levels(h.handle, byref(lev), byref(root)))
+    assert (lev.value, root.value) in ((2, 3), (3, 4))
+    assert lev.value == want_levels, (lev.value, want_levels, h.level_sizes())
     with env(IPD_NO_RESIDENT_REMOTE=1):
         hc = ipd.AMGHierarchy(Ae, options(cycle, n), ipd.MatlabRand(5489))
     assert solve_mode(hc)[0] == 0 and hc.level_sizes() == h.level_sizes()
