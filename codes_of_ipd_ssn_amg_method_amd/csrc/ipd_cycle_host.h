@@ -178,8 +178,21 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     const Level& l1 = h->L[1];
     const Level& l2 = h->L[2];
     const Level& l3 = h->L[3];
-    const LevelDev& d1 = st->run[1].dev;
-    const LevelDev& d2 = st->run[2].dev;
+    // Rows live in registers: the padded stride is only a layout here, so a level whose rows are too
+    // uneven for the launches' padded copy (hubs) gets a private copy with its longest row as stride
+    // (built below, once the hierarchy is known to be taken).  d1 / d2 carry the stride either way.
+    LevelDev d1 = st->run[1].dev;
+    LevelDev d2 = st->run[2].dev;
+    const bool nopriv = std::getenv("IPD_NO_RESIDENT_PRIVPAD") && std::getenv("IPD_NO_RESIDENT_PRIVPAD")[0] == '1';
+    bool priv1 = false, priv2 = false;
+    if (d1.S <= 0 && st->run[1].maxoff > 0 && !nopriv) {
+        d1.S = (st->run[1].maxoff + 3) / 4 * 4;
+        priv1 = true;
+    }
+    if (d2.S <= 0 && st->run[2].maxoff > 0 && !nopriv) {
+        d2.S = (st->run[2].maxoff + 3) / 4 * 4;
+        priv2 = true;
+    }
     const int N1 = l1.A.nr, N2 = l2.A.nr, Nt = l3.A.nr, nf = l1.nf, nc = N1 - nf;
     if (const char* dbg = std::getenv("IPD_DEBUG_LEVELS"); dbg && dbg[0] == '1')
         std::fprintf(stderr, "[ipd] resident plan: J=%d nf=%d nc=%d S1=%d S2=%d S3=%d N4=%d Nt=%d k_sub=%d sub_lds=%zu\n", h->J,
@@ -259,6 +272,19 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
         c.va = m.va;
         return c;
     };
+    auto private_pad = [&](const Csr& A, LevelDev& d) {   // k_pad_build with stride d.S
+        unsigned short* pci = ar.alloc<unsigned short>((size_t)A.nr * d.S);
+        double* pva = ar.alloc<double>((size_t)A.nr * d.S);
+        double* dg = ar.alloc<double>((size_t)A.nr);
+        hipLaunchKernelGGL(k_pad_build, dim3(std::max(1, std::min(cdiv(A.nr, 4), 4096))), dim3(256), 0,
+                           h->ctx->stream, A.nr, d.S, A.rp, A.ci, A.va, pci, pva, dg);
+        IPD_KERNEL_CHECK();
+        d.pci = pci;
+        d.pva = pva;
+        d.diag = dg;
+    };
+    if (priv1) private_pad(l1.A, d1);
+    if (priv2) private_pad(l2.A, d2);
     D.L1 = lev(d1);
     D.L2 = lev(d2);
     D.Pt2 = csr(l2.Pt);
@@ -271,19 +297,9 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     D.tail_root = three ? 4 : 3;
     if (three) {
         LevelDev d3 = st->run[3].dev;
-        if (d3.S <= 0) {   // private padded copy of level 3 (k_pad_build), stride = its longest row
-            const Csr& A3 = l3.A;
-            const int S3 = (st->run[3].maxoff + 3) / 4 * 4;
-            unsigned short* pci = ar.alloc<unsigned short>((size_t)A3.nr * S3);
-            double* pva = ar.alloc<double>((size_t)A3.nr * S3);
-            double* dg = ar.alloc<double>((size_t)A3.nr);
-            hipLaunchKernelGGL(k_pad_build, dim3(std::max(1, std::min(cdiv(A3.nr, 4), 4096))), dim3(256), 0,
-                               h->ctx->stream, A3.nr, S3, A3.rp, A3.ci, A3.va, pci, pva, dg);
-            IPD_KERNEL_CHECK();
-            d3.S = S3;
-            d3.pci = pci;
-            d3.pva = pva;
-            d3.diag = dg;
+        if (d3.S <= 0) {   // private padded copy of level 3, stride = its longest row
+            d3.S = (st->run[3].maxoff + 3) / 4 * 4;
+            private_pad(l3.A, d3);
         }
         D.L3 = lev(d3);
         D.Pt4 = csr(h->L[4].Pt);
