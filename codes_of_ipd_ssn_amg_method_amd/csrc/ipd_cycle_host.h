@@ -45,6 +45,8 @@ struct CycleState {
     bool sub_semi_root = false;    // d_sub's root level is semi-cached (rows from L2)
     SolveDesc* d_sub4 = nullptr;   // image rooted at level 4 for the resident kernel's `three` mode
     size_t sub4_lds = 0;           // (packed beside d_sub when that one is rooted at level 3)
+    SolveDesc* d_sub3 = nullptr;   // image rooted at level 3 for the resident kernel alone (k_sub == 0)
+    size_t sub3_lds = 0;
     int k_sub = 0;
     size_t sub_lds = 0;
     double* x2 = nullptr;
@@ -210,14 +212,15 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     if (!local_tail) {
         const char* nr = std::getenv("IPD_NO_RESIDENT_REMOTE");
         const bool cyc = h->opts.cycle == 'w' || h->opts.cycle == 'v';
-        remote = !(nr && nr[0] == '1') && h->J >= 4 && st->k_sub == 3 && st->d_sub && Nt <= BT && cyc;
+        remote = !(nr && nr[0] == '1') && h->J >= 4 && Nt <= BT && cyc &&
+                 ((st->k_sub == 3 && st->d_sub) || (st->k_sub == 0 && st->d_sub3));
         // Level 3 in the registers of the resident workgroups as well, the tail rooted at level 4: for
         // a level 3 too big for the tail's LDS (a few hundred rows of 15-100 entries), and preferred to
         // the tail rooted at level 3 whenever an image rooted at level 4 exists (the tail's legs are the
         // serial part of a cycle: ~22 us each from level 4, ~100 us from level 3).
         const char* n3 = std::getenv("IPD_NO_RESIDENT_THREE");
-        tail_img = st->d_sub;
-        tail_lds = st->sub_lds;
+        tail_img = st->k_sub == 0 ? st->d_sub3 : st->d_sub;
+        tail_lds = st->k_sub == 0 ? st->sub3_lds : st->sub_lds;
         const bool img4 = (st->k_sub == 4 && st->d_sub) || (st->k_sub == 3 && st->d_sub4);
         if (!(nr && nr[0] == '1') && !(n3 && n3[0] == '1') && h->J >= 5 && img4 && cyc) {
             // (its rows are usually too uneven for the launches' padded copy -- hubs -- but in registers
@@ -1045,6 +1048,32 @@ void amg_prepare_levels(ipd_amg* h) {
             sd->root_r = h->L[4].r;
             sd->root_e = h->L[4].e;
             st->d_sub4 = build_image(sd.get(), 4, stage, &st->sub4_lds);
+        }
+    }
+    // (b3) No sub-cycle at all because level 3's interpolation is big (P_3 with more than 40 k entries:
+    // a dense 1024 x 50 block early in a run), although levels 3..J themselves are small: the launch
+    // path would gain nothing from an image whose restriction and prolongation stay launches, but the
+    // resident kernel's remote tail does not use P_3 from the image -- its workgroups apply it -- so an
+    // image rooted at level 3 is packed for it alone.
+    if (st->k_sub == 0 && !st->small_ok && h->J >= 4 && h->J <= SOLVE_ML && lean_vectors && h->L[3].A.nr <= BT &&
+        h->L[1].nf > 0 && (h->opts.cycle == 'w' || h->opts.cycle == 'v') &&
+        !(std::getenv("IPD_NO_RESIDENT") && std::getenv("IPD_NO_RESIDENT")[0] == '1') &&
+        !(std::getenv("IPD_NO_SUBCYCLE") && std::getenv("IPD_NO_SUBCYCLE")[0] == '1')) {
+        bool ok = true;
+        for (int k = 3; k <= h->J && ok; ++k)
+            ok = h->L[k].A.nr <= 1024 && h->L[k].A.nnz <= 40000 && (k == 3 || h->L[k].P.nnz <= 40000);
+        const size_t stage = 16;
+        size_t used = 0;
+        if (ok && plan_lds(stage, &used) <= 3) {
+            std::unique_ptr<SolveDesc> sd(new SolveDesc());
+            fill_desc(sd.get());
+            sd->k_lds = 3;
+            sd->k_tiny = tiny_from(3);
+            sd->k_blk = blk_from(3);
+            sd->stage_bytes = (int)stage;
+            sd->root_r = h->L[3].r;
+            sd->root_e = h->L[3].e;
+            st->d_sub3 = build_image(sd.get(), 3, stage, &st->sub3_lds);
         }
     }
     // (c) realistic hierarchies whose levels 1-2 are too big for (a) and too small to need many
