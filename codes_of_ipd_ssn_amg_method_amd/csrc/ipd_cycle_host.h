@@ -237,7 +237,19 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
                 }
             }
         }
-        if (!remote) return;
+        // Four levels with a level 3 too big for any LDS image and a coarsest level of at most 64 rows
+        // (dense masks early in a run, the bench's tree / hub masks): level 3 resident, level 4 solved
+        // by every workgroup as the local tail -- no tail workgroup.
+        if (!remote && !(nr && nr[0] == '1') && !(n3 && n3[0] == '1') && h->J == 4 && cyc &&
+            h->L[4].A.nr <= RES_TAIL_MAX) {
+            const int S3 = st->run[3].dev.S > 0 ? st->run[3].dev.S : (st->run[3].maxoff + 3) / 4 * 4;
+            if (S3 > 0 && S3 <= 512 && Nt <= BT && N2 <= RES_NMAX / 2 && std::max(d1.S, d2.S) <= 512 &&
+                Nt + std::max(cdiv(std::max(nf, nc), RES_WAVES), cdiv(N2, RES_WAVES)) <= 2 * BT) {
+                three = true;
+                ke3 = S3 <= 256 ? 4 : 8;
+            }
+        }
+        if (!remote && !three) return;
     }
     const int smax = std::max(d1.S, d2.S);
     int ke = 4;
@@ -248,7 +260,7 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     if (const char* e = std::getenv("IPD_RESIDENT_G")) G = std::max(G, std::atoi(e));
     // every workgroup owns at least one row of every block (the hand-off protocol needs it)
     if (G + (remote ? 1 : 0) > st->num_cu || G > std::min(std::min(nf, nc), N2)) return;
-    const int Nin = three ? h->L[4].A.nr : Nt;   // rows of the remote tail's root level
+    const int Nin = three ? h->L[4].A.nr : Nt;   // rows of the remote tail's root level / of the local tail
     if (remote && Nin > RES_WAVES * G) return;   // one row of the restriction to it per wave
     if (three && Nt + G > 2 * BT) return;        // level-3 hand-offs: N3 + G granules, two per thread
     const size_t lds = remote ? std::max<size_t>(RES_LDS_BYTES, tail_lds) : RES_LDS_BYTES;
@@ -298,6 +310,7 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     D.Nt = Nin;
     D.three = three ? 1 : 0;
     D.tail_root = three ? 4 : 3;
+    D.A4 = csr(three ? h->L[4].A : l3.A);
     if (three) {
         LevelDev d3 = st->run[3].dev;
         if (d3.S <= 0) {   // private padded copy of level 3, stride = its longest row

@@ -65,6 +65,7 @@ struct ResDesc {
     ResCsr Pt3, P3;   // level 2 <-> 3 (the tail level of a three-level hierarchy)
     ResCsr Pt4, P4;   // level 3 <-> 4 (`three` only: the remote tail is rooted at level 4)
     ResCsr A3;        // tail operator (CSR), local tail only
+    ResCsr A4;        // ... when level 3 is resident too and level 4 is the (local) tail
     int three;        // levels 1-3 resident (hierarchies whose level 3 does not fit the tail's LDS)
     int tail_root;    // remote tail: 3 or 4
     // Remote tail (hierarchies with more than three levels): workgroup gridDim.x - 1 holds the LDS
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // unused upper half of the RR2 slot (restriction and prolongation use the same numbers), and
     // its operator is one number: the tail then costs two LDS passes instead of five dependent
     // trips to L2 per visit.
-    const bool tail1 = Nt == 1 && N2 <= RES_NMAX / 2;
+    const bool tail1 = !THREE && Nt == 1 && N2 <= RES_NMAX / 2;
     constexpr int oP3C = oRR2 + RES_NMAX / 2;
     // First sweep of a visit (zero start): e = D^-1 (r - (A 1) c) needs no matrix row, so every
     // workgroup forms ALL its entries itself from the r it has just received -- no hand-off.  The
@@ -691,6 +692,82 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         if (nsp) cnext = res_red8(red) / xxd;
         if (*fail) dead = true;
     };
+    // Local tail (at most 64 rows, solved redundantly by every workgroup on its own LDS copies, so no
+    // hand-off): restriction of the level above (residual at oRRs), Jacobi-PCG (PCG.m:68-87, zero
+    // guess), prolongation into the level above (oEd, with oRd / oAXd for the next scalar).
+    auto local_tail = [&](const ResCsr& PtT, const ResCsr& AT, const ResCsr& PT, int oRRs, int oEd, int oRd,
+                          int oAXd, double xxd, int Nabove, double& cnext) __attribute__((always_inline)) {
+        if (Nt == 1) {
+            // one row: its entries are dealt to all the waves, the eight partial sums are added in
+            // wave order (a single wave walking 1024 entries took four dependent trips)
+            const int e0 = PtT.rp[0], e1 = PtT.rp[1];
+            double s = 0.0;
+            for (int t = e0 + tid; t < e1; t += BT * 2) {
+                const int t1 = t + BT;
+                const int ja = PtT.ci[t], jb = PtT.ci[t1 < e1 ? t1 : e0];
+                const double aa = PtT.va[t], ab = PtT.va[t1 < e1 ? t1 : e0];
+                s += aa * sm[oRRs + ja];
+                s += t1 < e1 ? ab * sm[oRRs + jb] : 0.0;
+            }
+            s = wave_sum(s);
+            if (lane == 0) red[w] = s;
+            __syncthreads();
+            if (tid == 0) sm[oR3] = res_red8(red);
+        } else {
+            for (int i = w; i < Nt; i += RES_WAVES) {
+                const double s = res_csr_rowdot(PtT, PtT.rp[i], PtT.rp[i + 1], lane, sm, oRRs);
+                if (lane == 0) sm[oR3 + i] = s;
+            }
+        }
+        __syncthreads();
+        if (w == 0) {
+            const int i = lane < Nt ? lane : 0;
+            const bool valid = lane < Nt;
+            const int e0 = AT.rp[i], e1 = AT.rp[i + 1];
+            double dd = 0.0;
+            for (int t = e0; t < e1; ++t)
+                if (AT.ci[t] == i) dd = AT.va[t];
+            double r = valid ? sm[oR3 + i] : 0.0;
+            double p = valid ? r / dd : 0.0;
+            double d = 0.0;
+            double delta_new = wave_sum(valid ? r * p : 0.0);
+            const double thresh = 1e-11 * 1e-11 * delta_new;
+            long long it = 0;
+            while (it < D.pcg_maxit && delta_new > thresh) {
+                const double delta_old = delta_new;
+                if (valid) sm[oP3 + i] = p;
+                tiny_sync();
+                double q = 0.0;
+                if (valid)
+                    for (int t = e0; t < e1; ++t) q += AT.va[t] * sm[oP3 + AT.ci[t]];
+                tiny_sync();
+                const double qp = wave_sum(valid ? q * p : 0.0);
+                const double alpha = delta_old / qp;
+                d += alpha * p;
+                r = r - alpha * q;
+                const double wi = valid ? r / dd : 0.0;
+                delta_new = wave_sum(valid ? r * wi : 0.0);
+                p = wi + (delta_new / delta_old) * p;
+                ++it;
+            }
+            if (valid) sm[oE3 + i] = d;
+        }
+        __syncthreads();
+        double p0 = 0.0;
+        for (int j = tid; j < Nabove; j += BT) {
+            double s = 0.0;
+            for (int t = PT.rp[j]; t < PT.rp[j + 1]; ++t) s += PT.va[t] * sm[oE3 + PT.ci[t]];
+            const double en = sm[oEd + j] + s;
+            sm[oEd + j] = en;
+            p0 += sm[oRd + j] - sm[oAXd + j] * en;
+        }
+        if (nsp) {
+            p0 = wave_sum(p0);
+            if (lane == 0) red[w] = p0;
+        }
+        __syncthreads();
+        if (nsp) cnext = res_red8(red) / xxd;
+        };
     auto tail = [&]() __attribute__((always_inline)) {
         if (D.remote) {
             remote_tail(D.Pt3, oRR2, oE2, oR2, oAX2, xx2, N2, c2s);
@@ -732,76 +809,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
             if (nsp) c2s = res_red8(red) / xx2;
             return;
         }
-        if (Nt == 1) {
-            // one row: its entries are dealt to all the waves, the eight partial sums are added in
-            // wave order (a single wave walking 1024 entries took four dependent trips)
-            const int e0 = D.Pt3.rp[0], e1 = D.Pt3.rp[1];
-            double s = 0.0;
-            for (int t = e0 + tid; t < e1; t += BT * 2) {
-                const int t1 = t + BT;
-                const int ja = D.Pt3.ci[t], jb = D.Pt3.ci[t1 < e1 ? t1 : e0];
-                const double aa = D.Pt3.va[t], ab = D.Pt3.va[t1 < e1 ? t1 : e0];
-                s += aa * sm[oRR2 + ja];
-                s += t1 < e1 ? ab * sm[oRR2 + jb] : 0.0;
-            }
-            s = wave_sum(s);
-            if (lane == 0) red[w] = s;
-            __syncthreads();
-            if (tid == 0) sm[oR3] = res_red8(red);
-        } else {
-            for (int i = w; i < Nt; i += RES_WAVES) {
-                const double s = res_csr_rowdot(D.Pt3, D.Pt3.rp[i], D.Pt3.rp[i + 1], lane, sm, oRR2);
-                if (lane == 0) sm[oR3 + i] = s;
-            }
-        }
-        __syncthreads();
-        if (w == 0) {
-            const int i = lane < Nt ? lane : 0;
-            const bool valid = lane < Nt;
-            const int e0 = D.A3.rp[i], e1 = D.A3.rp[i + 1];
-            double dd = 0.0;
-            for (int t = e0; t < e1; ++t)
-                if (D.A3.ci[t] == i) dd = D.A3.va[t];
-            double r = valid ? sm[oR3 + i] : 0.0;
-            double p = valid ? r / dd : 0.0;
-            double d = 0.0;
-            double delta_new = wave_sum(valid ? r * p : 0.0);
-            const double thresh = 1e-11 * 1e-11 * delta_new;
-            long long it = 0;
-            while (it < D.pcg_maxit && delta_new > thresh) {
-                const double delta_old = delta_new;
-                if (valid) sm[oP3 + i] = p;
-                tiny_sync();
-                double q = 0.0;
-                if (valid)
-                    for (int t = e0; t < e1; ++t) q += D.A3.va[t] * sm[oP3 + D.A3.ci[t]];
-                tiny_sync();
-                const double qp = wave_sum(valid ? q * p : 0.0);
-                const double alpha = delta_old / qp;
-                d += alpha * p;
-                r = r - alpha * q;
-                const double wi = valid ? r / dd : 0.0;
-                delta_new = wave_sum(valid ? r * wi : 0.0);
-                p = wi + (delta_new / delta_old) * p;
-                ++it;
-            }
-            if (valid) sm[oE3 + i] = d;
-        }
-        __syncthreads();
-        double p0 = 0.0;
-        for (int j = tid; j < N2; j += BT) {
-            double s = 0.0;
-            for (int t = D.P3.rp[j]; t < D.P3.rp[j + 1]; ++t) s += D.P3.va[t] * sm[oE3 + D.P3.ci[t]];
-            const double en = sm[oE2 + j] + s;
-            sm[oE2 + j] = en;
-            p0 += sm[oR2 + j] - sm[oAX2 + j] * en;
-        }
-        if (nsp) {
-            p0 = wave_sum(p0);
-            if (lane == 0) red[w] = p0;
-        }
-        __syncthreads();
-        if (nsp) c2s = res_red8(red) / xx2;
+        local_tail(D.Pt3, D.A3, D.P3, oRR2, oE2, oR2, oAX2, xx2, N2, c2s);
     };
 
     // ---- third resident level (THREE): Jacobi like level 2, N3 <= BT rows dealt in contiguous runs to the
@@ -846,7 +854,10 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
                 if (lane == 0) sm[oPUB + w] = sm[oR3L + r3] - s;
                 RES_HANDOFF3({ sm[oRR3L + j] = v; }, 0, dum0);
             }
-            remote_tail(D.Pt4, oRR3L, oE3L, oR3L, oAX3L, xx3, N3, c3s);
+            if (D.remote)
+                remote_tail(D.Pt4, oRR3L, oE3L, oR3L, oAX3L, xx3, N3, c3s);
+            else
+                local_tail(D.Pt4, D.A4, D.P4, oRR3L, oE3L, oR3L, oAX3L, xx3, N3, c3s);
             for (int s = 0; s < nu; ++s) sweep3(false);
         }
     };
