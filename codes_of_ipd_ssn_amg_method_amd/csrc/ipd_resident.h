@@ -173,7 +173,7 @@ __device__ __forceinline__ int res_wait_slow(__amdgpu_buffer_rsrc_t rs, unsigned
         if ((spins & 15) == 15) {
             if (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 1;
             if (ctl && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 2;
-            if (spins > (1u << 24)) return 1;
+            if (spins > (1u << 21)) return 1;   // ~1 s: a sub-cycle leg takes 0.02-0.2 ms
         }
         __builtin_amdgcn_s_sleep(16);
         asm volatile("" ::: "memory");
