@@ -114,6 +114,63 @@ def cpu_baseline(Ae, f, guess, opts, n, budget_s=8.0):
                               "sample": "%d cycles in %.1f s (oracle/ipd_oracle.py, SciPy float64)" % (cycles, el)})
 
 
+def pmc_summary_for(args):
+    """The newest committed rocprofv3 PMC summary (tools/summarize_pmc.py) taken on the workload of
+    this run, or None.  Summaries record their bench arguments under "_workload"; the ones written
+    before that key existed were all taken on the default command."""
+    import glob
+    want = {"n1": args.n1, "mask": args.mask, "rho": float(args.rho), "cycle": args.cycle}
+    if args.mask != "bernoulli":
+        want.pop("rho")
+    for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary*.json")), reverse=True):
+        try:
+            pm = json.load(open(pf))
+        except Exception:
+            continue
+        wl = pm.get("_workload", {"n1": 1024, "mask": "bernoulli", "rho": 1.0, "cycle": "v"})
+        if all(wl.get(k) == v for k, v in want.items()):
+            return pm
+    return None
+
+
+def rank_command(n, argv, port):
+    """The command line `bench.py --gpus N` runs when it is started without a launcher: one rank
+    per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n, argv, run=None):
+    """Starts the N ranks as a child process (never exec: this process may be profiled), forwards
+    rank 0's JSON line to stdout, everything else to stderr, and returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = rank_command(n, argv, port)
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    res = (run or subprocess.run)(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True,
+                                  timeout=float(os.environ.get("IPD_BENCH_RANKS_TIMEOUT", "1500")))
+    line = None
+    for ln in (res.stdout or "").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line)
+        sys.stdout.flush()
+    if res.returncode == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited 0 without a result line\n")
+        return 4
+    return res.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,12 +192,23 @@ def main():
     ap.add_argument("--no-maskop", action="store_true", help="CSR sweeps on level 1 always")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # invoked plainly (`python bench.py --gpus N`): start the ranks ourselves, as a CHILD
+        # process, before this process has loaded the HIP library or touched the GPU
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    os.environ.setdefault("IPD_DEVICE", str(local_rank))
+        raise SystemExit("bench.py --gpus %d was started inside a job of %d rank(s)" % (args.gpus, world))
+    if "IPD_DEVICE" not in os.environ:
+        ndev = 0
+        if world > 1:
+            import torch
+            ndev = torch.cuda.device_count()     # does not initialise the GPU on this image
+        # fewer GPUs than ranks: the ranks double up on the devices there are, and RCCL then
+        # refuses the communicator (duplicate device) -- the loud failure below, not a hang
+        os.environ["IPD_DEVICE"] = str(local_rank % ndev if ndev > 0 else local_rank)
 
     # The HIP library is loaded BEFORE torch so that the system ROCm runtime is the
     # one in the process (torch bundles its own libamdhip64 with the same SONAME).
@@ -352,7 +420,7 @@ def main():
         "setup_seconds_host_api": setup_s,
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0:
         # roofline of the dominant kernel (k_smooth): per-launch algorithmic bytes over the
         # per-launch duration measured with HIP events on the library's stream
         tot_bytes = tot_ms = 0.0
@@ -388,21 +456,18 @@ def main():
         # HBM traffic per launch of the same kernel from the committed rocprofv3 PMC passes
         # (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, gfx950 x2 read
         # correction applied by tools/summarize_pmc.py); null when no profile is present
-        import glob
+        # ... of THIS workload only: a summary taken on another mask / size / cycle says nothing
+        # about this line, and `traffic` is then null
+        pm = pmc_summary_for(args)
         traffic = None
-        for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))[-1:]:
-            try:
-                pm = json.load(open(pf))
-                for kname, d in pm.items():
-                    if "hbm_traffic_bytes_per_launch" not in d:
-                        continue
-                    if "k_smooth_mask" in kname:
-                        if "level1_mask_operator" in result:
-                            result["level1_mask_operator"]["traffic"] = d["hbm_traffic_bytes_per_launch"]
-                    elif "k_smooth" in kname:
-                        traffic = d["hbm_traffic_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        for kname, d in (pm or {}).items():
+            if not isinstance(d, dict) or "hbm_traffic_bytes_per_launch" not in d:
+                continue
+            if "k_smooth_mask" in kname:
+                if "level1_mask_operator" in result:
+                    result["level1_mask_operator"]["traffic"] = d["hbm_traffic_bytes_per_launch"]
+            elif "k_smooth" in kname:
+                traffic = d["hbm_traffic_bytes_per_launch"]
         ksm = {"bound": "hbm", "kernel": "k_smooth", "achieved": achieved,
                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                "traffic": traffic,
@@ -417,19 +482,21 @@ def main():
             # registers, so `traffic` (PMC, per launch of `steps` cycles) is tiny beside it.
             ach = bytes_per_cycle * args.steps / ev_ms / 1e6
             tr = None
-            for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))[-1:]:
-                try:
-                    d = json.load(open(pf)).get("k_resident")
-                    if d:   # traffic = fixed part (matrix load) + per-cycle part, from two dispatches
-                        tr = d["hbm_traffic_bytes_fixed"] + d["hbm_traffic_bytes_per_cycle"] * args.steps
-                except Exception:
-                    tr = None
+            d = (pm or {}).get("k_resident")
+            if d:   # traffic = fixed part (matrix load) + per-cycle part, from two dispatches
+                tr = d["hbm_traffic_bytes_fixed"] + d["hbm_traffic_bytes_per_cycle"] * args.steps
             result["roofline"] = {
                 "bound": "hbm", "kernel": "k_resident", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr,
                 "cycles_per_launch": args.steps, "us_per_launch": 1e3 * ev_ms,
                 "algorithmic_bytes_per_launch": bytes_per_cycle * args.steps,
                 "us_per_handoff": 1e3 * ev_ms / (args.steps * handoffs) if handoffs else None,
+                # what `achieved` is and is not: an EFFECTIVE rate -- the bytes a
+                # matrix-streaming cycle would move, over the time -- for a kernel whose limiter is
+                # the latency of its hand-offs; the rate of the bytes it really moves is beside it
+                "achieved_kind": "effective (algorithmic bytes of SURVEY 8d / time)",
+                "limiter": "hand-off latency",
+                "frac_of_measured_traffic": (tr / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None,
                 "note": "algorithmic bytes (every sweep re-reads its matrix) over time: the kernel "
                         "itself keeps the matrices in registers, and the 38 MB hierarchy is "
                         "Infinity-Cache resident anyway, so FETCH_SIZE/WRITE_SIZE are not HBM bytes "
@@ -438,7 +505,7 @@ def main():
                 "multi_launch_k_smooth": ksm}
         else:
             result["roofline"] = ksm
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(Ae, f, guess, opts, n)
             result["cpu_baseline"]["host_cores_available"] = os.cpu_count()
     if rank == 0:

@@ -96,11 +96,16 @@ __global__ void k_mailbox(const unsigned* __restrict__ src, int nwords, volatile
     if (i == 0) box[0] = ticket;
 }
 
-bool ipd_lds_optin_needed(const void* kernel, int device) {
+// The attribute is set while the lock is held and the pair is recorded only once it is set: a second
+// host thread that reaches the same kernel at the same moment (AMG4POT's two solve phases) waits here
+// instead of launching with > 64 KiB of dynamic LDS before the first thread's call has taken effect.
+void ipd_lds_optin(const void* kernel, int device, int bytes) {
     static std::mutex mu;
     static std::set<std::pair<const void*, int>> done;
     std::lock_guard<std::mutex> lock(mu);
-    return done.insert({kernel, device}).second;
+    if (done.count({kernel, device})) return;
+    IPD_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({kernel, device});
 }
 
 static bool mailbox_enabled() {

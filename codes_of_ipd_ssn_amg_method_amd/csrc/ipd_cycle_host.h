@@ -63,6 +63,7 @@ struct CycleState {
     double* res_out = nullptr;
     unsigned char* res_block = nullptr;   // [gran0 | gran1 | tmo]: zeroed before every launch
     int res_timeouts = 0;    // launches whose bounded spins gave up (then: multi-launch path)
+    int res_capacity = -1;   // workgroups of the chosen instantiation the device holds at once (-1: not asked yet)
     // whole solve of a realistic hierarchy in one workgroup (ipd_mid.h): levels 1-2 thread-per-row
     // with rows in registers and vectors in LDS, levels 3..J out of the LDS image
     bool mid_ok = false;
@@ -359,6 +360,8 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     D.tout = remote ? st->res_block + 4 * gbytes + 16 : st->res_block;       // a remote tail
     D.tctl = remote ? reinterpret_cast<unsigned*>(st->res_block + 6 * gbytes + 16) : D.tmo;
     D.dbg = nullptr;
+    D.dbg_skip_seq = 0;
+    if (const char* e = std::getenv("IPD_RES_DEBUG_SKIP_PUBLISH")) D.dbg_skip_seq = (unsigned)std::max(0, std::atoi(e));
     st->res_desc = D;
     st->res_remote = remote;
     st->res_ke3 = ke3;
@@ -419,6 +422,10 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
                          std::vector<double>* out_host, float* ms, long long* dbg_dev = nullptr) {
     ipd_ctx* ctx = h->ctx;
     const int grid = st->res_G + (st->res_remote ? 1 : 0);
+    if (ctx->res_penalty > 0) {   // an earlier launch of this context gave up: stay on the launches for a while
+        --ctx->res_penalty;
+        return false;
+    }
     // A remote-tail launch is 129 workgroups at M = 2048: two of them do not fit side by side, and a
     // realistic solve is a few milliseconds of mostly serial sub-cycle work -- waiting for the other
     // solve (AMG4POT's two right-hand sides) would serialise them, so the loser runs as launches
@@ -427,6 +434,7 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
     if (!lease.ok) return false;
     ResDesc D = st->res_desc;
     D.dbg = dbg_dev;
+    st->res_desc.dbg_skip_seq = 0;   // the test hook fires on ONE launch
     IPD_HIP(hipMemsetAsync(st->res_block, 0, st->res_block_bytes, ctx->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ms) {
@@ -434,9 +442,22 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
         IPD_HIP(hipEventCreate(&e1));
         IPD_HIP(hipEventRecord(e0, ctx->stream));
     }
+    // The workgroups spin on one another, so ALL of them must be on the chip at once: the grid is
+    // checked against what the device can hold of this instantiation (registers, LDS: one workgroup
+    // per CU) before the first launch; an oversized grid takes the multi-launch path for good.
+    bool fits = true;
 #define IPD_RES_LAUNCH(KE, KE3)                                                                     \
     do {                                                                                            \
         IPD_OPTIN_LDS(ctx, (k_resident<KE, KE, KE3>), 156 * 1024);                                  \
+        if (st->res_capacity < 0) {                                                                 \
+            int nb_ = 0;                                                                            \
+            IPD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, (k_resident<KE, KE, KE3>), BT, st->res_lds)); \
+            st->res_capacity = nb_ * st->num_cu;                                                    \
+        }                                                                                           \
+        if (grid > st->res_capacity) {                                                              \
+            fits = false;                                                                           \
+            break;                                                                                  \
+        }                                                                                           \
         hipLaunchKernelGGL((k_resident<KE, KE, KE3>), dim3(grid), dim3(BT), st->res_lds, ctx->stream, \
                            D, b_dev, x, st->res_out, fixed_cycles);                                 \
     } while (0)
@@ -459,6 +480,14 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
             IPD_RES_LAUNCH(8, 8);
     }
 #undef IPD_RES_LAUNCH
+    if (!fits) {
+        if (ms) {
+            IPD_HIP(hipEventDestroy(e0));
+            IPD_HIP(hipEventDestroy(e1));
+        }
+        st->res_ok = false;
+        return false;
+    }
     IPD_KERNEL_CHECK();
     if (ms) IPD_HIP(hipEventRecord(e1, ctx->stream));
     const size_t nout = 4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2);
@@ -469,8 +498,11 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
         IPD_HIP(hipEventDestroy(e0));
         IPD_HIP(hipEventDestroy(e1));
     }
-    if (out[3] != 0.0) {   // a bounded spin gave up: not every workgroup was resident
+    if (out[3] != 0.0) {   // a bounded spin gave up somewhere (any workgroup: the kernel reports the
+        // time-out word, not only workgroup 0's own view): not every workgroup was resident
         ++st->res_timeouts;
+        ++ctx->res_giveups;
+        ctx->res_penalty = 32 << std::min(ctx->res_giveups - 1, 6);
         if (st->res_timeouts >= 2) st->res_ok = false;
         return false;
     }
@@ -1361,8 +1393,9 @@ static void launch_sweep(ipd_amg* h, CycleState* st, int k, int isnsp, bool post
         a.u0 = a.u1 = 0;
         a.wout = nullptr;
         run_rows(ctx, st, 0, lv.N, go, {a.enew});
-    } else if (k == 1 && st->mask_ok && st->shard_ranks == 1) {
-        // bit-mask operator: same two half sweeps, 1 bit per matrix entry
+    } else if (k == 1 && st->mask_ok) {
+        // bit-mask operator: same two half sweeps, 1 bit per matrix entry; sharded runs give each
+        // owner its block of the half's rows (a row range inside one half is all the kernel needs)
         const MaskOp& mo = st->maskop;
         const size_t dyn = sizeof(double) * 64 * (size_t)std::max(mo.nwf, mo.nwc);
         auto half = [&](int r0, int r1) {
@@ -1375,13 +1408,12 @@ static void launch_sweep(ipd_amg* h, CycleState* st, int k, int isnsp, bool post
         };
         const int f0 = post ? lv.nf : 0, f1 = post ? lv.N : lv.nf;
         const int s0 = post ? 0 : lv.nf, s1 = post ? lv.nf : lv.N;
-        flush_fused(ctx, st);
         a.u0 = a.u1 = 0;
-        half(f0, f1);
+        run_rows(ctx, st, f0, f1, half, {a.enew, a.wout});
         a.u0 = f0;
         a.u1 = f1;
         a.wout = nullptr;
-        half(s0, s1);
+        run_rows(ctx, st, s0, s1, half, {a.enew});
     } else {
         // pre: F rows then C rows (Rk{1});  post: C rows then F rows (Rk{1}')
         const int f0 = post ? lv.nf : 0, f1 = post ? lv.N : lv.nf;  // first half rows

@@ -880,6 +880,9 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
         // gain -- the setup is bound by its host round trips -- so both setups stay on this
         // thread and only the solve phases, which consume no random numbers, run concurrently.)
         CallScope aux_scope(aux);
+        // an injected component order (ipd_ctx_set_component_order) holds for both solves: without the
+        // shared component cache (IPD_NO_DONOR=1) the second call finds the components itself
+        aux->comp_order = ctx->comp_order;
         hybrid_amg_cached(aux, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o,
                           donors ? &cache : nullptr, &second);
         std::exception_ptr err;

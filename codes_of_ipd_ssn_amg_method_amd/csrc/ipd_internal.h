@@ -149,6 +149,13 @@ struct ipd_ctx {
     std::vector<int> comp_order;
     RcclState* comm = nullptr;
     ipd_ctx* aux = nullptr;   // second stream/arena for work that overlaps with this context's
+    // Level-resident kernel (ipd_resident.h): launches of this context whose bounded spins gave up
+    // (the workgroups were not all on the chip: the GPU is shared with something this process does
+    // not see), and the number of solves that stay on the multi-launch path before the next attempt
+    // (32 after the first give-up, doubling: a stall costs ~0.5 s, a run builds hundreds of
+    // hierarchies -- counting per hierarchy would pay the stall on every one of them)
+    int res_giveups = 0;
+    int res_penalty = 0;
 
     // read back `n` elements synchronously through the pinned staging buffer
     template <class T>
@@ -216,13 +223,9 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // Opt-in to more than 64 KiB of dynamic LDS.  The attribute is per DEVICE (a process may hold
 // contexts on several), so it is remembered per (kernel, device) pair, under a lock (contexts
 // are used from several host threads).  ipd_core.cpp
-bool ipd_lds_optin_needed(const void* kernel, int device);
-#define IPD_OPTIN_LDS(ctx, kernel, bytes)                                                        \
-    do {                                                                                         \
-        if (ipd_lds_optin_needed(reinterpret_cast<const void*>(kernel), (ctx)->device))          \
-            IPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                   \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)));   \
-    } while (0)
+void ipd_lds_optin(const void* kernel, int device, int bytes);
+#define IPD_OPTIN_LDS(ctx, kernel, bytes) \
+    ipd_lds_optin(reinterpret_cast<const void*>(kernel), (ctx)->device, (bytes))
 
 // ---------------------------------------------------------------------------
 // cross-TU device routines (all asynchronous on ctx->stream unless noted)

@@ -89,6 +89,8 @@ struct ResDesc {
     int pollsleep;      // ... and between two polls
     unsigned* tmo;      // [0] != 0: a bounded spin gave up (value = step number)
     long long* dbg;     // optional stamps (diagnostic build of the bench): see k_resident
+    unsigned dbg_skip_seq;   // test hook (IPD_RES_DEBUG_SKIP_PUBLISH=<step>): the last workgroup omits its
+                             // publish of that step, so every sweep of the step gives up; 0 = off
 };
 
 // one fp64 value as two self-tagged 8-byte granules
@@ -505,7 +507,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         if (w == 0) {                                                                              \
             const int l8_ = lane & (RES_WAVES - 1);                                                \
             const bool second_ = lane >= RES_WAVES;                                                \
-            if (lane < 2 * RES_WAVES && l8_ < (second_ ? (cB) : (cA)))                             \
+            if (lane < 2 * RES_WAVES && l8_ < (second_ ? (cB) : (cA)) &&                           \
+                !(seq == D.dbg_skip_seq && b == G - 1))                                            \
                 res_publish(rs, seq, (second_ ? (gB) : (gA)) + l8_, sm[oPUB + lane]);              \
         }                                                                                          \
         if (dbg) dbg_acc[0] -= __builtin_amdgcn_s_memtime();                                       \
@@ -1028,7 +1031,11 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         out[0] = (double)it;
         out[1] = rel_res;
         out[2] = res0;
-        out[3] = dead ? 1.0 : 0.0;
+        // any workgroup's give-up, not only this one's: a workgroup that gave up keeps publishing
+        // (tagged, but computed from values it never received), so the iterate is void even when
+        // workgroup 0 itself saw every hand-off arrive
+        const unsigned anytmo = __hip_atomic_load(D.tmo, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        out[3] = (dead || anytmo != 0) ? 1.0 : 0.0;
     }
     if (dbg) {
         D.dbg[0] = dbg_acc[0];

@@ -917,6 +917,10 @@ ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng,
     h->L.resize(2);
     h->J = 1;
     const int thr = amg_coarsest_threshold(A.nr);
+    // Levels 1-2 of a bigraph hierarchy depend on A and on bigph / fnode / isnsp / inter only
+    // (transfer.m:19-25 draws no random numbers and uses no theta; Rk{1}, Rk{2} use none of the
+    // options): exactly what is compared here, so a donor built under another theta, smoth, cycle,
+    // retol or maxit is still the same levels 1-2.
     const bool share = donor && o.bigph && !o.twogrid && donor->J >= 2 && donor->opts.bigph &&
                        !donor->opts.twogrid && donor->opts.fnode == o.fnode &&
                        donor->opts.isnsp == o.isnsp && donor->opts.inter == o.inter &&

@@ -10,12 +10,17 @@ AMG/MG_Wcycle.m:13-46.  Checked against the multi-launch path (IPD_NO_RESIDENT_R
 tests/test_gpu_cycle.py ties to the oracle: same cycle counts, residual histories to 1e-10, timed
 loop bodies to the rounding floor of A*x (5e-9 |f|), run-to-run identical bits."""
 import os
+import subprocess
+import sys
 from ctypes import byref, c_int32
 
 import numpy as np
 import pytest
 import scipy.sparse as sp
 
+import bench
+from oracle import ipd_oracle as O
+from tests import problems as PR
 from tests.test_gpu_bench_workload import bench_cycles, env, options, same_history, solve_mode
 
 pytestmark = pytest.mark.gpu
@@ -98,3 +103,122 @@ def test_remote_tail_matches_the_multi_launch_path(ipd, newton_system, cycle):
     assert np.array_equal(a, again)
     h.close()
     hc.close()
+
+
+def _against_oracle(ipd, Ae, f, n, cycle, x0, expect_mode=None, kv=None):
+    """One Class_AMG solve on the device against the SciPy oracle's (AMG/Class_AMG.m:86-109): the same
+    hierarchy sizes, the same cycle count, residual histories to 1e-10 and A(x - x_oracle) at the
+    rounding floor of A*x."""
+    opts = options(cycle, n)
+    with env(**(kv or {})):
+        h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand(5489))
+        mode = solve_mode(h)[0]
+        if expect_mode is not None and mode != expect_mode:
+            h.close()
+            return None
+        x, it, rr, relk, rhok = h.solve(f, x0)
+    assert solve_mode(h)[2] == 0
+    o = dict(opts)
+    o.update(guess=x0)
+    xo, ito, rro, relko, rhoko, ho = O.Class_AMG(Ae, f, o, O.matlab_rng(5489), return_hierarchy=True)
+    assert h.level_sizes() == ho.level_sizes()
+    assert [h.level_dims(k)[1] for k in range(1, h.J + 1)] == ho.level_nnz()
+    same_history(it, np.asarray(relk), ito, np.asarray(relko), tol=1e-10)
+    assert np.linalg.norm(Ae @ (x - xo)) <= 1e-9 * np.linalg.norm(f)
+    h.close()
+    return it, ito, relk, relko
+
+
+@pytest.mark.parametrize("cycle", ["v", "w"])
+def test_realistic_modes_against_the_oracle(ipd, newton_system, cycle):
+    """VERDICT r2 #2 / ADVICE r2: the resident kernel's REALISTIC modes (remote tail rooted at level 3
+    or 4, third resident level) tied to the oracle directly, not through the multi-launch path; and the
+    multi-launch path at this size with and without the fused restriction r_c = P'r - (P'A)e
+    (ipd_cycle_phases.h phase_rrc against the reference's P'(r - A e), AMG/MG_Vcycle.m:27)."""
+    Ae, f, n, want_levels = newton_system
+    x0 = np.zeros(Ae.shape[0])
+    got = _against_oracle(ipd, Ae, f, n, cycle, x0, expect_mode=2)
+    if got is None:
+        pytest.skip("hierarchy not taken by the resident kernel")
+    it, ito, relk, relko = got
+    # these systems take several informative cycles (contraction ~0.1-0.3 per cycle), unlike rho = 1
+    assert it >= 4 and np.sum(np.asarray(relko[:ito + 1]) > 1e-9) >= 4, relko
+    assert _against_oracle(ipd, Ae, f, n, cycle, x0, kv=dict(IPD_NO_RESIDENT=1)) is not None
+    assert _against_oracle(ipd, Ae, f, n, cycle, x0, kv=dict(IPD_NO_RESIDENT=1, IPD_NO_RRC=1)) is not None
+    assert _against_oracle(ipd, Ae, f, n, cycle, x0, kv=dict(IPD_NO_RESIDENT_THREE=1)) is not None
+
+
+@pytest.mark.parametrize("cycle", ["v", "w"])
+def test_tree_mask_against_the_oracle(ipd, cycle):
+    """bench.py --mask tree (three resident levels + local tail) against the oracle directly."""
+    m = n = 1024
+    s = bench.build_mask(m, n, "tree", 1.0)
+    Ae, f, guess, H0 = bench.build_newton_system(ipd, m, n, s)
+    got = _against_oracle(ipd, Ae, f, n, cycle, guess, expect_mode=2)
+    assert got is not None
+
+
+@pytest.mark.parametrize("cycle", ["v", "w"])
+def test_bernoulli_eighth_at_the_metric_size_against_the_oracle(ipd, cycle):
+    """rho = 1/8 at m=n=1024 (SURVEY 8d regime D): the metric's size with a system that takes several
+    cycles to converge, so "residual per cycle" is compared on more than one informative cycle."""
+    m = n = 1024
+    s = PR.mask_bernoulli(m, n, 1.0 / 8, seed=2)
+    Ae, f, guess, H0 = bench.build_newton_system(ipd, m, n, s)
+    got = _against_oracle(ipd, Ae, f, n, cycle, guess)
+    it, ito, relk, relko = got
+    informative = int(np.sum(np.asarray(relko[:ito + 1]) > 1e-9))
+    assert informative >= 2, relko
+
+
+def test_skipped_publish_gives_up_once_and_is_redone_by_the_launches(ipd):
+    """The recovery that makes the bounded spins safe (ipd_resident.h:res_sweep, run_resident): a test
+    hook makes the last workgroup omit ONE publish (hand-off 7), every sweep of that step gives up after
+    2^18 polls, the kernel reports it through the time-out word, and ipd_amg_solve redoes the solve from
+    the guess on the multi-launch path: same result as a hierarchy that never used the resident kernel,
+    one time-out on record, and the context stays on the launches for the next solves (back-off)."""
+    m = n = 512
+    s = PR.mask_bernoulli(m, n, 1.0, seed=5)
+    Ae, f, guess, H0 = bench.build_newton_system(ipd, m, n, s)
+    opts = options("v", n)
+    with env(IPD_NO_RESIDENT=1):
+        hc = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    xc, itc, relc, relkc, _ = hc.solve(f, guess)
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    cx = _lib.Context(_lib.get_ctx().device)      # own context: the back-off is per context
+    with env(IPD_RES_DEBUG_SKIP_PUBLISH=7):
+        h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand(), ctx=cx)
+    assert solve_mode(h)[0] == 2
+    x, it, rel, relk, _ = h.solve(f, guess)
+    assert solve_mode(h)[2] == 1                   # one launch gave up ...
+    assert it == itc and np.array_equal(x, xc)     # ... and the launches redid the solve, same bits
+    assert np.array_equal(np.asarray(relk), np.asarray(relkc))
+    x2, it2, _, _, _ = h.solve(f, guess)           # back-off: no second attempt, no second stall
+    assert solve_mode(h)[2] == 1 and np.array_equal(x2, xc)
+    h.close()
+    hc.close()
+
+
+def test_amg4pot_as_first_resident_use_in_a_fresh_process():
+    """AMG4POT's two solve phases run on two host threads and both opt the same
+    k_resident instantiation in to > 64 KB of LDS; in a process where no earlier test has done so the
+    second thread must not launch before the attribute is set (ipd_lds_optin sets it under its lock)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import codes_of_ipd_ssn_amg_method_amd as ipd\n"
+        "from tests import problems as PR\n"
+        "m = n = 512\n"
+        "rs = np.random.RandomState(2)\n"
+        "s = PR.mask_bernoulli(m, n, 1.0)\n"
+        "t = (rs.random_sample(m + n) < 0.7).astype(float)\n"
+        "pd = PR.make_prob(m, n, s, t=t)\n"
+        "pd['z'] = rs.randn(m + n + 1); pd['phi'] = np.ones(m * n)\n"
+        "pd['H0'] = ipd.ASAt(s, pd['p'], pd['q'])\n"
+        "o = dict(retol=1e-11, bigph=1, maxit=5, theta=0.25, smoth=10, cycle='w', isnsp=1, inter=1, guess=None, fnode=None)\n"
+        "zeta, it, res, info = ipd.AMG4POT(pd, o, 'amg', ipd.MatlabRand())\n"
+        "assert np.all(np.isfinite(zeta)) and it == 5\n"
+        "print('ok', it, res)\n") % root
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]

@@ -72,6 +72,42 @@ def test_sharded_emulation_is_bit_exact(ipd, mask, cycle, N1):
     h.close()
 
 
+@pytest.mark.parametrize("N1,G", [(512, 4), (2048, 8)])
+def test_sharded_mask_operator_is_bit_exact(ipd, N1, G):
+    """Sharded runs keep the matrix-free level 1 (the 1-bit-per-entry Gauss-Seidel half sweeps): G
+    emulated owners, each sweeping its block of a half's rows, reproduce the unsharded mask-operator
+    run BIT FOR BIT; N1 = 2048 with 8 owners is BASELINE config 4 as `bench.py --gpus 8 --n1 2048`
+    runs it.  The operator is in use (attach returns True) and agrees with the CSR sweeps to rounding."""
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    m = n = N1
+    Ae, pd = newton_matrix(m, n, PR.mask_bernoulli(m, n, 1.0))
+    f = np.concatenate([pd["q"], -pd["p"]]) * pd["z"]
+    x0 = np.random.RandomState(4).random_sample(m + n) * 1e-4
+    o = O.amg_options_class1("v")
+    o.update(fnode=n, isnsp=1)
+    os.environ["IPD_NO_SMALL"] = "1"
+    os.environ["IPD_NO_RESIDENT"] = "1"
+    try:
+        h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+        hc = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+    finally:
+        os.environ.pop("IPD_NO_SMALL")
+        os.environ.pop("IPD_NO_RESIDENT")
+    assert h.attach_mask_operator(pd["p"], pd["q"], pd["tk"])
+    ref = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles, h, f, x0, 3)
+    os.environ["IPD_SHARD_EMULATE"] = str(G)
+    try:
+        got = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles_sharded, h, f, x0, 3)
+    finally:
+        os.environ.pop("IPD_SHARD_EMULATE")
+    assert np.array_equal(got, ref)
+    csr = _run(_lib.lib, _lib.lib.ipd_amg_bench_cycles, hc, f, x0, 3)
+    assert not np.array_equal(csr, ref)          # a different summation order: the operator DID run
+    assert np.linalg.norm(Ae @ (csr - ref)) <= 1e-10 * np.linalg.norm(f)
+    h.close()
+    hc.close()
+
+
 def test_rccl_communicator_of_one(ipd):
     from codes_of_ipd_ssn_amg_method_amd import _lib
     m = n = 256

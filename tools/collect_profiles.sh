@@ -4,7 +4,7 @@
 #   default bench command; then the bench lines themselves.  Results land in gpurun_out/ with the
 #   names profiles/ uses (copy them over afterwards).
 set -o pipefail
-R=${1:-r2}
+R=${1:-r3}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

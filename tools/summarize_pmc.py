@@ -2,6 +2,9 @@
 """Summarise rocprofv3 --pmc counter_collection.csv files into per-kernel means.
 
 usage: summarize_pmc.py OUT.json NAME=counter_collection.csv [NAME=...] [RESIDENT_CYCLES=w,k]
+                        [WORKLOAD=n1:1024,mask:bernoulli,rho:1,cycle:v]
+WORKLOAD: the bench.py arguments of the profiled command, stored under "_workload"; bench.py quotes
+a summary's traffic only on a line of the same workload.
 RESIDENT_CYCLES: the profiled command launched k_resident twice, with w (warm-up) and k (timed)
 cycles; its traffic is then split into a fixed part (the one read of the matrices into registers)
 and a per-cycle part (hand-off granules, transfer operators): "k_resident" entry.
@@ -19,11 +22,17 @@ def main():
     out = sys.argv[1]
     res = collections.defaultdict(dict)
     res_cycles = None
+    workload = {"n1": 1024, "mask": "bernoulli", "rho": 1.0, "cycle": "v"}
     per_dispatch = collections.defaultdict(dict)
     for arg in sys.argv[2:]:
         name, path = arg.split("=", 1)
         if name == "RESIDENT_CYCLES":
             res_cycles = [int(v) for v in path.split(",")]
+            continue
+        if name == "WORKLOAD":
+            kv = dict(t.split(":", 1) for t in path.split(","))
+            workload = {"n1": int(kv.get("n1", 1024)), "mask": kv.get("mask", "bernoulli"),
+                        "rho": float(kv.get("rho", 1.0)), "cycle": kv.get("cycle", "v")}
             continue
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(path)):
@@ -51,6 +60,7 @@ def main():
             res["k_resident"] = {"kernel": k, "dispatch_cycles": res_cycles, "hbm_traffic_bytes": tr,
                                  "hbm_traffic_bytes_per_cycle": per,
                                  "hbm_traffic_bytes_fixed": t0 - per * c0}
+    res["_workload"] = workload
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 
 
