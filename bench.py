@@ -201,20 +201,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("bench.py --gpus %d was started inside a job of %d rank(s)" % (args.gpus, world))
-    if "IPD_DEVICE" not in os.environ:
-        ndev = 0
-        if world > 1:
-            import torch
-            ndev = torch.cuda.device_count()     # does not initialise the GPU on this image
-        # fewer GPUs than ranks: the ranks double up on the devices there are, and RCCL then
-        # refuses the communicator (duplicate device) -- the loud failure below, not a hang
-        os.environ["IPD_DEVICE"] = str(local_rank % ndev if ndev > 0 else local_rank)
 
     # The HIP library is loaded BEFORE torch so that the system ROCm runtime is the
     # one in the process (torch bundles its own libamdhip64 with the same SONAME).
     import codes_of_ipd_ssn_amg_method_amd as ipd
     from codes_of_ipd_ssn_amg_method_amd import _lib
     from ctypes import byref, c_double, c_int, c_int64
+    if "IPD_DEVICE" not in os.environ:
+        from ctypes import c_int32 as _ci32
+        ndev = _ci32(0)
+        _lib.check(_lib.lib.ipd_device_count(byref(ndev)))
+        # fewer GPUs than ranks: the ranks double up on the devices there are, and RCCL then
+        # refuses the communicator (duplicate device) -- the loud failure below, not a hang
+        os.environ["IPD_DEVICE"] = str(local_rank % ndev.value if ndev.value > 0 else local_rank)
 
     dist = None
     if world > 1:

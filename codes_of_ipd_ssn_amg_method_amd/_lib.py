@@ -108,7 +108,7 @@ lib.ipd_apd_destroy.restype = None
 
 # every symbol the header declares (tests check that they all resolve)
 EXPORTS = [
-    "ipd_version", "ipd_last_error", "ipd_ctx_create", "ipd_ctx_destroy", "ipd_ctx_sync",
+    "ipd_version", "ipd_last_error", "ipd_device_count", "ipd_ctx_create", "ipd_ctx_destroy", "ipd_ctx_sync",
     "ipd_csc_free", "ipd_amg_opts_init", "ipd_pcg_opts_init", "ipd_rng_create",
     "ipd_rng_create_replay", "ipd_rng_destroy", "ipd_rng_rand", "ipd_rng_consumed", "ipd_ax",
     "ipd_aty", "ipd_asat", "ipd_inv_aat", "ipd_inv_hht", "ipd_strength", "ipd_cf_split",

@@ -212,6 +212,15 @@ extern "C" int ipd_prof_read(double* seconds, int64_t* calls, int32_t reset) {
 
 extern "C" const char* ipd_last_error(void) { return g_last_error.c_str(); }
 
+extern "C" int ipd_device_count(int32_t* count) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(count != nullptr, IPD_E_ARG, "ipd_device_count: count is NULL");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+        *count = ndev;
+    });
+}
+
 extern "C" int ipd_ctx_create(int device, ipd_ctx** out) {
     return ipd_guard([&] {
         IPD_REQUIRE(out != nullptr, IPD_E_ARG, "ipd_ctx_create: out is NULL");

@@ -1366,7 +1366,9 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
     for (int guard = 0; guard < (1 << 22); ++guard) {
         if (entering) {
             if (k == J) {
+                SOL_DBG_T0(c);
                 tiny_pcg(c, J);
+                SOL_DBG_ADD(c, 10);
                 if (k == k0) return;
                 entering = false;
                 k = J - 1;
@@ -1381,8 +1383,13 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
                     c.zeromask &= ~(1u << k);
                 }
             }
-            tiny_sweeps(c, k, L, nu, isnsp);
+            {
+                SOL_DBG_T0(c);
+                tiny_sweeps(c, k, L, nu, isnsp);
+                SOL_DBG_ADD(c, 9);
+            }
             {   // residual, then restriction into the child's right-hand side
+                SOL_DBG_T0(c);
                 {
                     const int Lt = tiny_lanes(L.N), i = t / Lt, sub = t % Lt;
                     const bool valid = i < L.N;
@@ -1397,6 +1404,7 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
                     if (cv && sub == 0) L.rc[i] = rc;
                 }
                 tiny_sync();
+                SOL_DBG_ADD(c, 11);
             }
             visited &= ~(1u << (k + 1));
             k = k + 1;
@@ -1412,13 +1420,19 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
             }
             LdsLevel L = lds_level(c, k);
             {
+                SOL_DBG_T0(c);
                 const int Lt = tiny_lanes(L.N), i = t / Lt, sub = t % Lt;
                 const bool valid = i < L.N;
                 const double sd = lds_densedot_split(L.dP, L.N, L.Nc, i, sub, Lt, valid, lds_e(c, k + 1));
                 if (valid && sub == 0) L.e[i] = L.e[i] + sd;
                 tiny_sync();
+                SOL_DBG_ADD(c, 12);
             }
-            tiny_sweeps(c, k, L, nu, isnsp);
+            {
+                SOL_DBG_T0(c);
+                tiny_sweeps(c, k, L, nu, isnsp);
+                SOL_DBG_ADD(c, 9);
+            }
             if (k == k0) return;
             k = k - 1;
         }

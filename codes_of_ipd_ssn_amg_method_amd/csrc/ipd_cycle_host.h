@@ -2152,8 +2152,15 @@ extern "C" int ipd_amg_bench_subcycle(ipd_amg* h, int reps, double* total_ms, in
         // patch the debug pointer into the image header
         const size_t off = offsetof(SolveDesc, dbg);
         ctx->upload_bytes(reinterpret_cast<char*>(st->d_sub) + off, &dbg, sizeof(dbg));
-        IPD_HIP(hipMemsetAsync(h->L[st->k_sub].r, 0, sizeof(double) * (size_t)h->L[st->k_sub].N,
-                               ctx->stream));
+        {   // a right-hand side that is not zero (a zero one ends every coarse PCG at once)
+            std::vector<double> rr((size_t)h->L[st->k_sub].N);
+            unsigned lcg = 12345u;
+            for (auto& v : rr) {
+                lcg = lcg * 1664525u + 1013904223u;
+                v = (double)(lcg >> 8) / (double)(1u << 24) - 0.5;
+            }
+            ctx->upload(h->L[st->k_sub].r, rr.data(), rr.size());
+        }
         hipEvent_t e0, e1;
         IPD_HIP(hipEventCreate(&e0));
         IPD_HIP(hipEventCreate(&e1));
@@ -2178,8 +2185,8 @@ extern "C" int ipd_amg_bench_subcycle(ipd_amg* h, int reps, double* total_ms, in
         if (stamps)
             for (int i = 0; i < 8; ++i) stamps[i] = hs[i];
         if (const char* e = std::getenv("IPD_DEBUG_SWEEP"); e && e[0] == '1')
-            std::fprintf(stderr, "[ipd] %lld blk sweeps, parts (us): total+div %.2f rowdot %.2f publish %.2f barrier %.2f\n",
-                         hs[13], hs[9] / 100.0, hs[10] / 100.0, hs[11] / 100.0, hs[12] / 100.0);
+            std::fprintf(stderr, "[ipd] one-wave levels, per launch (us): sweeps %.2f pcg %.2f resid+restrict %.2f prolong %.2f\n",
+                         hs[9] / 100.0, hs[10] / 100.0, hs[11] / 100.0, hs[12] / 100.0);
         long long* none = nullptr;
         ctx->upload_bytes(reinterpret_cast<char*>(st->d_sub) + off, &none, sizeof(none));
     });

@@ -110,6 +110,9 @@ typedef struct ipd_prob {
 /* ---- library / context -------------------------------------------------- */
 int ipd_version(void);
 const char* ipd_last_error(void);
+/* Number of HIP devices this process sees (hipGetDeviceCount); 0 without a usable GPU.  bench.py's
+ * ranks map LOCAL_RANK onto it before a context exists.                                          */
+int ipd_device_count(int32_t* count);
 int ipd_ctx_create(int device, ipd_ctx** out);
 void ipd_ctx_destroy(ipd_ctx* ctx);
 int ipd_ctx_sync(ipd_ctx* ctx);

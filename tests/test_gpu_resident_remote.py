@@ -160,15 +160,16 @@ def test_tree_mask_against_the_oracle(ipd, cycle):
 
 @pytest.mark.parametrize("cycle", ["v", "w"])
 def test_bernoulli_eighth_at_the_metric_size_against_the_oracle(ipd, cycle):
-    """rho = 1/8 at m=n=1024 (SURVEY 8d regime D): the metric's size with a system that takes several
-    cycles to converge, so "residual per cycle" is compared on more than one informative cycle."""
+    """rho = 1/8 at m=n=1024 (SURVEY 8d regime D) against the oracle directly.  Measured: like rho = 1
+    this Bernoulli system reaches the rounding floor (2.7e-11) in ONE cycle, the oracle's too -- every
+    regime-D mask does; the systems that take several informative cycles at the metric's size are the
+    captured Newton systems above (4+ cycles each, asserted there)."""
     m = n = 1024
     s = PR.mask_bernoulli(m, n, 1.0 / 8, seed=2)
     Ae, f, guess, H0 = bench.build_newton_system(ipd, m, n, s)
     got = _against_oracle(ipd, Ae, f, n, cycle, guess)
     it, ito, relk, relko = got
-    informative = int(np.sum(np.asarray(relko[:ito + 1]) > 1e-9))
-    assert informative >= 2, relko
+    assert relko[1] <= 1e-9 and relk[1] <= 1e-9
 
 
 def test_skipped_publish_gives_up_once_and_is_redone_by_the_launches(ipd):
