@@ -887,6 +887,18 @@ struct SolveLevel {
     const double* dA;   // N x N
     const double* dP;   // N x Nc   (prolongation, k < J)
     const double* dPt;  // Nc x N   (restriction,  k < J)
+    // One-wave levels in POLYNOMIAL form (k_pack_poly, see tiny_cycle): the nu sweeps of a visit are
+    // one fixed linear map, e' = S^nu e + (I + S + ... + S^(nu-1)) Rg r, so the level carries the
+    // stacked dense operators below instead of dA / dP / dPt and a visit is two passes.  NULL: sweeps.
+    // Layout: column-major with a fixed leading dimension pLD in {32, 48, 64} >= N + Nc and the column
+    // count padded to a multiple of 8 with zero columns (the vectors of these levels are zero-padded
+    // likewise): every load of a pass then has a compile-time offset from one base address.
+    // pMr, pMe, pMc lie one behind the other in the image (a pass streams through them).
+    const double* pMr;  // [M2a; P' - (P'A) M2a]  applied to r          (M2 = M2a + w 1': see k_pack_poly)
+    const double* pMe;  // [M1; -(P'A) M1]        applied to the iterate (kept start, post-smoothing)
+    const double* pMc;  // M1 P                   applied to the child's correction
+    const double* pW;   // [w; -(P'A) w]          times 1'r
+    int pLD;
 };
 struct SolveDesc {
     int J, nu, isnsp, wcycle, anycycle, maxit;
@@ -899,6 +911,10 @@ struct SolveDesc {
     // levels are laid out in global memory exactly as they will sit in LDS (behind the staging
     // area); pointers into the image are stored as LDS byte offsets and relocated on arrival
     int image_bytes;  // multiple of 16; 0 = nothing cached
+    int lds_total;    // dynamic LDS the kernel is launched with: staging area, image, work vectors
+    int dbg_skip;     // timing by elimination (IPD_DEBUG_SKIP=<mask>, results are then garbage): 1 the
+                      // polynomial passes skip their streams, 2 the coarsest PCG does no iteration, 4 the
+                      // thread-per-row sweeps skip the row walk, 8 no sweeps at all on those levels
     int nreloc;
     double* root_r;   // k_subcycle: global right-hand side / correction of the root level
     double* root_e;
@@ -1009,6 +1025,12 @@ struct LdsLevel {
     AS3 const double* dA;   // dense copies (tiny levels only)
     AS3 const double* dP;
     AS3 const double* dPt;
+    AS3 const double* pMr;  // polynomial form (tiny levels, see SolveLevel); NULL: sweeps
+    AS3 const double* pMe;
+    AS3 const double* pMc;
+    AS3 const double* pW;
+    int pLD;
+    bool poly;
     double xx;
     // semi-cached level: a 1024-row level does not fit in LDS beside the deeper ones, but its
     // rows are short (3-7 entries) and L2-resident; only r, e, e2 live in LDS
@@ -1054,6 +1076,12 @@ __device__ __forceinline__ LdsLevel lds_level(const SolveCtx& c, int k) {
     L.dA = as_lds(G.dA);
     L.dP = as_lds(G.dP);
     L.dPt = as_lds(G.dPt);
+    L.pMr = as_lds(G.pMr);
+    L.pMe = as_lds(G.pMe);
+    L.pMc = as_lds(G.pMc);
+    L.pW = as_lds(G.pW);
+    L.pLD = G.pLD;
+    L.poly = G.pMr != nullptr;
     L.semi = (k == D->k_semi);
     L.grp = G.lv.rp;
     L.gci = G.lv.ci;
@@ -1321,8 +1349,229 @@ __device__ __forceinline__ void tiny_sweeps(SolveCtx& c, int k, LdsLevel& L, int
     }
 }
 
+// ---- polynomial form of a one-wave level --------------------------------------------------
+// nu smoothing sweeps are nu applications of ONE affine map, e <- S e + Rg r with
+// Rg g = 1 (1'g / xx) + R (g - A1 (1'g) / xx)  (isnsp; MG_Vcycle.m:15-21) or R g, R = Rk{k} = 0.5 D^-1
+// (Class_AMG.m:84), S = I - Rg A.  So the sweeps of a visit are e' = M1 e + M2 r with M1 = S^nu,
+// M2 = (I + S + ... + S^(nu-1)) Rg: dense N x N matrices (N <= 48) that k_pack_poly forms once per
+// hierarchy.  Residual and restriction of the visit (MG_Vcycle.m:27) fold in as well,
+//   r_c = P'(r - A e_pre) = (P' - (P'A) M2) r - (P'A) M1 e ,
+// and so does the prolongation (MG_Vcycle.m:31) into the post-smoothing,
+//   e'' = M1 (e_pre + P e_c) + M2 r = M1 e_pre + (M1 P) e_c + M2 r :
+// a visit is TWO passes of independent dense row dots by one wave (~0.3 us each) instead of 2 nu
+// dependent sweeps + residual + restriction + prolongation (~9 us at nu = 5).  Same linear operator,
+// different rounding (1e-15 relative): the solve phase is compared through residual histories.
+// One pass = one stream of 8-column blocks over the operators [Mr | Me | Mc], which lie one behind the
+// other in the image (block q of the stream starts at M + q*8*LD), against the vectors x0 (blocks
+// [0, n0)), x1 ([n0, n0+n1)), x2 (the rest).  Every load of a block sits at a compile-time offset from
+// the block's two base addresses, and the loads of the NEXT block are issued before the current one
+// is consumed: with the latency of every trip exposed a pass took 1.0-1.7 us (measured), it is
+// bound by LDS issue otherwise.  sx (optional): sum of the entries of x0.
+template <int LD>
+struct PolyBlk {
+    double a[8], v[8];
+    __device__ __forceinline__ void load(AS3 const double* pm, AS3 const double* px) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = pm[u * LD];
+            v[u] = px[u];
+        }
+    }
+    __device__ __forceinline__ void use(double (&s)[4], double& sx, double fx) const {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u & 3] = __builtin_fma(a[u], v[u], s[u & 3]);
+        if (fx != 0.0) {   // (uniform per block of a lane's stream)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sx += v[u];
+        }
+    }
+};
+// (a plain function of scalars: a lambda's closure object ended up in scratch memory, one
+// scratch_load per block, because the select between its fields became a load through a selected address)
+__device__ __forceinline__ AS3 const double* poly_px(int q, int n0, int n01, unsigned a0, unsigned a1,
+                                                     unsigned a2) {
+    unsigned base = a2;
+    if (q < n01) base = a1;
+    if (q < n0) base = a0;
+    return (AS3 const double*)(size_t)(base + 64u * (unsigned)q);
+}
+template <int LD>
+__device__ __forceinline__ double poly_stream(AS3 const double* M, int nb, int sub, int Lt, AS3 const double* x0,
+                                              int n0, AS3 const double* x1, int n1, AS3 const double* x2,
+                                              bool want_sx, double& sx) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    PolyBlk<LD> A, B;
+    if (nb <= 0) return 0.0;
+    if (Lt == 1) {
+        // One lane per row (more than 32 rows: the usual case): the block index is uniform, so the
+        // segment selects are scalar and the prefetch is unconditional (the last trip re-reads its own
+        // block) -- a load inside a divergent branch makes the compiler wait for ALL outstanding loads
+        // at the join (seen in the ISA: s_waitcnt lgkmcnt(0) right behind the prefetch).
+        // (the vectors' LDS addresses as plain integers in SGPRs: selecting among the three POINTERS
+        // made the compiler park them in scratch memory and fetch the chosen one per block)
+        const unsigned a0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)x0);
+        const unsigned a1 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)x1) - 64u * (unsigned)n0;
+        const unsigned a2 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)x2) - 64u * (unsigned)(n0 + n1);
+#define px_of(q) poly_px((q), n0, n0 + n1, a0, a1, a2)
+        int q = 0;
+        A.load(M, px_of(0));
+        for (;;) {
+            int qn = q + 1;
+            int ql = qn < nb ? qn : q;
+            B.load(M + ql * (8 * LD), px_of(ql));
+            A.use(s, sx, (want_sx && q < n0) ? 1.0 : 0.0);
+            if (qn >= nb) break;
+            q = qn;
+            qn = q + 1;
+            ql = qn < nb ? qn : q;
+            A.load(M + ql * (8 * LD), px_of(ql));
+            B.use(s, sx, (want_sx && q < n0) ? 1.0 : 0.0);
+            if (qn >= nb) break;
+            q = qn;
+        }
+#undef px_of
+        return (s[0] + s[1]) + (s[2] + s[3]);
+    }
+    // several lanes per row (at most 32 rows): each lane walks its own blocks sub, sub + Lt, ...
+    for (int q = sub; q < nb; q += Lt) {
+        AS3 const double* px = q < n0 ? x0 + 8 * q : (q < n0 + n1 ? x1 + 8 * (q - n0) : x2 + 8 * (q - n0 - n1));
+        A.load(M + q * (8 * LD), px);
+        A.use(s, sx, (want_sx && q < n0) ? 1.0 : 0.0);
+    }
+    return (s[0] + s[1]) + (s[2] + s[3]);
+}
+__device__ __forceinline__ int poly_lanes(int rows) {
+    int L = 1;
+    while (L < 8 && rows * (L * 2) <= 64) L <<= 1;
+    return L;
+}
+// pre-smoothing + residual + restriction: e2 <- M1 e + M2 r, child's r <- (...) r - (...) e
+template <int LD>
+__device__ __forceinline__ void poly_pre_ld(SolveCtx& c, int k, LdsLevel& L, bool keep) {
+    const int N = L.N, R = L.N + L.Nc, Lt = poly_lanes(R), t = threadIdx.x;
+    const int sub = t % Lt, row = t / Lt, rw = row < R ? row : 0, nblk = (N + 7) >> 3;
+    double sx = 0.0;
+    const int skip = (((const AS3 SolveDesc*)c.D)->dbg_skip & 1) ? 0 : 1;
+    double y = poly_stream<LD>(L.pMr + rw, skip * (keep ? 2 * nblk : nblk), sub, Lt, L.r, nblk, L.e, nblk, L.e, true, sx);
+    y = subwave_sum(y, Lt);
+    sx = subwave_sum(sx, Lt);
+    y = __builtin_fma(L.pW[rw], sx, y);
+    if (t == 0) as_lds(c.sumr)[k] = sx;      // 1'r of this visit: the post-smoothing pass needs it again
+    if (row < R && sub == 0) {
+        if (row < N)
+            L.e2[row] = y;
+        else
+            L.rc[row - N] = y;
+    }
+    tiny_sync();
+    AS3 double* tt = L.e;
+    L.e = L.e2;
+    L.e2 = tt;
+    c.swapmask ^= (1u << k);
+    c.zeromask &= ~(1u << k);
+}
+// prolongation + post-smoothing: e2 <- M1 e + (M1 P) e_c + M2 r
+template <int LD>
+__device__ __forceinline__ void poly_post_ld(SolveCtx& c, int k, LdsLevel& L, AS3 const double* ec) {
+    const int N = L.N, Lt = poly_lanes(N), t = threadIdx.x;
+    const int sub = t % Lt, row = t / Lt, rw = row < N ? row : 0, nblk = (N + 7) >> 3;
+    double dum = 0.0;
+    const int skip = (((const AS3 SolveDesc*)c.D)->dbg_skip & 1) ? 0 : 1;
+    double y = poly_stream<LD>(L.pMr + rw, skip * (2 * nblk + ((L.Nc + 7) >> 3)), sub, Lt, L.r, nblk, L.e, nblk, ec, false, dum);
+    y = subwave_sum(y, Lt);
+    y = __builtin_fma(L.pW[rw], as_lds(c.sumr)[k], y);
+    if (row < N && sub == 0) L.e2[row] = y;
+    tiny_sync();
+    AS3 double* tt = L.e;
+    L.e = L.e2;
+    L.e2 = tt;
+    c.swapmask ^= (1u << k);
+}
+__device__ __forceinline__ void poly_pre(SolveCtx& c, int k, LdsLevel& L, bool keep) {
+    if (L.pLD == 32)
+        poly_pre_ld<32>(c, k, L, keep);
+    else if (L.pLD == 48)
+        poly_pre_ld<48>(c, k, L, keep);
+    else
+        poly_pre_ld<64>(c, k, L, keep);
+}
+__device__ __forceinline__ void poly_post(SolveCtx& c, int k, LdsLevel& L, AS3 const double* ec) {
+    if (L.pLD == 32)
+        poly_post_ld<32>(c, k, L, ec);
+    else if (L.pLD == 48)
+        poly_post_ld<48>(c, k, L, ec);
+    else
+        poly_post_ld<64>(c, k, L, ec);
+}
+
+// PCG.m:68-87 on at most 16 rows (the coarsest level of every realistic hierarchy: thr = 1 + fix(M^(1/3))
+// <= 16 up to M = 4096, Class_AMG.m:76).  Row i lives on lane i of the first DPP row, its matrix row in
+// registers: the two sums of an iteration are 4-step row sums whose result every lane holds (no
+// read-back through an SGPR), the matrix-vector product is one trip of independent LDS reads, the
+// reciprocal of delta_old is formed beside that trip, and M^-1 r multiplies by the stored reciprocal
+// diagonal.  Measured on 7 / 11 rows: 3.2 / 2.9 -> see DESIGN us per solve.  Same recurrences as
+// tiny_pcg; beta and M^-1 r differ from a true division by one rounding.
+__device__ __forceinline__ void tiny_pcg16(SolveCtx& c, int k, const LdsLevel& L) {
+    const AS3 SolveDesc* D = (const AS3 SolveDesc*)c.D;
+    const double tol = D->pcg.tol;
+    const long long maxit = (D->dbg_skip & 2) ? 0 : D->pcg.maxit;
+    const int precd = D->pcg.precd;
+    AS3 double* pv = as_lds(D->pcg.work);
+    const int N = L.N, i = threadIdx.x;
+    const bool valid = i < N;
+    const int ir = valid ? i : 0;
+    double a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = (valid && j < N) ? L.dA[ir + (j < N ? j : 0) * N] : 0.0;
+    const double dg = valid ? L.dA[ir + ir * N] : 1.0;
+    const double idg = precd == 2 ? 1.0 / dg : 1.0;
+    double r = valid ? L.r[ir] : 0.0;
+    double p = precd == 2 ? r / dg : r;
+    double d = 0.0;
+    double delta_new = row16_sum(r * p);
+    delta_new = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(delta_new)),
+                                 __builtin_amdgcn_readfirstlane(__double2loint(delta_new)));
+    const double thresh = tol * tol * delta_new;
+    long long it = 0;
+    while (it < maxit && delta_new > thresh) {   // (wave-uniform: delta_new is lane 0's)
+        const double delta_old = delta_new;
+        if (valid) pv[i] = p;
+        tiny_sync();
+        const double rcp_old = 1.0 / delta_old;
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {
+            if (j >= N) break;   // uniform: whole 4-column chunks only
+            const double x0 = pv[j < N ? j : 0], x1 = pv[j + 1 < N ? j + 1 : 0];
+            const double x2 = pv[j + 2 < N ? j + 2 : 0], x3 = pv[j + 3 < N ? j + 3 : 0];
+            q0 += a[j] * (j < N ? x0 : 0.0);
+            q1 += a[j + 1] * (j + 1 < N ? x1 : 0.0);
+            q2 += a[j + 2] * (j + 2 < N ? x2 : 0.0);
+            q3 += a[j + 3] * (j + 3 < N ? x3 : 0.0);
+        }
+        const double q = (q0 + q1) + (q2 + q3);
+        tiny_sync();
+        const double alpha = delta_old / row16_sum(q * p);
+        d += alpha * p;
+        r -= alpha * q;
+        const double w = r * idg;
+        delta_new = row16_sum(r * w);
+        delta_new = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(delta_new)),
+                                     __builtin_amdgcn_readfirstlane(__double2loint(delta_new)));
+        p = w + (delta_new * rcp_old) * p;
+        ++it;
+    }
+    if (valid) L.e[i] = d;
+    tiny_sync();
+    c.zeromask &= ~(1u << k);
+}
+
 __device__ __forceinline__ void tiny_pcg(SolveCtx& c, int k) {  // PCG.m:68-87, Jacobi, zero guess
     const LdsLevel L = lds_level(c, k);
+    if (L.N <= 16) {
+        tiny_pcg16(c, k, L);
+        return;
+    }
     const AS3 SolveDesc* D = (const AS3 SolveDesc*)c.D;
     const double tol = D->pcg.tol;
     const long long maxit = D->pcg.maxit;
@@ -1375,6 +1624,15 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
                 continue;
             }
             LdsLevel L = lds_level(c, k);
+            if (L.poly) {   // polynomial form: sweeps, residual and restriction in one pass
+                SOL_DBG_T0(c);
+                poly_pre(c, k, L, keep);
+                SOL_DBG_ADD(c, 9);
+                visited &= ~(1u << (k + 1));
+                k = k + 1;
+                keep = false;
+                continue;
+            }
             if (!keep) {
                 c.zeromask |= (1u << k);
                 if (nu == 0) {
@@ -1419,6 +1677,14 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
                 continue;
             }
             LdsLevel L = lds_level(c, k);
+            if (L.poly) {   // polynomial form: prolongation and post-smoothing in one pass
+                SOL_DBG_T0(c);
+                poly_post(c, k, L, lds_e(c, k + 1));
+                SOL_DBG_ADD(c, 9);
+                if (k == k0) return;
+                k = k - 1;
+                continue;
+            }
             {
                 SOL_DBG_T0(c);
                 const int Lt = tiny_lanes(L.N), i = t / Lt, sub = t % Lt;
@@ -1486,8 +1752,10 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
     // more than two entries per lane on average: four per trip (one dependent LDS round trip less per
     // sweep on such levels; with two or fewer the masked slots of a wider batch only cost issue slots)
     const bool wide = !L.semi && L.rp[N] > 2 * N * Lr;
+    const int dskip = c.D->dbg_skip;
+    if (dskip & 8) nu = 0;
     for (int s = 0; s < nu; ++s) {
-        const bool ez = (c.zeromask >> k) & 1u;
+        const bool ez = (c.zeromask >> k) & 1u || (dskip & 4);
         const double eo = (valid && !ez) ? L.e[i] : 0.0;
         double cc = 0.0;
         if (isnsp) cc = (sumr - (ez ? 0.0 : blk_total(part + 16 * cur))) / L.xx;
@@ -1767,6 +2035,147 @@ __global__ __launch_bounds__(256) void k_pack_dense(const DenseEntry* __restrict
         for (int t = e.rp[r]; t < e.rp[r + 1]; ++t) dst[r + (size_t)e.ci[t] * e.rows] = e.va[t];
 }
 
+// Polynomial form of a one-wave level (see poly_pre / poly_post): one workgroup per level forms
+//   Rg = R + u 1', u = (1 - R A1) / xx (isnsp) or 0 ;  S = I - Rg A ;  M1 = S^nu ;
+//   M2 = sum_{j<nu} S^j Rg = M2a + w 1'  with  M2a = sum S^j R ,  w = sum S^j u
+//   T1 = P'A ;  Mr = [M2a; P' - T1 M2a] ;  W = [w; -T1 w] ;  Me = [M1; -T1 M1] ;  Mc = M1 P
+// with dense column-major matrices in LDS and writes Mr, Me, Mc, W into the image.  The rank-one part
+// w 1' stays apart because u ~ 1/xx is large (xx = 1'A1 ~ N bk1): added into every entry of M2 it
+// would cost the cancellation inside 1'r that the sweeps' own xig = 1'g enjoys (MG_Vcycle.m:17).
+struct PolyEntry {
+    const int *Arp, *Aci;
+    const double* Ava;
+    const int *Prp, *Pci;   // P  : N x Nc  (CSR)
+    const double* Pva;
+    const double* dinv;
+    const double* Axi;
+    const double* xx;
+    int N, Nc, nu, isnsp, LD;
+    unsigned offMr, offMe, offMc, offW;
+};
+__global__ __launch_bounds__(BT) void k_pack_poly(const PolyEntry* __restrict__ ents, char* __restrict__ img) {
+    extern __shared__ __attribute__((aligned(16))) char poly_raw[];
+    const PolyEntry e = ents[blockIdx.x];
+    const int N = e.N, Nc = e.Nc, R = N + Nc, LD = e.LD, t = threadIdx.x;
+    const int N8 = (N + 7) / 8 * 8, Nc8 = (Nc + 7) / 8 * 8;
+    double* A = reinterpret_cast<double*>(poly_raw);   // N x N, column-major like everything here
+    double* S = A + N * N;
+    double* M1 = S + N * N;
+    double* M2 = M1 + N * N;                            // M2a
+    double* T = M2 + N * N;                             // product scratch
+    double* P = T + N * N;                              // N x Nc
+    double* T1 = P + N * Nc;                            // Nc x N
+    double* u = T1 + Nc * N;                            // N
+    double* dv = u + N;                                 // N
+    double* w = dv + N;                                 // N
+    double* w2 = w + N;                                 // N
+    for (int i = t; i < N * N; i += BT) A[i] = 0.0;
+    for (int i = t; i < N * Nc; i += BT) P[i] = 0.0;
+    __syncthreads();
+    for (int r = t; r < N; r += BT) {
+        for (int q = e.Arp[r]; q < e.Arp[r + 1]; ++q) A[r + e.Aci[q] * N] = e.Ava[q];
+        for (int q = e.Prp[r]; q < e.Prp[r + 1]; ++q) P[r + e.Pci[q] * N] = e.Pva[q];
+        const double d = e.dinv[r];
+        dv[r] = d;
+        u[r] = e.isnsp ? (1.0 - d * e.Axi[r]) / e.xx[0] : 0.0;
+        w[r] = 0.0;
+    }
+    __syncthreads();
+    // S = I - Rg A,  (Rg A)[i][j] = dinv_i A[i][j] + u_i (1'A)_j ;  M1 = I ;  M2a = 0 ;  w = 0
+    for (int q = t; q < N * N; q += BT) {
+        const int i = q % N, j = q / N;
+        double cs = 0.0;
+        for (int k = 0; k < N; ++k) cs += A[k + j * N];
+        S[q] = (i == j ? 1.0 : 0.0) - (dv[i] * A[q] + u[i] * cs);
+        M1[q] = i == j ? 1.0 : 0.0;
+        M2[q] = 0.0;
+    }
+    __syncthreads();
+    for (int s = 0; s < e.nu; ++s) {
+        // M2a <- R + S M2a ;  w <- u + S w ;  M1 <- S M1     (results parked: all read the old values)
+        for (int q = t; q < 2 * N * N + N; q += BT) {
+            if (q >= 2 * N * N) {
+                const int i = q - 2 * N * N;
+                double acc = 0.0;
+                for (int k = 0; k < N; ++k) acc += S[i + k * N] * w[k];
+                w2[i] = u[i] + acc;
+                continue;
+            }
+            const bool second = q >= N * N;
+            const int qq = second ? q - N * N : q;
+            const int i = qq % N, j = qq / N;
+            const double* B = second ? M1 : M2;
+            double acc = 0.0;
+            for (int k = 0; k < N; ++k) acc += S[i + k * N] * B[k + j * N];
+            if (second)
+                T[qq] = acc;
+            else
+                A[qq] = acc + (i == j ? dv[i] : 0.0);   // A is rebuilt below; until then: second scratch
+        }
+        __syncthreads();
+        for (int q = t; q < N * N; q += BT) {
+            M1[q] = T[q];
+            M2[q] = A[q];
+        }
+        for (int i = t; i < N; i += BT) w[i] = w2[i];
+        __syncthreads();
+    }
+    // A again (it was scratch), then T1 = P'A
+    for (int i = t; i < N * N; i += BT) A[i] = 0.0;
+    __syncthreads();
+    for (int r = t; r < N; r += BT)
+        for (int q = e.Arp[r]; q < e.Arp[r + 1]; ++q) A[r + e.Aci[q] * N] = e.Ava[q];
+    __syncthreads();
+    for (int q = t; q < Nc * N; q += BT) {
+        const int c = q % Nc, j = q / Nc;
+        double acc = 0.0;
+        for (int k = 0; k < N; ++k) acc += P[k + c * N] * A[k + j * N];
+        T1[q] = acc;
+    }
+    __syncthreads();
+    double* Mr = reinterpret_cast<double*>(img + e.offMr);
+    double* Me = reinterpret_cast<double*>(img + e.offMe);
+    double* Mc = reinterpret_cast<double*>(img + e.offMc);
+    double* W = reinterpret_cast<double*>(img + e.offW);
+    for (int q = t; q < LD * N8; q += BT) {
+        const int row = q % LD, j = q / LD;
+        double vr = 0.0, ve = 0.0;
+        if (j < N && row < N) {
+            vr = M2[row + j * N];
+            ve = M1[row + j * N];
+        } else if (j < N && row < R) {
+            const int c = row - N;
+            double a2 = 0.0, a1 = 0.0;
+            for (int k = 0; k < N; ++k) {
+                a2 += T1[c + k * Nc] * M2[k + j * N];
+                a1 += T1[c + k * Nc] * M1[k + j * N];
+            }
+            vr = P[j + c * N] - a2;
+            ve = -a1;
+        }
+        Mr[q] = vr;
+        Me[q] = ve;
+    }
+    for (int q = t; q < LD * Nc8; q += BT) {
+        const int i = q % LD, c = q / LD;
+        double acc = 0.0;
+        if (i < N && c < Nc)
+            for (int k = 0; k < N; ++k) acc += M1[i + k * N] * P[k + c * N];
+        Mc[q] = acc;
+    }
+    for (int row = t; row < LD; row += BT) {
+        double v = 0.0;
+        if (row < N) {
+            v = w[row];
+        } else if (row < R) {
+            const int c = row - N;
+            for (int k = 0; k < N; ++k) v += T1[c + k * Nc] * w[k];
+            v = -v;
+        }
+        W[row] = v;
+    }
+}
+
 static constexpr int RELOC_MAX = 640;
 __host__ __device__ constexpr size_t sol_r16(size_t b) { return (b + 15) / 16 * 16; }
 static constexpr size_t SOL_HEAD = sol_r16(sizeof(SolveDesc)) + sol_r16(4 * RELOC_MAX);
@@ -1778,6 +2187,13 @@ __device__ __forceinline__ SolveDesc* sol_load_image(const SolveDesc* Dg, char* 
     const uint4* src = reinterpret_cast<const uint4*>(Dg);
     uint4* dst = reinterpret_cast<uint4*>(dyn_raw + stage);
     for (int i = threadIdx.x; i < n16; i += BT) dst[i] = src[i];
+    // the work vectors behind the image start from zero: the polynomial passes read the vectors of the
+    // one-wave levels in whole 8-entry blocks, and their padding must stay zero
+    {
+        const int w16 = (Dg->lds_total - stage - Dg->image_bytes) / 16;
+        uint4* wz = dst + n16;
+        for (int i = threadIdx.x; i < w16; i += BT) wz[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     __syncthreads();
     SolveDesc* LD = reinterpret_cast<SolveDesc*>(dyn_raw + stage);
     const unsigned* rel =

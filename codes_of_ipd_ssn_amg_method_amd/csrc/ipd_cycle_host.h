@@ -748,18 +748,30 @@ void amg_prepare_levels(ipd_amg* h) {
         }
     };
     // bottom run of levels with <= 32 rows (k >= 2): candidates for the wave-level sub-cycle
-    // (33..64 rows run faster block-wide with 16 lanes per row than in one wave)
+    // (33..64 rows run faster block-wide with 16 lanes per row than in one wave) -- <= 48 rows when
+    // the one-wave levels take the polynomial form (tiny_cycle: a visit is two dense passes whatever
+    // the row count; IPD_NO_POLY=1: sweeps)
     int tiny_lo = h->J + 1;
-    int tiny_rows_max = 32;
-    if (const char* e = std::getenv("IPD_TINY_ROWS")) tiny_rows_max = std::max(1, std::min(64, std::atoi(e)));
-    {
+    bool use_poly = h->opts.smoth >= 1 && (h->opts.cycle == 'w' || h->opts.cycle == 'v') &&
+                    !(std::getenv("IPD_NO_POLY") && std::getenv("IPD_NO_POLY")[0] == '1') &&
+                    !(std::getenv("IPD_NO_BLK") && std::getenv("IPD_NO_BLK")[0] == '1');
+    auto find_tiny_lo = [&](int rows_max) {
+        int lo = h->J + 1;
+        if (const char* e = std::getenv("IPD_TINY_ROWS")) rows_max = std::max(1, std::min(64, std::atoi(e)));
         const char* nt = std::getenv("IPD_NO_TINY");
         if (!(nt && nt[0] == '1'))
             for (int k = h->J; k >= 2; --k) {
-                if (h->L[k].A.nr > tiny_rows_max) break;
-                tiny_lo = k;
+                if (h->L[k].A.nr > rows_max) break;
+                lo = k;
             }
-    }
+        return lo;
+    };
+    tiny_lo = find_tiny_lo(use_poly ? 48 : 32);
+    auto r8 = [](size_t n) { return (n + 7) / 8 * 8; };
+    auto poly_ld = [](size_t rows) -> size_t { return rows <= 32 ? 32 : (rows <= 48 ? 48 : 64); };
+    auto is_poly = [&](int k) {
+        return use_poly && k >= tiny_lo && k < h->J && h->L[k].A.nr + h->L[k + 1].A.nr <= 64;
+    };
     // the thread-per-row / wave sub-cycles keep the residual in the free iterate buffer and never
     // use the Gauss-Seidel scratch vector: 5 vectors per cached level instead of 7
     bool lean_vectors = true;
@@ -775,16 +787,24 @@ void amg_prepare_levels(ipd_amg* h) {
         for (int k = h->J; k >= 1; --k) {
             const Level& lv = h->L[k];
             const size_t N = (size_t)lv.A.nr;
-            size_t bytes = r16(4 * (N + 1)) + r16(4 * (size_t)lv.A.nnz) + r16(8 * (size_t)lv.A.nnz) +
-                           ((lean_vectors && k >= 2) ? 5 : 7) * r16(8 * N) + 16;
-            if (k < h->J) {
-                const size_t Nc = (size_t)h->L[k + 1].A.nr, np = (size_t)h->L[k + 1].P.nnz;
-                bytes += r16(4 * (Nc + 1)) + r16(4 * (N + 1)) + 2 * (r16(4 * np) + r16(8 * np));
-            }
-            if (k == h->J) bytes += r16(4 * 8 * N);
-            if (k >= tiny_lo) {   // dense copies of the tiny levels
-                bytes += r16(8 * N * N);
-                if (k < h->J) bytes += 2 * r16(8 * N * (size_t)h->L[k + 1].A.nr);
+            size_t bytes;
+            if (is_poly(k)) {
+                // polynomial form: [M2a; ..] and [M1; ..] stacked with the restriction, M1 P, w; three
+                // vectors; none of the level's CSR arrays (its parent applies the transfers to and from it)
+                const size_t Nc = (size_t)h->L[k + 1].A.nr, LD = poly_ld(N + Nc);
+                bytes = 2 * (8 * LD * r8(N)) + 8 * LD * r8(Nc) + 8 * LD + 3 * r16(8 * r8(N)) + 32;
+            } else {
+                bytes = r16(4 * (N + 1)) + r16(4 * (size_t)lv.A.nnz) + r16(8 * (size_t)lv.A.nnz) +
+                        ((lean_vectors && k >= 2) ? 5 : 7) * r16(8 * (k >= tiny_lo ? r8(N) : N)) + 16;
+                if (k < h->J) {
+                    const size_t Nc = (size_t)h->L[k + 1].A.nr, np = (size_t)h->L[k + 1].P.nnz;
+                    bytes += r16(4 * (Nc + 1)) + r16(4 * (N + 1)) + 2 * (r16(4 * np) + r16(8 * np));
+                }
+                if (k == h->J) bytes += r16(4 * 8 * N);
+                if (k >= tiny_lo) {   // dense copies of the tiny levels
+                    bytes += r16(8 * N * N);
+                    if (k < h->J) bytes += 2 * r16(8 * N * (size_t)h->L[k + 1].A.nr);
+                }
             }
             if (used + bytes > budget) break;
             used += bytes;
@@ -793,6 +813,17 @@ void amg_prepare_levels(ipd_amg* h) {
         *used_out = used;
         return k_lds;
     };
+    if (use_poly) {   // not at the price of a level that would otherwise be cached
+        size_t u = 0;
+        const int with_poly = plan_lds(16, &u);
+        const int lo_poly = tiny_lo;
+        use_poly = false;
+        tiny_lo = find_tiny_lo(32);
+        if (with_poly <= plan_lds(16, &u)) {
+            use_poly = true;
+            tiny_lo = lo_poly;
+        }
+    }
     auto tiny_from = [&](int k_lds) {   // tiny levels: <= 32 rows, cached, Jacobi (k >= 2)
         return std::max(tiny_lo, std::max(2, k_lds));
     };
@@ -829,6 +860,14 @@ void amg_prepare_levels(ipd_amg* h) {
             SolveLevel& T = sd->L[k];
             const size_t N = (size_t)T.lv.N;
             if (k == sd->k_semi) continue;         // matrix, transfers, dinv, Axi stay in global memory
+            if (is_poly(k) && k >= sd->k_tiny && sd->k_blk <= k) {   // polynomial form: no CSR arrays (see plan_lds)
+                put(T.lv.xx, 1);
+                T.lv.rp = T.lv.ci = nullptr;
+                T.lv.va = T.lv.dinv = T.lv.Axi = nullptr;
+                T.rest.rp = T.rest.ci = T.prol.rp = T.prol.ci = nullptr;
+                T.rest.va = T.prol.va = nullptr;
+                continue;
+            }
             put(T.lv.rp, N + 1);
             put(T.lv.ci, (size_t)T.nnzA);
             put(T.lv.va, (size_t)T.nnzA);
@@ -846,10 +885,49 @@ void amg_prepare_levels(ipd_amg* h) {
             }
         }
         std::vector<DenseEntry> dense;
+        std::vector<PolyEntry> polys;
+        size_t poly_lds = 0;
         for (int k = std::max(k_from, sd->k_tiny); k <= h->J; ++k) {
             SolveLevel& T = sd->L[k];
             const Level& lv = h->L[k];
             const size_t N = (size_t)lv.A.nr;
+            if (is_poly(k) && sd->k_blk <= k && k != sd->k_semi) {
+                const Csr& P = h->L[k + 1].P;
+                const size_t Nc = (size_t)P.nc;
+                const LevelDev& gd = st->run[(size_t)k].dev;   // global pointers (T's are LDS offsets by now)
+                PolyEntry pe;
+                pe.Arp = lv.A.rp;
+                pe.Aci = lv.A.ci;
+                pe.Ava = lv.A.va;
+                pe.Prp = P.rp;
+                pe.Pci = P.ci;
+                pe.Pva = P.va;
+                pe.dinv = gd.dinv;
+                pe.Axi = gd.Axi;
+                pe.xx = gd.xx;
+                pe.N = (int)N;
+                pe.Nc = (int)Nc;
+                pe.nu = sd->nu;
+                pe.isnsp = sd->isnsp;
+                const size_t LD = poly_ld(N + Nc);
+                pe.LD = (int)LD;
+                T.pLD = (int)LD;
+                size_t o = carve(8 * LD * r8(N));
+                pe.offMr = (unsigned)(o - stage);
+                set_off(T.pMr, o);
+                o = carve(8 * LD * r8(N));
+                pe.offMe = (unsigned)(o - stage);
+                set_off(T.pMe, o);
+                o = carve(8 * LD * r8(Nc));
+                pe.offMc = (unsigned)(o - stage);
+                set_off(T.pMc, o);
+                o = carve(8 * LD);
+                pe.offW = (unsigned)(o - stage);
+                set_off(T.pW, o);
+                polys.push_back(pe);
+                poly_lds = std::max(poly_lds, 8 * (5 * N * N + 2 * N * Nc + 4 * N) + 64);
+                continue;
+            }
             auto add = [&](const double*& field, const Csr& m) {
                 const size_t o = carve(8 * (size_t)m.nr * m.nc);
                 dense.push_back(DenseEntry{m.rp, m.ci, m.va, m.nr, m.nc, (unsigned)(o - stage)});
@@ -865,7 +943,8 @@ void amg_prepare_levels(ipd_amg* h) {
         const size_t image_bytes = off - stage;
         for (int k = k_from; k <= h->J; ++k) {     // work vectors: carved, not copied
             SolveLevel& T = sd->L[k];
-            const size_t N = (size_t)T.lv.N;
+            // (one-wave levels: zero-padded to whole 8-entry blocks, see sol_load_image)
+            const size_t N = k >= sd->k_tiny ? r8((size_t)T.lv.N) : (size_t)T.lv.N;
             set_off(T.lv.r, carve(N * 8));
             set_off(T.e, carve(N * 8));
             set_off(T.e2, carve(N * 8));
@@ -898,6 +977,9 @@ void amg_prepare_levels(ipd_amg* h) {
         }
         IPD_REQUIRE(relocs.size() <= (size_t)RELOC_MAX, IPD_E_LIMIT, "LDS image: too many relocations");
         sd->image_bytes = (int)image_bytes;
+        sd->dbg_skip = std::getenv("IPD_DEBUG_SKIP") ? std::atoi(std::getenv("IPD_DEBUG_SKIP")) : 0;
+        sd->lds_total = (int)r16(off);
+        off = r16(off);
         sd->nreloc = (int)relocs.size();
         *lds_total = off;
         char* img = reinterpret_cast<char*>(ar.alloc_bytes(image_bytes));
@@ -916,6 +998,14 @@ void amg_prepare_levels(ipd_amg* h) {
             ctx->upload_bytes(dd, dense.data(), dense.size() * sizeof(DenseEntry));
             hipLaunchKernelGGL(k_pack_dense, dim3((unsigned)dense.size()), dim3(256), 0, ctx->stream,
                                (const DenseEntry*)dd, img);
+            IPD_KERNEL_CHECK();
+        }
+        if (!polys.empty()) {
+            PolyEntry* pp = ctx->scratch->alloc<PolyEntry>(polys.size());
+            ctx->upload_bytes(pp, polys.data(), polys.size() * sizeof(PolyEntry));
+            IPD_OPTIN_LDS(ctx, k_pack_poly, 156 * 1024);
+            hipLaunchKernelGGL(k_pack_poly, dim3((unsigned)polys.size()), dim3(BT), poly_lds, ctx->stream,
+                               (const PolyEntry*)pp, img);
             IPD_KERNEL_CHECK();
         }
         return reinterpret_cast<SolveDesc*>(img);
@@ -2151,7 +2241,11 @@ extern "C" int ipd_amg_bench_subcycle(ipd_amg* h, int reps, double* total_ms, in
         IPD_HIP(hipMemsetAsync(dbg, 0, 128, ctx->stream));
         // patch the debug pointer into the image header
         const size_t off = offsetof(SolveDesc, dbg);
-        ctx->upload_bytes(reinterpret_cast<char*>(st->d_sub) + off, &dbg, sizeof(dbg));
+        // IPD_BENCH_NODBG=1: no stamps -- a stamp is two s_memrealtime reads and a read-modify-write of
+        // global memory (~0.5 us each): the per-stage figures are for proportions, the launch time
+        // without them is the one to quote
+        const bool nodbg = std::getenv("IPD_BENCH_NODBG") && std::getenv("IPD_BENCH_NODBG")[0] == '1';
+        if (!nodbg) ctx->upload_bytes(reinterpret_cast<char*>(st->d_sub) + off, &dbg, sizeof(dbg));
         {   // a right-hand side that is not zero (a zero one ends every coarse PCG at once)
             std::vector<double> rr((size_t)h->L[st->k_sub].N);
             unsigned lcg = 12345u;

@@ -153,11 +153,15 @@ def check_run(out, ref, keys, late_counts=True, rtol=1e-7):
     assert out["k"] == ref["k"]
     assert abs(out["fval"] - ref["fval"]) <= 1e-8 * max(1.0, abs(ref["fval"]))
     # Newton-step counts: identical while the stopping test |Fk| <= max(bk1/k^2, 1e-11) is far
-    # from the rounding floor; later the test compares numbers of size 1e-11 and may flip by one
+    # from the rounding floor.  Later the test compares two numbers of size 1e-11 (the AMG solve
+    # itself stops at retol = 1e-11, Class_AMG.m:95), so the count of a late iteration is rounding
+    # noise: the ORACLE's own late counts move when its Newton directions are perturbed by one
+    # unit in the last place (tests/test_oracle_drivers.py::test_late_newton_counts_are_rounding_noise:
+    # 5-6 of the last 11 iterations change), and one flipped test costs one or two further steps.
     a, b = out["SsN_itnum"].astype(int), np.asarray(ref["SsN_itnum"])
     assert a.shape == b.shape and np.array_equal(a[:15], b[:15])
     if late_counts:
-        assert np.abs(a - b).max() <= 1 and np.array_equal(a[:len(a) // 2], b[:len(a) // 2])
+        assert np.abs(a - b).max() <= 2 and np.array_equal(a[:len(a) // 2], b[:len(a) // 2])
     for key in keys:
         a, b = np.asarray(out[key]), np.asarray(ref[key])
         assert a.shape == b.shape

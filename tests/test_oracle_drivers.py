@@ -69,3 +69,35 @@ def test_class2_direct_and_amg_inner_solvers_agree():
     assert min(x.min(), y.min(), z.min()) >= 0
     assert abs(phi @ x - mu) <= 1e-5 * (1 + mu)              # transported mass
     assert np.linalg.norm(O.Ax(x, p, q) + np.concatenate([y, z]) - np.concatenate([r, l])) <= 1e-5
+
+
+def test_late_newton_counts_are_rounding_noise():
+    """Why the device tests bound late Newton-step counts loosely (and what round 2 saw as an
+    unexplained drift under IPD_NO_BLK=1): once SsN_Tol = max(bk1/k^2, 1e-11) sits at 1e-11 the
+    stopping test of the SsN loop (APD_SsN_Class1.m:137) compares |Fk|, which the AMG solve leaves at
+    ~retol = 1e-11 (Class_AMG.m:95), with 1e-11.  The ORACLE itself shows it: scaling every Newton
+    direction by (1 + 1e-15) -- one unit in the last place -- leaves k, f and the first 40 iterations'
+    counts unchanged and changes the counts of several later iterations."""
+    import numpy as np
+    from tests.test_gpu_driver import problem
+    pr = problem(1, 40, 28, seed=1)
+    start = D.warmup_class1(pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], np.inf, 100)
+    ref = D.apd_ssn_class1(pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], np.inf, inner="amg", start=start,
+                           rng=O.matlab_rng())
+    orig = O.Hybrid_AMG
+
+    def perturbed(pd, opts, rng):
+        z, it, rs, info = orig(pd, opts, rng)
+        return z * (1.0 + 1e-15), it, rs, info
+
+    O.Hybrid_AMG = perturbed
+    try:
+        out = D.apd_ssn_class1(pr["c"], pr["r"], pr["l"], pr["p"], pr["q"], np.inf, inner="amg", start=start,
+                               rng=O.matlab_rng())
+    finally:
+        O.Hybrid_AMG = orig
+    a, b = np.asarray(ref["SsN_itnum"]).astype(int), np.asarray(out["SsN_itnum"]).astype(int)
+    assert ref["k"] == out["k"] and a.shape == b.shape
+    assert abs(ref["fval"] - out["fval"]) <= 1e-10 * abs(ref["fval"])
+    assert np.array_equal(a[:40], b[:40])
+    assert np.count_nonzero(a != b) >= 2           # measured: 5 late iterations differ by one step
