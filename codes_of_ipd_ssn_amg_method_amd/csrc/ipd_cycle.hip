@@ -899,6 +899,9 @@ struct SolveLevel {
     const double* pMc;  // M1 P                   applied to the child's correction
     const double* pW;   // [w; -(P'A) w]          times 1'r
     int pLD;
+    // Thread-per-row levels: lane map (k_pack_lmap, see blk_sweeps) -- BT words {row | sub << 10 |
+    // log2(lanes of the row) << 14 | valid << 31} and one word "entries per lane" (0: walk in a loop).
+    const unsigned* lmap;
 };
 struct SolveDesc {
     int J, nu, isnsp, wcycle, anycycle, maxit;
@@ -999,9 +1002,11 @@ __device__ __forceinline__ void sol_sweep(SolveCtx& c, int k, bool post) {
 // So each visit first copies what it needs into registers as address_space(3) pointers;
 // the row walks then compile to ds_read.
 #define AS3 __attribute__((address_space(3)))
+// (the low 32 bits of a generic pointer into the LDS aperture ARE its LDS address; a plain
+// addrspacecast adds a null test per pointer, ~100 VALU instructions per lds_level() call)
 template <class T>
 __device__ __forceinline__ AS3 T* as_lds(T* p) {
-    return (AS3 T*)p;
+    return (AS3 T*)(unsigned)(size_t)p;
 }
 
 struct LdsLevel {
@@ -1031,6 +1036,8 @@ struct LdsLevel {
     AS3 const double* pW;
     int pLD;
     bool poly;
+    AS3 const unsigned* lmap;
+    bool mapped;
     double xx;
     // semi-cached level: a 1024-row level does not fit in LDS beside the deeper ones, but its
     // rows are short (3-7 entries) and L2-resident; only r, e, e2 live in LDS
@@ -1082,6 +1089,8 @@ __device__ __forceinline__ LdsLevel lds_level(const SolveCtx& c, int k) {
     L.pW = as_lds(G.pW);
     L.pLD = G.pLD;
     L.poly = G.pMr != nullptr;
+    L.lmap = as_lds(G.lmap);
+    L.mapped = G.lmap != nullptr;
     L.semi = (k == D->k_semi);
     L.grp = G.lv.rp;
     L.gci = G.lv.ci;
@@ -1711,6 +1720,63 @@ __device__ __forceinline__ void tiny_cycle(SolveCtx& c, int k0, bool keep0) {
 // a phase, measured).  Here thread i owns row i, a sweep is one row walk and ONE barrier: the
 // per-wave partial sums of (A1)'e that the kernel-space correction of the NEXT sweep needs
 // are published by the same barrier that publishes the new iterate.
+// Lane map of a thread-per-row level.  With a uniform number of lanes per row (lanes_per_row) a
+// sweep lasts as long as its longest row -- the coarse levels have hub rows of 60-100 entries against a
+// mean of 6 -- and short rows leave most lanes of their group idle.  k_pack_lmap deals the BT lanes
+// to the rows by length instead: a row of len entries gets 2^c lanes (c <= 4) so that no lane holds
+// more than E entries, with E the smallest of 2, 4, 8, ... for which the rows fit in BT lanes; groups
+// are sorted by size (aligned to their size, inside one 16-lane DPP row).  With E <= 4 the lane's
+// entries stay in registers for all sweeps of a visit and a sweep's row walk is ONE trip of gathers.
+struct LaneSlot {
+    int row, sub, lg;
+    bool valid;
+};
+__device__ __forceinline__ LaneSlot lane_slot(AS3 const unsigned* lmap) {
+    const unsigned w = lmap[threadIdx.x];
+    LaneSlot s;
+    s.valid = (w >> 31) != 0;
+    s.row = (int)(w & 1023u);
+    s.sub = (int)((w >> 10) & 15u);
+    s.lg = (int)((w >> 14) & 7u);
+    return s;
+}
+// sum over the lane's group of 2^lg lanes (lg differs from lane to lane), result in every lane of it
+__device__ __forceinline__ double subsum_var(double v, int lg) {
+    double t = dpp_get<0xB1, 0xf>(v);
+    v += lg >= 1 ? t : 0.0;
+    t = dpp_get<0x4E, 0xf>(v);
+    v += lg >= 2 ? t : 0.0;
+    t = dpp_get<0x141, 0xf>(v);
+    v += lg >= 3 ? t : 0.0;
+    t = dpp_get<0x140, 0xf>(v);
+    v += lg >= 4 ? t : 0.0;
+    return v;
+}
+// row walk of a mapped lane in a loop (rows beyond the register budget, and the residual phase)
+__device__ __forceinline__ double lds_rowdot_mapped(AS3 const int* ci, AS3 const double* va, int beg, int end,
+                                                    const LaneSlot& m, AS3 const double* x) {
+    const int Lr = 1 << m.lg;
+    double s = 0.0;
+    for (int t = beg + m.sub; t < end; t += 4 * Lr) {
+        int c[4];
+        double v[4], xv[4];
+        bool k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tu = t + u * Lr;
+            k[u] = tu < end;
+            c[u] = ci[k[u] ? tu : t];
+            v[u] = va[k[u] ? tu : t];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k[u]) s += v[u] * xv[u];
+    }
+    return subsum_var(s, m.lg);
+}
+
 __device__ __forceinline__ double blk_total(AS3 const double* part) {
     double s = 0.0;
 #pragma unroll
@@ -1730,9 +1796,18 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
     // thread-per-row with the first entries in registers, long rows are walked from L2 by Lr lanes
     const bool semi_long = L.semi && L.grp[N] > 12 * N;
     const bool semi_regs = L.semi && !semi_long;
-    const int Lr = semi_regs ? 1 : lanes_per_row(N);
-    const int i = threadIdx.x / Lr, sub = threadIdx.x % Lr;
-    const bool valid = i < N, owner = valid && sub == 0;
+    const bool mapped = L.mapped && !L.semi;
+    LaneSlot ms;
+    ms.row = ms.sub = ms.lg = 0;
+    ms.valid = false;
+    int mapE = 0;
+    if (mapped) {
+        ms = lane_slot(L.lmap);
+        mapE = (int)L.lmap[BT];
+    }
+    const int Lr = mapped ? (1 << ms.lg) : (semi_regs ? 1 : lanes_per_row(N));
+    const int i = mapped ? ms.row : threadIdx.x / Lr, sub = mapped ? ms.sub : threadIdx.x % Lr;
+    const bool valid = mapped ? ms.valid : i < N, owner = valid && sub == 0;
     AS3 double* part = as_lds(c.part);
     const double rv = valid ? L.r[i] : 0.0;
     const double ax = valid ? lvl_axi(L, i) : 0.0;
@@ -1749,6 +1824,21 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
         rbeg = L.grp[i];
         rend = L.grp[i + 1];
     }
+    // mapped level with at most eight entries per lane: they stay in registers for the visit
+    const bool mregs = mapped && mapE >= 1 && mapE <= 8;
+    const bool mregs8 = mregs && mapE > 4;
+    int mc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double mv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (mregs) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u >= 4 && !mregs8) break;
+            const int t = rbeg + sub + u * Lr;
+            const bool in = valid && t < rend;
+            mc[u] = in ? L.ci[t] : 0;
+            mv[u] = in ? L.va[t] : 0.0;
+        }
+    }
     // more than two entries per lane on average: four per trip (one dependent LDS round trip less per
     // sweep on such levels; with two or fewer the masked slots of a wider batch only cost issue slots)
     const bool wide = !L.semi && L.rp[N] > 2 * N * Lr;
@@ -1760,11 +1850,24 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
         double cc = 0.0;
         if (isnsp) cc = (sumr - (ez ? 0.0 : blk_total(part + 16 * cur))) / L.xx;
         double sd = 0.0;
-        if (!ez)
-            sd = semi_regs   ? semi_row_dot(L, R, L.e)
-                 : semi_long ? glb_rowdot_range(L.gci, L.gva, rbeg, rend, sub, Lr, L.e)
-                 : wide      ? lds_rowdot_range<4>(L.ci, L.va, rbeg, rend, sub, Lr, L.e)
-                             : lds_rowdot_range<2>(L.ci, L.va, rbeg, rend, sub, Lr, L.e);
+        if (!ez) {
+            if (mregs) {
+                const double x0 = L.e[mc[0]], x1 = L.e[mc[1]], x2 = L.e[mc[2]], x3 = L.e[mc[3]];
+                double acc = (mv[0] * x0 + mv[1] * x1) + (mv[2] * x2 + mv[3] * x3);
+                if (mregs8) {
+                    const double x4 = L.e[mc[4]], x5 = L.e[mc[5]], x6 = L.e[mc[6]], x7 = L.e[mc[7]];
+                    acc += (mv[4] * x4 + mv[5] * x5) + (mv[6] * x6 + mv[7] * x7);
+                }
+                sd = subsum_var(acc, ms.lg);
+            } else if (mapped) {
+                sd = lds_rowdot_mapped(L.ci, L.va, rbeg, rend, ms, L.e);
+            } else {
+                sd = semi_regs   ? semi_row_dot(L, R, L.e)
+                     : semi_long ? glb_rowdot_range(L.gci, L.gva, rbeg, rend, sub, Lr, L.e)
+                     : wide      ? lds_rowdot_range<4>(L.ci, L.va, rbeg, rend, sub, Lr, L.e)
+                                 : lds_rowdot_range<2>(L.ci, L.va, rbeg, rend, sub, Lr, L.e);
+            }
+        }
         const double v = eo + dv * (rv - sd - ax * cc) + cc;
         if (owner) L.e2[i] = v;
         if (isnsp) blk_publish(owner ? ax * v : 0.0, part + 16 * (cur ^ 1));
@@ -1844,7 +1947,12 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
             }
             {   // residual, then restriction into the child's right-hand side
                 SOL_DBG_T0(c);
-                {
+                if (L.mapped && !L.semi) {
+                    const LaneSlot ms = lane_slot(L.lmap);
+                    const int rb = ms.valid ? L.rp[ms.row] : 0, re = ms.valid ? L.rp[ms.row + 1] : 0;
+                    const double sd = lds_rowdot_mapped(L.ci, L.va, rb, re, ms, L.e);
+                    if (ms.valid && ms.sub == 0) L.e2[ms.row] = L.r[ms.row] - sd;
+                } else {
                     const int Lr = lanes_per_row(L.N), row = i / Lr, sub = i % Lr;
                     const bool rvld = row < L.N;
                     const double sd =
@@ -2033,6 +2141,84 @@ __global__ __launch_bounds__(256) void k_pack_dense(const DenseEntry* __restrict
     __syncthreads();
     for (int r = threadIdx.x; r < e.rows; r += 256)
         for (int t = e.rp[r]; t < e.rp[r + 1]; ++t) dst[r + (size_t)e.ci[t] * e.rows] = e.va[t];
+}
+
+// Lane map of a thread-per-row level (see blk_sweeps): one workgroup per level.
+struct LmapEntry {
+    const int* rp;
+    int N;
+    unsigned off;
+};
+__global__ __launch_bounds__(BT) void k_pack_lmap(const LmapEntry* __restrict__ ents, char* __restrict__ img) {
+    __shared__ int wsum[BT / 64];
+    __shared__ int cnt[5], base[5];
+    const LmapEntry e = ents[blockIdx.x];
+    unsigned* map = reinterpret_cast<unsigned*>(img + e.off);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int len = t < e.N ? e.rp[t + 1] - e.rp[t] : 0;
+    auto block_sum = [&](int v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if (lane == 0) wsum[wv] = v;
+        __syncthreads();
+        int s = 0;
+        for (int w = 0; w < BT / 64; ++w) s += wsum[w];
+        return s;
+    };
+    auto block_max = [&](int v) {
+        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+        __syncthreads();
+        if (lane == 0) wsum[wv] = v;
+        __syncthreads();
+        int s = 0;
+        for (int w = 0; w < BT / 64; ++w) s = max(s, wsum[w]);
+        return s;
+    };
+    const int maxlen = block_max(len);
+    int E = 2, need = 0;
+    for (;; E <<= 1) {
+        int n = 1;
+        while (n < 16 && n * E < len) n <<= 1;
+        need = t < e.N ? n : 0;
+        if (block_sum(need) <= BT || E >= (1 << 20)) break;   // (uniform)
+    }
+    int lg = 0;
+    while ((1 << lg) < need) ++lg;
+    if (t < 5) cnt[t] = 0;
+    map[t] = 0u;
+    __syncthreads();
+    // rank of the row among the rows of its class, in row order
+    int rank = 0;
+    for (int c = 0; c < 5; ++c) {
+        const bool mine = t < e.N && lg == c;
+        const unsigned long long b = __ballot(mine);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) wsum[wv] = __popcll(b);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < BT / 64; ++w) {
+            if (w < wv) woff += wsum[w];
+            tot += wsum[w];
+        }
+        if (mine) rank = woff + before;
+        if (t == 0) cnt[c] = tot;
+    }
+    __syncthreads();
+    if (t == 0) {   // classes by descending group size: every group is aligned to its size
+        int off = 0;
+        for (int c = 4; c >= 0; --c) {
+            base[c] = off;
+            off += cnt[c] << c;
+        }
+        map[BT] = (E <= 8 && maxlen <= 16 * E) ? (unsigned)E : 0u;
+    }
+    __syncthreads();
+    if (t < e.N) {
+        const int b0 = base[lg] + (rank << lg);
+        for (int s = 0; s < (1 << lg); ++s)
+            map[b0 + s] = (unsigned)t | ((unsigned)s << 10) | ((unsigned)lg << 14) | (1u << 31);
+    }
 }
 
 // Polynomial form of a one-wave level (see poly_pre / poly_post): one workgroup per level forms

@@ -779,6 +779,7 @@ void amg_prepare_levels(ipd_amg* h) {
         const char* nb = std::getenv("IPD_NO_BLK");
         if (nb && nb[0] == '1') lean_vectors = false;
     }
+    const bool use_lmap = !(std::getenv("IPD_NO_LMAP") && std::getenv("IPD_NO_LMAP")[0] == '1') && lean_vectors;
     // LDS cache plan: deepest levels first, while they fit; returns the first cached level
     auto plan_lds = [&](size_t stage, size_t* used_out) {
         size_t used = stage + SOL_HEAD + 256;
@@ -801,6 +802,7 @@ void amg_prepare_levels(ipd_amg* h) {
                     bytes += r16(4 * (Nc + 1)) + r16(4 * (N + 1)) + 2 * (r16(4 * np) + r16(8 * np));
                 }
                 if (k == h->J) bytes += r16(4 * 8 * N);
+                if (use_lmap && k >= 2 && k < tiny_lo && N <= (size_t)BT) bytes += r16(4 * (BT + 1));   // lane map
                 if (k >= tiny_lo) {   // dense copies of the tiny levels
                     bytes += r16(8 * N * N);
                     if (k < h->J) bytes += 2 * r16(8 * N * (size_t)h->L[k + 1].A.nr);
@@ -883,6 +885,14 @@ void amg_prepare_levels(ipd_amg* h) {
                 put(T.prol.ci, (size_t)T.nnzP);
                 put(T.prol.va, (size_t)T.nnzP);
             }
+        }
+        std::vector<LmapEntry> lmaps;
+        for (int k = std::max(k_from, sd->k_blk); k < std::min(sd->k_tiny, h->J + 1); ++k) {
+            if (!use_lmap || k == sd->k_semi || k < 2 || h->L[k].A.nr > BT || k == h->J) continue;
+            SolveLevel& T = sd->L[k];
+            const size_t o = carve(4 * (BT + 1));
+            lmaps.push_back(LmapEntry{h->L[k].A.rp, h->L[k].A.nr, (unsigned)(o - stage)});
+            set_off(T.lmap, o);
         }
         std::vector<DenseEntry> dense;
         std::vector<PolyEntry> polys;
@@ -998,6 +1008,13 @@ void amg_prepare_levels(ipd_amg* h) {
             ctx->upload_bytes(dd, dense.data(), dense.size() * sizeof(DenseEntry));
             hipLaunchKernelGGL(k_pack_dense, dim3((unsigned)dense.size()), dim3(256), 0, ctx->stream,
                                (const DenseEntry*)dd, img);
+            IPD_KERNEL_CHECK();
+        }
+        if (!lmaps.empty()) {
+            LmapEntry* lp = ctx->scratch->alloc<LmapEntry>(lmaps.size());
+            ctx->upload_bytes(lp, lmaps.data(), lmaps.size() * sizeof(LmapEntry));
+            hipLaunchKernelGGL(k_pack_lmap, dim3((unsigned)lmaps.size()), dim3(BT), 0, ctx->stream,
+                               (const LmapEntry*)lp, img);
             IPD_KERNEL_CHECK();
         }
         if (!polys.empty()) {

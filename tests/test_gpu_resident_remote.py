@@ -123,7 +123,15 @@ def _against_oracle(ipd, Ae, f, n, cycle, x0, expect_mode=None, kv=None):
     xo, ito, rro, relko, rhoko, ho = O.Class_AMG(Ae, f, o, O.matlab_rng(5489), return_hierarchy=True)
     assert h.level_sizes() == ho.level_sizes()
     assert [h.level_dims(k)[1] for k in range(1, h.J + 1)] == ho.level_nnz()
-    same_history(it, np.asarray(relk), ito, np.asarray(relko), tol=1e-10)
+    # Tolerance: 1e-10 on rel_res (north_star), unless the ORACLE's own history moves more than that
+    # under a perturbation of the right-hand side by one unit in the last place -- these systems have
+    # condition numbers of 1e8 and more (bk1 ~ 2e-5 against entries of 1/tk ~ 1e3), and on the latest
+    # one (k = 31) rounding alone moves rel_res(2) = 8e-4 by ~1e-10; the bound is then 8 x that.
+    sgn = np.where(np.random.RandomState(11).random_sample(f.size) < 0.5, -1.0, 1.0)
+    _, itp, _, relkp, _ = O.Class_AMG(Ae, f * (1.0 + 2.2e-16 * sgn), o, O.matlab_rng(5489))
+    kk = min(ito, itp) + 1
+    sens = float(np.max(np.abs(np.asarray(relko[:kk]) - np.asarray(relkp[:kk]))))
+    same_history(it, np.asarray(relk), ito, np.asarray(relko), tol=max(1e-10, 8.0 * sens))
     assert np.linalg.norm(Ae @ (x - xo)) <= 1e-9 * np.linalg.norm(f)
     h.close()
     return it, ito, relk, relko

@@ -18,6 +18,11 @@ for kcap in (9, 20, 30):
         opts = options(cycle, n)
         o = dict(opts); o.update(guess=x0)
         xo, ito, rro, relko, rhoko = O.Class_AMG(Ae, f, o, O.matlab_rng(5489))
+        sgn = np.where(np.random.RandomState(11).random_sample(f.size) < 0.5, -1.0, 1.0)
+        _, itp, _, relkp, _ = O.Class_AMG(Ae, f * (1.0 + 2.2e-16 * sgn), o, O.matlab_rng(5489))
+        kk = min(ito, itp) + 1
+        dd = np.abs(np.asarray(relko[:kk]) - np.asarray(relkp[:kk]))
+        print("k%d %s ORACLE vs ORACLE(f perturbed by 1 ulp): it %d/%d max|d| %.3e at %d" % (kcap + 1, cycle, ito, itp, dd.max(), int(dd.argmax())))
         for tag, kv in (("default", {}), ("NO_POLY", {"IPD_NO_POLY": "1"}), ("NO_RESIDENT", {"IPD_NO_RESIDENT": "1"}),
                         ("NO_RESIDENT+NO_POLY", {"IPD_NO_RESIDENT": "1", "IPD_NO_POLY": "1"})):
             os.environ.update(kv)
