@@ -41,6 +41,36 @@ def build_mask(m, n, kind, rho, seed=2):
     return mask_hub(m, n, seed=seed) if kind == "hub" else mask_tree(m, n, seed=seed)
 
 
+def capture_newton_system(ipd, N, kcap):
+    """A REALISTIC Newton system (regime R of SURVEY 8d): the Class 1 device driver on the synthetic
+    m=n=N problem (seed 1, draw order c, r, l; Sum l = Sum r) is run for `kcap` APD iterations, and
+    the first semismooth-Newton system of iteration kcap + 1 is assembled exactly as Hybrid_AMG.m:17-24
+    does (p = q = 1, T = 0).  Returns Ae, f, guess, nf, s (its largest connected component)."""
+    rs = np.random.RandomState(1)
+    c, r, l = rs.random_sample(N * N), rs.random_sample(N), rs.random_sample(N)
+    l = l * r.sum() / l.sum()
+    one = np.ones(N)
+    ws = ipd.APDWorkspace(1, c, r, l, one, one, gama=np.inf)
+    ws.warmup(0.0, 100)
+    amg = dict(retol=1e-11, bigph=1, maxit=30, theta=1 / 4, smoth=5, cycle="w", isnsp=1, inter=1)
+    ws.run(amg, ipd.MatlabRand(5489), iters=kcap)
+    lam = ws.state()[2]
+    sc = ws.begin(kcap + 1)
+    ev = ws.eval(lam)
+    ws.close()
+    H0 = ipd.ASAt(ev["s"], one, one)
+    Q0 = sp.diags(np.concatenate([one, -one]))
+    Ae = sp.csr_matrix(sc["bk1"] * (Q0 @ Q0) + (1.0 / sc["tk"]) * ((Q0 @ H0) @ Q0))
+    f = Q0 @ np.random.RandomState(3).standard_normal(2 * N)
+    guess = np.zeros(2 * N)
+    ncomp, lab = sp.csgraph.connected_components(Ae)
+    nf = N
+    if ncomp > 1:      # Hybrid_AMG.m:55-70: the large component, F side (indices < n) first
+        pk = np.flatnonzero(lab == np.argmax(np.bincount(lab)))
+        Ae, f, guess, nf = sp.csr_matrix(Ae[pk, :][:, pk]), f[pk], guess[pk], int((pk < N).sum())
+    return Ae, f, guess, nf, ev["s"], sc["bk1"], sc["tk"]
+
+
 def build_newton_system(ipd, m, n, s):
     """One semismooth-Newton system of the Class 1 driver in the rescaled form of
     Hybrid_AMG.m:17-24: Ae u = f.  H0 comes from the GPU ASAt."""
@@ -178,7 +208,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n1", type=int, default=1024)
     ap.add_argument("--rho", type=float, default=1.0)
-    ap.add_argument("--mask", default="bernoulli", choices=["bernoulli", "tree", "hub"])
+    ap.add_argument("--mask", default="bernoulli", choices=["bernoulli", "tree", "hub", "newton"],
+                    help="newton: a realistic Newton system captured from the Class 1 device driver "
+                         "at APD iteration --newton-k + 1 (regime R of SURVEY 8d)")
+    ap.add_argument("--newton-k", type=int, default=30)
     ap.add_argument("--cycle", default="v", choices=["v", "w"])
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -223,17 +256,22 @@ def main():
 
     m = n = args.n1
     M = m + n
-    s = build_mask(m, n, args.mask, args.rho)
-    Ae, f, guess, H0 = build_newton_system(ipd, m, n, s)
+    nf = n
+    if args.mask == "newton":
+        Ae, f, guess, nf, s, bk1_, tk_ = capture_newton_system(ipd, args.n1, args.newton_k)
+        M = Ae.shape[0]
+    else:
+        s = build_mask(m, n, args.mask, args.rho)
+        Ae, f, guess, H0 = build_newton_system(ipd, m, n, s)
     opts = dict(retol=1e-11, bigph=1, maxit=30, theta=0.25, smoth=5, cycle=args.cycle, isnsp=1,
-                inter=1, fnode=n)
+                inter=1, fnode=nf)
     t0 = time.perf_counter()
     h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
     setup_s = time.perf_counter() - t0
     ctx = _lib.get_ctx()
     # matrix-free level 1: same policy as the solvers (csrc/ipd_cycle_host.h amg_attach_maskop)
     maskop = False
-    if not args.no_maskop and (args.maskop or Ae.nnz >= 4.0e6):
+    if args.mask != "newton" and not args.no_maskop and (args.maskop or Ae.nnz >= 4.0e6):
         from ctypes import c_int32 as _ci32
         dp = _lib.DeviceBuffer.from_array(np.ones(m))
         dq = _lib.DeviceBuffer.from_array(np.ones(n))
@@ -394,9 +432,13 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True,
         "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "class1-OT m=n=%d, regime-D mask %s rho=%g, %s-cycle AMG "
-                               "(smoth 5, theta 1/4, bigph, isnsp), fixed hierarchy" % (
-                                   m, args.mask, args.rho, args.cycle.upper()),
+        "config": {"workload": ("class1-OT m=n=%d, regime-D mask %s rho=%g, %s-cycle AMG "
+                                "(smoth 5, theta 1/4, bigph, isnsp), fixed hierarchy" % (
+                                    m, args.mask, args.rho, args.cycle.upper()))
+                   if args.mask != "newton" else
+                   ("class1-OT m=n=%d, regime R: first Newton system of APD iteration %d of the device "
+                    "driver run (bk1 %.3e, tk %.3e), %s-cycle AMG (smoth 5, theta 1/4, bigph, isnsp), "
+                    "fixed hierarchy" % (m, args.newton_k + 1, bk1_, tk_, args.cycle.upper())),
                    "M": M, "E": int(s.sum()), "levels": h.level_sizes(),
                    "level_nnz": [h.level_dims(k)[1] for k in range(1, h.J + 1)],
                    "level1_operator": "bit mask + scale vectors" if maskop else "CSR",
@@ -505,7 +547,7 @@ def main():
         else:
             result["roofline"] = ksm
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(Ae, f, guess, opts, n)
+            result["cpu_baseline"] = cpu_baseline(Ae, f, guess, opts, nf)
             result["cpu_baseline"]["host_cores_available"] = os.cpu_count()
     if rank == 0:
         print(json.dumps(result))
