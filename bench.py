@@ -279,6 +279,10 @@ def main():
         _lib.check(_lib.lib.ipd_amg_attach_mask_operator(h.handle, dp.ptr, dq.ptr, c_int64(m),
                                                          c_int64(n), c_double(TK), byref(got)))
         maskop = bool(got.value)
+    xmask = False
+    if args.mask != "newton" and not args.no_maskop:
+        # level-resident kernel: level 1 <-> 2 transfers from the bit mask (what Hybrid_AMG does itself)
+        xmask = h.attach_mask_transfers(np.ones(m), np.ones(n), TK)
     db = _lib.DeviceBuffer.from_array(f)
     dx = _lib.DeviceBuffer.from_array(guess)
 
@@ -442,6 +446,7 @@ def main():
                    "M": M, "E": int(s.sum()), "levels": h.level_sizes(),
                    "level_nnz": [h.level_dims(k)[1] for k in range(1, h.J + 1)],
                    "level1_operator": "bit mask + scale vectors" if maskop else "CSR",
+                   "resident_transfers": "bit mask + scale vectors" if xmask else "CSR rows of P', P",
                    "parallelism": ("row-block sharded x%d, RCCL all-gather" % world) if sharded
                    else ("replicas x%d" % world if world > 1 else "single GPU")},
         "cycle_bytes_algorithmic": bytes_per_cycle,

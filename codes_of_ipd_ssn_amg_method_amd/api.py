@@ -248,6 +248,18 @@ class AMGHierarchy:
         self.ctx.sync()
         return bool(got.value)
 
+    def attach_mask_transfers(self, p, q, tk) -> bool:
+        """``ipd_amg_attach_mask_transfers``: the level-resident kernel's level 1 <-> 2 transfers from the
+        bit mask (True when in use)."""
+        p_, q_ = f64(p), f64(q)
+        dp = L.DeviceBuffer.from_array(p_, self.ctx)
+        dq = L.DeviceBuffer.from_array(q_, self.ctx)
+        got = c_int32(0)
+        check(lib.ipd_amg_attach_mask_transfers(self.handle, dp.ptr, dq.ptr, c_int64(p_.size),
+                                                c_int64(q_.size), c_double(float(tk)), byref(got)))
+        self.ctx.sync()
+        return bool(got.value)
+
     def level_dims(self, k: int):
         rows, nnz = c_int64(), c_int64()
         check(lib.ipd_amg_level_dims(self.handle, c_int(k), byref(rows), byref(nnz)))

@@ -274,6 +274,8 @@ extern "C" void ipd_ctx_destroy(ipd_ctx* ctx) {
     ctx->pool.release_all();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->mailbox) (void)hipHostFree(const_cast<unsigned*>(ctx->mailbox));
+    for (hipEvent_t& ev : ctx->tev)
+        if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -434,12 +434,17 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
     if (!lease.ok) return false;
     ResDesc D = st->res_desc;
     D.dbg = dbg_dev;
+    if (const char* dl = std::getenv("IPD_DEBUG_LEVELS"); dl && dl[0] == '1')
+        std::fprintf(stderr, "[ipd] resident launch: grid %d ke %d ke3 %d xm %d wident %d three %d remote %d\n", grid,
+                     st->res_ke, st->res_ke3, D.xm, D.wident, D.three, D.remote);
     st->res_desc.dbg_skip_seq = 0;   // the test hook fires on ONE launch
     IPD_HIP(hipMemsetAsync(st->res_block, 0, st->res_block_bytes, ctx->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ms) {
-        IPD_HIP(hipEventCreate(&e0));
-        IPD_HIP(hipEventCreate(&e1));
+        for (hipEvent_t& ev : ctx->tev)
+            if (!ev) IPD_HIP(hipEventCreate(&ev));
+        e0 = ctx->tev[0];
+        e1 = ctx->tev[1];
         IPD_HIP(hipEventRecord(e0, ctx->stream));
     }
     // The workgroups spin on one another, so ALL of them must be on the chip at once: the grid is
@@ -481,10 +486,6 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
     }
 #undef IPD_RES_LAUNCH
     if (!fits) {
-        if (ms) {
-            IPD_HIP(hipEventDestroy(e0));
-            IPD_HIP(hipEventDestroy(e1));
-        }
         st->res_ok = false;
         return false;
     }
@@ -493,11 +494,7 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
     const size_t nout = 4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2);
     std::vector<double> out(nout);
     ctx->fetch(st->res_out, out.data(), nout);   // synchronises the stream
-    if (ms) {
-        IPD_HIP(hipEventElapsedTime(ms, e0, e1));
-        IPD_HIP(hipEventDestroy(e0));
-        IPD_HIP(hipEventDestroy(e1));
-    }
+    if (ms) IPD_HIP(hipEventElapsedTime(ms, e0, e1));
     if (out[3] != 0.0) {   // a bounded spin gave up somewhere (any workgroup: the kernel reports the
         // time-out word, not only workgroup 0's own view): not every workgroup was resident
         ++st->res_timeouts;
@@ -1557,16 +1554,24 @@ __global__ void k_maskop_scales(int nf, int nc, const double* __restrict__ p,
 // attach it from 4 M entries on; IPD_MASKOP=1 lowers that to 16 entries per row, IPD_NO_MASKOP=1
 // switches it off.  An explicit ipd_amg_attach_mask_operator call is not subject to the policy.
 bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int m, int n, double tk,
-                       bool policy) {
+                       bool policy, bool transfers_only) {
     ipd_ctx* ctx = h->ctx;
     CycleState* st = state_of(h);
     if (!st) return false;
     const Level& lv = h->L[1];
+    // the level-resident kernel takes its level 1 <-> 2 transfers from the mask whatever the size
+    const bool for_resident = st->res_ok && !st->res_desc.three && st->res_desc.wident && h->J == 3 &&
+                              !(std::getenv("IPD_RES_NO_XMASK") && std::getenv("IPD_RES_NO_XMASK")[0] == '1');
+    bool sweeps_too = !transfers_only;
+    if (transfers_only && !for_resident) return false;
     if (policy) {
         const char* off = std::getenv("IPD_NO_MASKOP");
         if (off && off[0] == '1') return false;
         const char* on = std::getenv("IPD_MASKOP");
-        if (!(on && on[0] == '1') && (double)lv.A.nnz < 4.0e6) return false;
+        if (!(on && on[0] == '1') && (double)lv.A.nnz < 4.0e6) {
+            if (!for_resident) return false;
+            sweeps_too = false;   // below the size where the mask SWEEPS of the launch path pay
+        }
     }
     if (h->J < 2 || lv.nf != n || lv.N != m + n || tk == 0.0) return false;
     // a row of the mask costs nw word walks whatever its population: with fewer than ~16 entries
@@ -1600,6 +1605,27 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
     mo.alpha = alpha;
     mo.beta = beta;
     mo.diag = diag;
+    if (for_resident && lv.nf <= RES_NMAX / 2 && h->L[2].A.nr == m) {
+        // W(j,i) = s_ij beta_i rho_j: rho from the row sums (isnsp: rows normalised to sum 1, transfer.m:22-24)
+        // or alpha_j / A_jj, then every entry of P checked against the form
+        double* rho = ar.alloc<double>((size_t)n);
+        IPD_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_res_xmask_rho, dim3(cdiv(n, 4)), dim3(256), 0, ctx->stream, n, m, h->opts.isnsp,
+                           (const unsigned long long*)fb, mo.nwf, (const double*)alpha, (const double*)beta,
+                           (const double*)diag, h->L[2].P.rp, h->L[2].P.ci, h->L[2].P.va, rho, bad);
+        IPD_KERNEL_CHECK();
+        if (ctx->fetch1(bad) == 0) {
+            ResDesc& D = st->res_desc;
+            D.xm = 1;
+            D.xm_nwf = mo.nwf;
+            D.xm_nwc = mo.nwc;
+            D.xm_fbits = fb;
+            D.xm_cbits = cb;
+            D.xm_beta = beta;
+            D.xm_rho = rho;
+        }
+    }
+    if (!sweeps_too) return st->res_desc.xm != 0;
     st->maskop = mo;
     st->mask_ok = true;
     // captured graphs (if any) were recorded with the CSR sweeps
@@ -1617,7 +1643,18 @@ extern "C" int ipd_amg_attach_mask_operator(ipd_amg* h, const double* p_dev, con
         IPD_REQUIRE(h && p_dev && q_dev && m > 0 && n > 0, IPD_E_ARG, "bad argument");
         h->ctx->set_device();
         CallScope scope(h->ctx);
-        const bool ok = amg_attach_maskop(h, p_dev, q_dev, (int)m, (int)n, tk, false);
+        const bool ok = amg_attach_maskop(h, p_dev, q_dev, (int)m, (int)n, tk, false, false);
+        if (attached) *attached = ok ? 1 : 0;
+    });
+}
+
+extern "C" int ipd_amg_attach_mask_transfers(ipd_amg* h, const double* p_dev, const double* q_dev,
+                                             int64_t m, int64_t n, double tk, int32_t* attached) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && p_dev && q_dev && m > 0 && n > 0, IPD_E_ARG, "bad argument");
+        h->ctx->set_device();
+        CallScope scope(h->ctx);
+        const bool ok = amg_attach_maskop(h, p_dev, q_dev, (int)m, (int)n, tk, false, true);
         if (attached) *attached = ok ? 1 : 0;
     });
 }

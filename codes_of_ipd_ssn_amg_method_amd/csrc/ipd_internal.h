@@ -156,6 +156,9 @@ struct ipd_ctx {
     // hierarchies -- counting per hierarchy would pay the stall on every one of them)
     int res_giveups = 0;
     int res_penalty = 0;
+    // a pair of timing events kept for the context's lifetime (bench hooks: creating and destroying
+    // a pair per call costs ~10 us of the timed region)
+    hipEvent_t tev[2] = {nullptr, nullptr};
 
     // read back `n` elements synchronously through the pinned staging buffer
     template <class T>

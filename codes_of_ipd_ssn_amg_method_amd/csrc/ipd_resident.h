@@ -41,7 +41,7 @@ static constexpr int RES_WAVES = BT / 64;     // row slots per block and workgro
 static constexpr int RES_TAIL_MAX = 64;       // rows of the redundantly solved tail level
 static constexpr int RES_NMAX = 4 * BT;        // rows per level (fixed LDS slots)
 static constexpr int RES_GRAN_MAX = RES_NMAX;  // granules per hand-off buffer
-static constexpr size_t RES_LDS_BYTES = sizeof(double) * ((size_t)9 * RES_NMAX + 3 * RES_TAIL_MAX + 16 * RES_WAVES + 12);
+static constexpr size_t RES_LDS_BYTES = sizeof(double) * ((size_t)9 * RES_NMAX + RES_NMAX / 2 + 3 * RES_TAIL_MAX + 16 * RES_WAVES + 12);
 static constexpr unsigned RES_SPIN_MAX = 1u << 18;
 
 struct ResLevelDesc {
@@ -77,6 +77,16 @@ struct ResDesc {
     unsigned char* tin;       // 2 x RES_GRAN_MAX granules by visit parity
     unsigned char* tout;
     unsigned* tctl;           // [0] != 0: the solve is over, the tail workgroup leaves
+    // Level 1 <-> 2 transfers from the active-set bit mask (amg_attach_maskop, three-level hierarchies
+    // with bigraph transfers only): W(j,i) = s_ij beta_i rho_j (AMG/transfer.m:19-25 on Hybrid_AMG's
+    // rescaled operator), so a row of P' or P is 1 bit per entry -- 16 bits per lane, held in one
+    // register -- against a pre-scaled LDS vector, instead of a CSR row walked from L2 (12.6 MB per
+    // cycle, 5 us of a 72 us cycle).  xm != 0: fbits / cbits as MaskOp (row-major 64-bit words).
+    int xm, xm_nwf, xm_nwc;
+    const unsigned long long* xm_fbits;
+    const unsigned long long* xm_cbits;
+    const double* xm_beta;   // nc: the C node's factor
+    const double* xm_rho;    // nf: the F row's factor (1 / row sum with isnsp)
     int localfirst;   // zero-start first sweeps formed locally (see k_resident); 0: handed off like the rest
     int wident;       // P = [W; I] verified (k_res_check_ident): identity entries are added, not walked
     int Nt;           // rows of the tail level (local tail) or of the remote tail's root level
@@ -263,6 +273,39 @@ __global__ void k_res_check_ident(int nf, int N2, ResCsr P, ResCsr Pt, int* __re
     }
 }
 
+// rho of the mask-form transfers and the check of P against W(j,i) = s_ij beta_i rho_j (one wave per F row
+// j: its row of P holds exactly the row's mask entries, in column order, each within 1e-12 of the form)
+__global__ __launch_bounds__(256) void k_res_xmask_rho(int nf, int nc, int isnsp,
+                                                       const unsigned long long* __restrict__ fbits, int nwf,
+                                                       const double* __restrict__ alpha,
+                                                       const double* __restrict__ beta,
+                                                       const double* __restrict__ diag, const int* __restrict__ prp,
+                                                       const int* __restrict__ pci, const double* __restrict__ pva,
+                                                       double* __restrict__ rho, int* __restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (j >= nf) return;
+    double sb = 0.0;
+    int cnt = 0;
+    for (int w = 0; w < nwf; ++w) {
+        const unsigned long long bits = fbits[(size_t)j * nwf + w];
+        const int i = w * 64 + lane;
+        if ((bits >> lane) & 1ull) sb += beta[i];
+        cnt += __popcll(bits);
+    }
+    sb = wave_sum(sb);
+    const double r = isnsp ? 1.0 / sb : alpha[j] / diag[j];
+    if (lane == 0) rho[j] = r;
+    bool wrong = (prp[j + 1] - prp[j]) != cnt;
+    for (int t = prp[j] + lane; t < prp[j + 1] && !wrong; t += 64) {
+        const int i = pci[t];
+        const bool bit = i >= 0 && i < nc && ((fbits[(size_t)j * nwf + (i >> 6)] >> (i & 63)) & 1ull);
+        const double ref = beta[i < nc ? i : 0] * r;
+        if (!bit || !(fabs(pva[t] - ref) <= 1e-12 * fabs(ref))) wrong = true;
+    }
+    if (wrong) atomicExch(bad, 1);
+}
+
 // Block sums of up to two per-thread partials through red[0..2*RES_WAVES): the caller has
 // written red[w] / red[RES_WAVES + w] before the barrier that precedes this call.
 __device__ __forceinline__ double res_red8(const double* red) {
@@ -353,7 +396,10 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     constexpr int oX = 0, oE1 = RES_NMAX, oE2 = 2 * RES_NMAX, oRR1 = 3 * RES_NMAX;
     constexpr int oR1 = 4 * RES_NMAX, oAX1 = 5 * RES_NMAX, oR2 = 6 * RES_NMAX, oRR2 = 7 * RES_NMAX;
     constexpr int oAX2 = 8 * RES_NMAX;
-    constexpr int oR3 = 9 * RES_NMAX, oE3 = oR3 + RES_TAIL_MAX, oP3 = oE3 + RES_TAIL_MAX;
+    constexpr int oRHO = 9 * RES_NMAX;                 // mask-form transfers: rho of the F rows (nf <= RES_NMAX / 2)
+    constexpr int oBETA = oAX2 + RES_NMAX / 2;         // ... beta of the C nodes: upper half of the AX2 slot (!THREE)
+    constexpr int oU = oRR2;                           // ... beta .* e_2: lower half of the RR2 slot (free after the visit)
+    constexpr int oR3 = 9 * RES_NMAX + RES_NMAX / 2, oE3 = oR3 + RES_TAIL_MAX, oP3 = oE3 + RES_TAIL_MAX;
     constexpr int oRED = oP3 + RES_TAIL_MAX;          // 2*RES_WAVES doubles
     constexpr int oPUB = oRED + 2 * RES_WAVES;        // values the waves publish this step (2 blocks)
     constexpr int oOWN = oPUB + 2 * RES_WAVES;        // 10 scalars of each wave's rows
@@ -464,6 +510,28 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         if (lfirst2)
             for (int j = tid; j < N2; j += BT) sm[oDV2 + j] = D.L2.dinv[j];
     }
+    // mask-form transfers: this wave's F-row bits over the C nodes (low half) and its C-row bits over the
+    // F rows (high half); bit q of a half <-> entry lane + 64 q, the layout of the register slices
+    const bool xm = !THREE && D.xm != 0 && nc == N2 && D.wident != 0;
+    unsigned xbits = 0;
+    if (xm) {
+        // (all 32 words requested in one burst: a loop of dependent loads cost ~1 us per word)
+        unsigned long long wf[16], wc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            wf[q] = D.xm_fbits[(size_t)rF * D.xm_nwf + (q < D.xm_nwf ? q : 0)];
+            wc[q] = D.xm_cbits[(size_t)(rC - nf) * D.xm_nwc + (q < D.xm_nwc ? q : 0)];
+        }
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            lo |= (vF && q < D.xm_nwf) ? (unsigned)((wf[q] >> lane) & 1ull) << q : 0u;
+            hi |= (vC && q < D.xm_nwc) ? (unsigned)((wc[q] >> lane) & 1ull) << q : 0u;
+        }
+        xbits = lo | (hi << 16);
+        for (int j = tid; j < nf; j += BT) sm[oRHO + j] = D.xm_rho[j];
+        for (int j = tid; j < nc; j += BT) sm[oBETA + j] = D.xm_beta[j];
+    }
     double h33 = 0.0;
     if (tail1) {
         for (int j = tid; j < N2; j += BT) {
@@ -553,6 +621,18 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         if (*fail) dead = true;                                                                 \
     } while (0)
 
+    // sum of the LDS vector at `off` over the set bits of `bits` (entry lane + 64 q <-> bit q), n entries
+    auto masked_sum = [&](unsigned bits, int off, int n) __attribute__((always_inline)) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            const int j0 = lane + 64 * q, j1 = lane + 64 * (q + 1);
+            const double x0 = sm[off + (j0 < n ? j0 : 0)], x1 = sm[off + (j1 < n ? j1 : 0)];
+            s0 += ((bits >> q) & 1u) ? x0 : 0.0;
+            s1 += ((bits >> (q + 1)) & 1u) ? x1 : 0.0;
+        }
+        return wave_sum(s0 + s1);
+    };
     double c1 = 0.0, c2s = 0.0;     // kernel-space scalars of the next sweep on level 1 / 2
     double res = 0.0, res0 = 0.0, prev = 0.0;
     double dum0 = 0.0, dum1 = 0.0;
@@ -911,13 +991,19 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
                 sm[oPUB + w] = sm[oR1 + rF] - sF;
                 sm[oPUB + RES_WAVES + w] = sm[oR1 + rC] - sC;
             }
-            RES_HANDOFF(4, N1, loF, hiF - loF, loC, hiC - loC, { sm[oRR1 + j] = v; }, {}, 0, dum0, dum1);
+            if (xm) {   // the F part arrives pre-scaled by rho for the mask-form restriction below
+                RES_HANDOFF(4, N1, loF, hiF - loF, loC, hiC - loC,
+                            { sm[oRR1 + j] = j < nf ? v * sm[oRHO + j] : v; }, {}, 0, dum0, dum1);
+            } else {
+                RES_HANDOFF(4, N1, loF, hiF - loF, loC, hiC - loC, { sm[oRR1 + j] = v; }, {}, 0, dum0, dum1);
+            }
         }
         {   // r_2 = P' rr ; E2 := 0 ; c for the zero start
             if (dbg) dbg_acc[6] -= __builtin_amdgcn_s_memtime();
             // row r2 of P' is [W(:,r2)' , 1 at nf + r2]; rowC == nf + row2 (level 2 = the C nodes)
-            const double s = res_csr_rowdot(D.Pt2, rowp[12 * w + 0], rowp[12 * w + 1], lane, sm, oRR1) +
-                             (D.wident ? sm[oRR1 + rC] : 0.0);
+            const double s = xm ? sm[oBETA + r2] * masked_sum(xbits >> 16, oRR1, nf) + sm[oRR1 + rC]
+                                : res_csr_rowdot(D.Pt2, rowp[12 * w + 0], rowp[12 * w + 1], lane, sm, oRR1) +
+                                      (D.wident ? sm[oRR1 + rC] : 0.0);
             if (dbg) dbg_acc[6] += __builtin_amdgcn_s_memtime();
             if (lane == 0) sm[oPUB + w] = s;
             double sumr = 0.0;
@@ -946,7 +1032,12 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         {   // e_1 += P e_2                                                        MG_Vcycle.m:31
             if (dbg) dbg_acc[6] -= __builtin_amdgcn_s_memtime();
             // F rows: W(rowF,:) against E2 (A's columns nf + i are level-2 indices i); C rows: identity
-            const double sF = res_csr_rowdot(D.P2, rowp[12 * w + 2], rowp[12 * w + 3], lane, sm, oE2);
+            if (xm) {   // beta .* e_2 once per workgroup, then one masked sum per F row
+                for (int j = tid; j < N2; j += BT) sm[oU + j] = sm[oBETA + j] * sm[oE2 + j];
+                __syncthreads();
+            }
+            const double sF = xm ? sm[oRHO + rF] * masked_sum(xbits & 0xffffu, oU, N2)
+                                 : res_csr_rowdot(D.P2, rowp[12 * w + 2], rowp[12 * w + 3], lane, sm, oE2);
             const double sC = D.wident ? sm[oE2 + r2]
                                        : res_csr_rowdot(D.P2, rowp[12 * w + 4], rowp[12 * w + 5], lane, sm, oE2);
             if (dbg) dbg_acc[6] += __builtin_amdgcn_s_memtime();

@@ -378,6 +378,12 @@ int ipd_apd_bench_eval(ipd_apd* h, int32_t reps, double* total_ms, double* bytes
  * ipd_hybrid_amg(_dev) and ipd_amg4pot attach it themselves.                               */
 int ipd_amg_attach_mask_operator(ipd_amg* h, const double* p_dev, const double* q_dev,
                                  int64_t m, int64_t n, double tk, int32_t* attached);
+/* The same check, for the level-resident solve kernel only: its level 1 <-> 2 transfers
+ * W(j,i) = s_ij*beta_i*rho_j (AMG/transfer.m:19-25 applied to that operator) then read the bit mask
+ * too, whatever the size; the sweeps of the launch path keep their CSR rows.  *attached = 0 when the
+ * hierarchy does not run in that kernel or P does not have the form.  The solvers do this themselves. */
+int ipd_amg_attach_mask_transfers(ipd_amg* h, const double* p_dev, const double* q_dev,
+                                  int64_t m, int64_t n, double tk, int32_t* attached);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------- */
 /* Runs `cycles` iterations of the Class_AMG loop body (residual, one V/W
