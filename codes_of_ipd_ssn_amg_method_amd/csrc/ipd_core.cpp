@@ -159,8 +159,24 @@ void ipd_ctx::fetch_bytes(const void* dsrc, void* hdst, size_t bytes) {
 
 void ipd_ctx::upload_bytes(void* ddst, const void* hsrc, size_t bytes) {
     if (bytes == 0) return;
-    // The source is usually a transient pageable host buffer: complete the copy
-    // before returning so the caller may free or reuse it.
+    // The source is usually a transient pageable host buffer, which the caller may free or reuse on
+    // return.  Small uploads (descriptor tables, random numbers: ~20 per hierarchy) therefore go
+    // through a ring of pinned staging memory: the bytes are copied into the ring on the host and
+    // the copy to the device is queued WITHOUT waiting for it (a copy from pageable memory followed by
+    // a stream synchronisation cost ~20 us each, 0.3-0.4 ms per hierarchy).  A slot is reused only
+    // after the ring has wrapped, and wrapping waits for the stream once.
+    if (up_ring && bytes <= up_ring_bytes / 8) {
+        const size_t need = (bytes + 255) & ~size_t(255);
+        if (up_ring_off + need > up_ring_bytes) {
+            IPD_HIP(hipStreamSynchronize(stream));
+            up_ring_off = 0;
+        }
+        char* slot = up_ring + up_ring_off;
+        up_ring_off += need;
+        std::memcpy(slot, hsrc, bytes);
+        IPD_HIP(hipMemcpyAsync(ddst, slot, bytes, hipMemcpyHostToDevice, stream));
+        return;
+    }
     IPD_HIP(hipMemcpyAsync(ddst, hsrc, bytes, hipMemcpyHostToDevice, stream));
     IPD_HIP(hipStreamSynchronize(stream));
 }
@@ -242,6 +258,12 @@ extern "C" int ipd_ctx_create(int device, ipd_ctx** out) {
         c->scratch.reset(new Arena(&c->pool));
         c->pinned_bytes = size_t(1) << 20;
         IPD_HIP(hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault));
+        if (!(getenv("IPD_NO_UPLOAD_RING") && getenv("IPD_NO_UPLOAD_RING")[0] == '1')) {
+            void* ring = nullptr;
+            c->up_ring_bytes = size_t(4) << 20;
+            IPD_HIP(hipHostMalloc(&ring, c->up_ring_bytes, hipHostMallocDefault));
+            c->up_ring = static_cast<char*>(ring);
+        }
         void* box = nullptr;
         IPD_HIP(hipHostMalloc(&box, 64 * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(box, 0, 64 * sizeof(unsigned));
@@ -273,6 +295,7 @@ extern "C" void ipd_ctx_destroy(ipd_ctx* ctx) {
     ctx->scratch.reset();
     ctx->pool.release_all();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
     if (ctx->mailbox) (void)hipHostFree(const_cast<unsigned*>(ctx->mailbox));
     for (hipEvent_t& ev : ctx->tev)
         if (ev) (void)hipEventDestroy(ev);

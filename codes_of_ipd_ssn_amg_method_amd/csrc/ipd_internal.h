@@ -138,6 +138,8 @@ struct ipd_ctx {
     std::unique_ptr<Arena> scratch;  // per-call temporaries (reset by CallScope)
     void* pinned = nullptr;          // host staging for small readbacks
     size_t pinned_bytes = 0;
+    char* up_ring = nullptr;         // pinned staging ring of upload_bytes (ipd_core.cpp)
+    size_t up_ring_bytes = 0, up_ring_off = 0;
     // mailbox for scalar readbacks: host-coherent memory a one-wave kernel writes the words and
     // then a ticket into, while the host spins on the ticket (no copy engine, no stream wait)
     volatile unsigned* mailbox = nullptr;   // [0] ticket, [16..48) payload words

@@ -238,6 +238,303 @@ __global__ void k_mis_iso(int n, const int* __restrict__ rowcnt, uint8_t* __rest
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// mis_set of a SMALL level in one launch                   (AMG/mis_set.m:25-67)
+// ---------------------------------------------------------------------------
+// Levels >= 2 of the drivers' Newton systems have a few hundred rows and a few thousand entries.
+// There the launch-per-step form above is ~20 launches and 4 host round trips per level (strength,
+// degree flags + scan, random numbers, every round of the selection, the clean-up, the C index
+// scan): 100-150 us of launch and round-trip latency around ~10 us of work.  For levels of at most
+// 1024 rows and MIS_SMALL_NNZ entries ONE workgroup does all of it, thread i = node i: the rows'
+// strong neighbours are listed once in LDS (16-bit indices), the rounds run on those lists with the
+// degrees and flags in LDS, and the loop test of mis_set.m:42 is taken on the device.  The random
+// numbers of mis_set.m:35 are handed in as the NEXT N numbers of the stream; the kernel uses the
+// first `nconn` of them (as the reference does) and reports nconn, and the host then consumes exactly
+// that many (ipd_rng state saved and restored around the peek).  Same statements, same order of
+// evaluation per entry as k_rowmax / k_strong / k_deg_init / k_mis_sel_kill / k_mis_settle /
+// k_mis_absorb / k_mis_iso / k_u8_to_flag / k_count_bad_split + the scans: identical bits.
+static constexpr int MIS_SMALL_ROWS = 1024;
+static constexpr int MIS_SMALL_NNZ = 40000;
+struct MisSmallArgs {
+    int N, N0;
+    const int* rp;
+    const int* ci;
+    const double* va;
+    double theta;
+    const double* randv;      // N values: the stream's next numbers
+    uint8_t* strong;          // out: nnz flags
+    double* maxrow;           // out (interpolation needs them again, transfer.m:49-51)
+    double* diag;
+    uint8_t* isC;             // out
+    uint8_t* isF;             // out
+    int* cidx;                // out: N + 1 entries, cidx[N] = Nc
+    volatile unsigned* box;   // mailbox: {status, nconn, Nc, bad, rounds}; status 1 = degenerate branch (:30-34)
+    unsigned ticket;
+};
+__device__ __forceinline__ int mis_block_exscan(int v, int* wsum, int* total) {   // 1024 threads
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int sgm = wsum[k];
+        if (k < w) woff += sgm;
+        tot += sgm;
+    }
+    *total = tot;
+    return woff + x - v;
+}
+__global__ __launch_bounds__(1024) void k_mis_small(const MisSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char mis_raw[];
+    __shared__ int wsum[16];
+    __shared__ int s_cnt[2];
+    const int N = a.N, i = threadIdx.x;
+    const bool valid = i < N;
+    double* maxrow = reinterpret_cast<double*>(mis_raw);            // N
+    double* deg = maxrow + MIS_SMALL_ROWS;                          // N
+    int* degi = reinterpret_cast<int*>(deg + MIS_SMALL_ROWS);       // N
+    int* srp = degi + MIS_SMALL_ROWS;                               // N + 1
+    uint8_t* fC = reinterpret_cast<uint8_t*>(srp + MIS_SMALL_ROWS + 8);
+    uint8_t* fF = fC + MIS_SMALL_ROWS;
+    uint8_t* fU = fF + MIS_SMALL_ROWS;
+    uint8_t* fS = fU + MIS_SMALL_ROWS;
+    uint8_t* fS2 = fS + MIS_SMALL_ROWS;
+    unsigned short* sci = reinterpret_cast<unsigned short*>(fS2 + MIS_SMALL_ROWS);   // strong neighbours
+    const int r0 = valid ? a.rp[i] : 0, r1 = valid ? a.rp[i + 1] : 0;
+    // ---- strength.m:7-10 (k_rowmax)
+    {
+        double mx = 0.0, dg = 0.0;
+        for (int t = r0; t < r1; ++t) {
+            const int j = a.ci[t];
+            const double v = a.va[t];
+            if (j == i)
+                dg = v;
+            else
+                mx = fmax(mx, -v);
+        }
+        if (valid) {
+            const double m = mx > 0.0 ? mx : INFINITY;
+            maxrow[i] = m;
+            a.maxrow[i] = m;
+            a.diag[i] = dg;
+            degi[i] = 0;
+        }
+    }
+    __syncthreads();
+    // ---- mis_set.m:25-29 (k_strong): the mask, its column counts (deg) and row counts
+    int rowcnt = 0;
+    {
+        const double mr = valid ? maxrow[i] : 1.0;
+        for (int t = r0; t < r1; ++t) {
+            const int j = a.ci[t];
+            bool f = false;
+            if (j != i) {
+                const double sv = (-a.va[t]) / fmin(mr, maxrow[j]);
+                f = sv >= a.theta;
+            }
+            a.strong[t] = f ? 1 : 0;
+            if (f) {
+                atomicAdd(&degi[j], 1);
+                ++rowcnt;
+            }
+        }
+    }
+    int total = 0;
+    const int sbeg = mis_block_exscan(rowcnt, wsum, &total);   // (synchronises: degi is final afterwards)
+    if (valid) {
+        srp[i] = sbeg;
+        int o = sbeg;
+        for (int t = r0; t < r1; ++t)
+            if (a.strong[t]) sci[o++] = (unsigned short)a.ci[t];
+    }
+    if (i == 0) srp[N] = total;
+    const int d = valid ? degi[i] : 0;
+    int nconn = 0;
+    const int rank = mis_block_exscan(d > 0 ? 1 : 0, wsum, &nconn);
+    if ((double)nconn < 0.25 * sqrt((double)N)) {              // :30-34: the host takes this (rare) branch
+        if (i == 0) {
+            a.box[16] = 1u;
+            a.box[17] = (unsigned)nconn;
+            __threadfence_system();
+            a.box[0] = a.ticket;
+        }
+        return;
+    }
+    // ---- :35-40 (k_deg_init)
+    if (valid) {
+        double dv = 0.0;
+        if (d > 0) {
+            const double tie = 0.1 * a.randv[rank];
+            dv = (double)d + tie;
+        }
+        deg[i] = dv;
+        fC[i] = 0;
+        fF[i] = d == 0 ? 1 : 0;
+        fU[i] = 1;
+        fS[i] = d > 0 ? 1 : 0;
+    }
+    __syncthreads();
+    // ---- :42-65: the rounds
+    const int s0 = valid ? srp[i] : 0, s1 = valid ? srp[i + 1] : 0;
+    int sumC = 0, sumU = N, rounds = 0;
+    uint8_t* cur = fS;
+    uint8_t* nxt = fS2;
+    while ((double)sumC < (double)N / 2.0 && sumU > a.N0 && rounds <= N + 8) {
+        ++rounds;
+        if (valid) {                                           // k_mis_sel_kill (:49-52)
+            const double di = deg[i];
+            if (di > 0.0)
+                for (int t = s0; t < s1; ++t) {
+                    const int j = sci[t];
+                    if (j > i) {
+                        const double dj = deg[j];
+                        if (dj > 0.0) {
+                            if (di >= dj)
+                                cur[j] = 0;
+                            else
+                                cur[i] = 0;
+                        }
+                    }
+                }
+        }
+        if (i < 2) s_cnt[i] = 0;
+        __syncthreads();
+        int c1 = 0, u1 = 0;
+        if (valid) {                                           // k_mis_settle (:53-59)
+            bool hit = false;
+            for (int t = s0; t < s1; ++t) {
+                const int j = sci[t];
+                if (fC[j] || cur[j]) hit = true;
+            }
+            const bool c = fC[i] || cur[i];
+            const bool f = fF[i] || hit;
+            const bool u = !(c || f);
+            c1 = c ? 1 : 0;
+            u1 = u ? 1 : 0;
+            nxt[i] = u ? 1 : 0;
+            fU[i] = u ? 1 : 0;
+            if (f) fF[i] = 1;
+            if (!u) deg[i] = 0.0;
+        }
+        // (fC is read by the neighbours in this phase: committed after the barrier below)
+        const unsigned long long bc = __ballot(c1 != 0), bu = __ballot(u1 != 0);
+        if ((threadIdx.x & 63) == 0) {
+            if (bc) atomicAdd(&s_cnt[0], __popcll(bc));
+            if (bu) atomicAdd(&s_cnt[1], __popcll(bu));
+        }
+        __syncthreads();
+        if (valid && c1) fC[i] = 1;
+        sumC = s_cnt[0];
+        sumU = s_cnt[1];
+        uint8_t* tsw = cur;
+        cur = nxt;
+        nxt = tsw;
+        __syncthreads();
+        if (sumU <= a.N0) {                                    // :61-64 (k_mis_absorb)
+            if (valid && fU[i]) {
+                fC[i] = 1;
+                fU[i] = 0;
+            }
+            sumU = 0;
+            __syncthreads();
+        }
+    }
+    // ---- :67 (k_mis_iso), then the C index scan and the consistency count of transfer.m:46-47
+    int isc = 0, isf = 0;
+    if (valid) {
+        isc = fC[i];
+        isf = fF[i];
+        if (rowcnt == 0) {
+            isc = 1;
+            isf = 0;
+        }
+        a.isC[i] = (uint8_t)isc;
+        a.isF[i] = (uint8_t)isf;
+    }
+    int Nc = 0, bad = 0;
+    const int cpos = mis_block_exscan(isc, wsum, &Nc);
+    mis_block_exscan((valid && (isc != 0) == (isf != 0)) ? 1 : 0, wsum, &bad);
+    if (valid) a.cidx[i] = cpos;
+    if (i == 0) {
+        a.cidx[N] = Nc;
+        a.box[16] = 0u;
+        a.box[17] = (unsigned)nconn;
+        a.box[18] = (unsigned)Nc;
+        a.box[19] = (unsigned)bad;
+        a.box[20] = (unsigned)rounds;
+        __threadfence_system();
+        a.box[0] = a.ticket;
+    }
+}
+
+// -> true: done (Nc, bad filled, cidx / maxrow / diag written); false: not taken (size, mailbox off) or
+// the degenerate branch of :30-34 came up, and the caller runs the launch-per-step form
+static bool mis_set_small(ipd_ctx* ctx, const Csr& A, double theta, ipd_rng* rng, uint8_t* isC, uint8_t* isF,
+                          uint8_t* strong, double* maxrow, double* diag, int* cidx, int* Nc, int* bad) {
+    const int N = A.nr;
+    if (N > MIS_SMALL_ROWS || A.nnz > MIS_SMALL_NNZ || N < 1) return false;
+    if (const char* e = getenv("IPD_NO_MIS_SMALL"); e && e[0] == '1') return false;
+    unsigned ticket = 0;
+    if (!ctx->mailbox_begin(&ticket)) return false;
+    Arena& tmp = *ctx->scratch;
+    // peek at the stream's next N numbers (state restored below; a replay stream may hold fewer)
+    std::vector<double> rv((size_t)N, 0.0);
+    {
+        const bool rp = rng->replay;
+        const int64_t have = rp ? std::max<int64_t>(0, (int64_t)rng->values.size() - rng->consumed) : N;
+        const int64_t take = std::min<int64_t>(N, have);
+        uint32_t mt[624];
+        std::memcpy(mt, rng->mt, sizeof(mt));
+        const int mti = rng->mti;
+        const int64_t consumed = rng->consumed;
+        if (take > 0) rng->fill(rv.data(), take);
+        std::memcpy(rng->mt, mt, sizeof(mt));
+        rng->mti = mti;
+        rng->consumed = consumed;
+    }
+    double* drand = tmp.alloc<double>((size_t)N);
+    ctx->upload(drand, rv.data(), (size_t)N);
+    MisSmallArgs a;
+    a.N = N;
+    a.N0 = std::min((int)std::floor(std::sqrt((double)N)) + 1, 25);   // :12
+    a.rp = A.rp;
+    a.ci = A.ci;
+    a.va = A.va;
+    a.theta = theta;
+    a.randv = drand;
+    a.strong = strong;
+    a.maxrow = maxrow;
+    a.diag = diag;
+    a.isC = isC;
+    a.isF = isF;
+    a.cidx = cidx;
+    a.box = ctx->mailbox;
+    a.ticket = ticket;
+    const size_t lds = 16 * (size_t)MIS_SMALL_ROWS + 4 * (size_t)MIS_SMALL_ROWS * 2 + 32 + 5 * (size_t)MIS_SMALL_ROWS +
+                       2 * (size_t)std::max(A.nnz, 1) + 64;
+    IPD_OPTIN_LDS(ctx, k_mis_small, 156 * 1024);
+    hipLaunchKernelGGL(k_mis_small, dim3(1), dim3(1024), lds, ctx->stream, a);
+    IPD_KERNEL_CHECK();
+    unsigned w[5] = {0, 0, 0, 0, 0};
+    ctx->mailbox_wait(ticket, w, sizeof(w));
+    if (w[0] != 0) return false;                     // degenerate branch: nothing consumed yet
+    IPD_REQUIRE((int)w[4] <= N + 8, IPD_E_NUMERIC, "mis_set: no progress");
+    std::vector<double> used((size_t)w[1]);
+    rng->fill(used.data(), (int64_t)w[1]);           // mis_set.m:35 consumes sum(deg > 0) numbers
+    *Nc = (int)w[2];
+    *bad = (int)w[3];
+    return true;
+}
+
 void amg_mis_set(ipd_ctx* ctx, const Csr& A, double theta, ipd_rng* rng, uint8_t* isC,
                  uint8_t* isF, uint8_t* strong_out) {
     IPD_REQUIRE(rng, IPD_E_ARG, "mis_set needs a rand stream");
@@ -702,6 +999,245 @@ __global__ void k_ideal_rows(int N, int Nc, const uint8_t* __restrict__ isF, con
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// interpolation rows -> P, P', P'A, P'AP of a SMALL level in one launch   (transfer.m:46-66)
+// ---------------------------------------------------------------------------
+// What follows k_build_W on a small level (mis_set_small's sizes) used to be 16 launches and 3 host
+// round trips: scan + compaction of the dense interpolation rows, row normalisation, the bitmap
+// transpose (4 launches), and two ordered products of three launches each.  One workgroup does it
+// here, a wave per row, with the same statements per entry as k_dense_compact2 / k_row_normalize /
+// k_tr_mark / k_tr_prefix / k_tr_scatter / k_spgemm_rows / k_dense_compact -- every C(i,j) still
+// receives its terms one at a time in ascending inner index, multiply and add rounded separately --
+// so the bits do not change.  Outputs are sized for the worst case (P, P': N*Nc entries, P'A: Nc*N,
+// P'AP: Nc*Nc); the three entry counts go to the host mailbox in one ticket.
+struct GalSmallArgs {
+    int N, Nc, isnsp, wpc;
+    const int* Arp;
+    const int* Aci;
+    const double* Ava;
+    const double* dense;     // N x Nc interpolation rows (k_build_W)
+    const int* rowcnt;       // their entry counts
+    const uint8_t* isF;
+    int *Prp, *Pci;
+    double* Pva;
+    int *Qrp, *Qci;          // Q = P'
+    double* Qva;
+    int *Trp, *Tci;          // T1 = P'A
+    double* Tva;
+    int *Crp, *Cci;          // C = P'AP
+    double* Cva;
+    unsigned* bits;          // Nc * wpc words (transpose bitmap), scratch
+    int* pref;               // Nc * wpc
+    int* tci;                // Nc * max(N, Nc): a row's compacted entries before its offset is known
+    double* tva;
+    int* tcnt;               // Nc
+    volatile unsigned* box;
+    unsigned ticket;
+};
+__device__ __forceinline__ void gal_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// ordered product rows: out(i,:) = sum_e x(i,k_e) * y(k_e,:), one wave per row, LDS accumulator of `nc`
+// doubles per wave; the compacted row goes to tci/tva at stride `ld`, its length to tcnt
+__device__ __forceinline__ void gal_product_rows(int nr, int nc, int ld, const int* xrp, const int* xci,
+                                                 const double* xva, const int* yrp, const int* yci,
+                                                 const double* yva, double* acc, int* tci, double* tva,
+                                                 int* tcnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int i = wave; i < nr; i += nwaves) {
+        for (int j = lane; j < nc; j += 64) acc[j] = 0.0;
+        gal_wave_sync();
+        const int xb = xrp[i], xe = xrp[i + 1];
+        // The inner index is walked in ascending order, but the memory round trips are taken 64 / 8
+        // terms at a time: lane u fetches term e0 + u (column, value, the y row's range) in one burst,
+        // then the y entries of eight terms are requested together before they are added one term after
+        // the other (a dependent chain of three L2 round trips PER TERM made this kernel 0.4 ms).
+        for (int e0 = xb; e0 < xe; e0 += 64) {
+            const int eu = e0 + lane;
+            const bool have = eu < xe;
+            const int kk = have ? xci[eu] : 0;
+            const double aa = have ? xva[eu] : 0.0;
+            const int ybb = have ? yrp[kk] : 0, yee = have ? yrp[kk + 1] : 0;
+            const int cnt = min(64, xe - e0);
+            for (int u0 = 0; u0 < cnt; u0 += 8) {
+                int jj[8], yb[8], ye[8];
+                double vv[8], au[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int src = min(u0 + u, 63);
+                    yb[u] = __shfl(ybb, src);
+                    ye[u] = (u0 + u < cnt) ? __shfl(yee, src) : yb[u];
+                    au[u] = __shfl(aa, src);
+                    const int t = yb[u] + lane;
+                    const bool in = t < ye[u];
+                    jj[u] = in ? yci[t] : -1;
+                    vv[u] = in ? yva[t] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (jj[u] >= 0) {
+                        const double prod = au[u] * vv[u];
+                        acc[jj[u]] = acc[jj[u]] + prod;
+                    }
+                    for (int t = yb[u] + 64 + lane; t < ye[u]; t += 64) {   // y rows of more than 64 entries
+                        const int j = yci[t];
+                        const double prod = au[u] * yva[t];
+                        acc[j] = acc[j] + prod;
+                    }
+                    gal_wave_sync();
+                }
+            }
+        }
+        int base = 0;
+        for (int j0 = 0; j0 < nc; j0 += 64) {
+            const int j = j0 + lane;
+            const double v = j < nc ? acc[j] : 0.0;
+            const bool nzf = v != 0.0;
+            const unsigned long long mask = __ballot(nzf);
+            if (nzf) {
+                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                tci[(size_t)i * ld + pos] = j;
+                tva[(size_t)i * ld + pos] = v;
+            }
+            base += __popcll(mask);
+        }
+        if (lane == 0) tcnt[i] = base;
+        gal_wave_sync();
+    }
+}
+__device__ __forceinline__ void gal_copy_rows(int nr, int ld, const int* rp, const int* tci, const double* tva,
+                                              int* ci, double* va) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int i = wave; i < nr; i += nwaves) {
+        const int b = rp[i], n = rp[i + 1] - b;
+        for (int t = lane; t < n; t += 64) {
+            ci[b + t] = tci[(size_t)i * ld + t];
+            va[b + t] = tva[(size_t)i * ld + t];
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void k_galerkin_small(const GalSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char gal_raw[];
+    __shared__ int wsum[16];
+    const int N = a.N, Nc = a.Nc, wpc = a.wpc, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    // ---- P: row pointers, ordered compaction (k_dense_compact2), normalisation (k_row_normalize)
+    int nnzP = 0;
+    {
+        const int off = mis_block_exscan(tid < N ? a.rowcnt[tid] : 0, wsum, &nnzP);
+        if (tid < N) a.Prp[tid] = off;
+        if (tid == 0) a.Prp[N] = nnzP;
+    }
+    __syncthreads();
+    for (int i = wave; i < N; i += nwaves) {
+        int base = a.Prp[i];
+        const double* drow = a.dense + (size_t)i * Nc;
+        for (int j0 = 0; j0 < Nc; j0 += 64) {
+            const int j = j0 + lane;
+            const double v = j < Nc ? drow[j] : 0.0;
+            const bool nzf = v != 0.0;
+            const unsigned long long mask = __ballot(nzf);
+            if (nzf) {
+                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                a.Pci[pos] = j;
+                a.Pva[pos] = v;
+            }
+            base += __popcll(mask);
+        }
+    }
+    __syncthreads();
+    if (a.isnsp == 1) {
+        for (int i = wave; i < N; i += nwaves) {
+            if (!a.isF[i]) continue;
+            const int b = a.Prp[i], e = a.Prp[i + 1];
+            double accs = 0.0;
+            if (lane == 0)
+                for (int t = b; t < e; ++t) accs = accs + a.Pva[t];  // ascending columns, sequential
+            const double sgm = __shfl(accs, 0);
+            for (int t = b + lane; t < e; t += 64) a.Pva[t] = a.Pva[t] / sgm;
+        }
+        __syncthreads();
+    }
+    // ---- Q = P' by the row bitmaps of the columns (k_tr_mark / k_tr_prefix / k_tr_scatter)
+    for (int wd = tid; wd < Nc * wpc; wd += blockDim.x) a.bits[wd] = 0u;
+    __syncthreads();
+    for (int r = wave; r < N; r += nwaves) {
+        const int b = a.Prp[r], e = a.Prp[r + 1];
+        for (int t = b + lane; t < e; t += 64)
+            atomicOr(&a.bits[(size_t)a.Pci[t] * wpc + (r >> 5)], 1u << (r & 31));
+    }
+    __syncthreads();
+    for (int c = wave; c < Nc; c += nwaves) {
+        int carry = 0;
+        for (int base = 0; base < wpc; base += 64) {
+            const int wd = base + lane;
+            const int v = wd < wpc ? __popc(a.bits[(size_t)c * wpc + wd]) : 0;
+            int x = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            if (wd < wpc) a.pref[(size_t)c * wpc + wd] = carry + x - v;
+            carry += __shfl(x, 63);
+        }
+        if (lane == 0) a.tcnt[c] = carry;
+    }
+    __syncthreads();
+    {
+        int tot = 0;
+        const int off = mis_block_exscan(tid < Nc ? a.tcnt[tid] : 0, wsum, &tot);
+        if (tid < Nc) a.Qrp[tid] = off;
+        if (tid == 0) a.Qrp[Nc] = tot;
+    }
+    __syncthreads();
+    for (int r = wave; r < N; r += nwaves) {
+        const int b = a.Prp[r], e = a.Prp[r + 1];
+        const unsigned below = (1u << (r & 31)) - 1u;
+        for (int t = b + lane; t < e; t += 64) {
+            const int c = a.Pci[t];
+            const size_t wd = (size_t)c * wpc + (r >> 5);
+            const int pos = a.Qrp[c] + a.pref[wd] + __popc(a.bits[wd] & below);
+            a.Qci[pos] = r;
+            a.Qva[pos] = a.Pva[t];
+        }
+    }
+    __syncthreads();
+    // ---- T1 = P'A, then C = T1 P: left to right (transfer.m:66)
+    double* acc = reinterpret_cast<double*>(gal_raw) + (size_t)wave * (size_t)(N > Nc ? N : Nc);
+    const int ld = N > Nc ? N : Nc;
+    gal_product_rows(Nc, N, ld, a.Qrp, a.Qci, a.Qva, a.Arp, a.Aci, a.Ava, acc, a.tci, a.tva, a.tcnt);
+    __syncthreads();
+    int nnzT = 0;
+    {
+        const int off = mis_block_exscan(tid < Nc ? a.tcnt[tid] : 0, wsum, &nnzT);
+        if (tid < Nc) a.Trp[tid] = off;
+        if (tid == 0) a.Trp[Nc] = nnzT;
+    }
+    __syncthreads();
+    gal_copy_rows(Nc, ld, a.Trp, a.tci, a.tva, a.Tci, a.Tva);
+    __syncthreads();
+    gal_product_rows(Nc, Nc, ld, a.Trp, a.Tci, a.Tva, a.Prp, a.Pci, a.Pva, acc, a.tci, a.tva, a.tcnt);
+    __syncthreads();
+    int nnzC = 0;
+    {
+        const int off = mis_block_exscan(tid < Nc ? a.tcnt[tid] : 0, wsum, &nnzC);
+        if (tid < Nc) a.Crp[tid] = off;
+        if (tid == 0) a.Crp[Nc] = nnzC;
+    }
+    __syncthreads();
+    gal_copy_rows(Nc, ld, a.Crp, a.tci, a.tva, a.Cci, a.Cva);
+    if (tid == 0) {
+        a.box[16] = (unsigned)nnzP;
+        a.box[17] = (unsigned)nnzT;
+        a.box[18] = (unsigned)nnzC;
+        __threadfence_system();
+        a.box[0] = a.ticket;
+    }
+}
+
 void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int level,
                   ipd_rng* rng, Csr* Ac, Csr* Pout, Csr* Ptout, uint8_t* cmask, Csr* T1out) {
     IPD_REQUIRE(A.nr == A.nc, IPD_E_ARG, "transfer: A must be square");
@@ -734,18 +1270,24 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         uint8_t* isC = cmask;
         uint8_t* isF = tmp.alloc<uint8_t>((size_t)N);
         uint8_t* strong = tmp.alloc<uint8_t>((size_t)std::max(A.nnz, 1));
-        amg_mis_set(ctx, A, o.theta, rng, isC, isF, strong);                 // :41
-        int* flag = tmp.alloc<int>((size_t)N + 1);
         int* cidx = tmp.alloc<int>((size_t)N + 2);  // cidx[N] = Nc, cidx[N+1] = #bad
-        IPD_HIP(hipMemsetAsync(cidx + N + 1, 0, sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(k_u8_to_flag, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N, isC,
-                           flag);
-        hipLaunchKernelGGL(k_count_bad_split, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N, isC,
-                           isF, cidx + N + 1);
-        IPD_KERNEL_CHECK();
-        exclusive_scan_i32(ctx, flag, cidx, N);
-        int meta[2];
-        ctx->fetch(cidx + N, meta, 2);
+        double* maxrow = tmp.alloc<double>((size_t)N);
+        double* diag = tmp.alloc<double>((size_t)N);
+        int meta[2] = {0, 0};
+        const bool small_done = mis_set_small(ctx, A, o.theta, rng, isC, isF, strong, maxrow, diag, cidx,
+                                              &meta[0], &meta[1]);
+        if (!small_done) {
+            amg_mis_set(ctx, A, o.theta, rng, isC, isF, strong);             // :41
+            int* flag = tmp.alloc<int>((size_t)N + 1);
+            IPD_HIP(hipMemsetAsync(cidx + N + 1, 0, sizeof(int), ctx->stream));
+            hipLaunchKernelGGL(k_u8_to_flag, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N, isC,
+                               flag);
+            hipLaunchKernelGGL(k_count_bad_split, dim3(elems_grid(N)), dim3(256), 0, ctx->stream, N, isC,
+                               isF, cidx + N + 1);
+            IPD_KERNEL_CHECK();
+            exclusive_scan_i32(ctx, flag, cidx, N);
+            ctx->fetch(cidx + N, meta, 2);
+        }
         const int Nc = meta[0];
         IPD_REQUIRE(meta[1] == 0, IPD_E_NUMERIC,
                     "mis_set left nodes in neither/both of the C and F sets (SURVEY A-6)");
@@ -753,11 +1295,11 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         IPD_REQUIRE((size_t)Nc * 16 <= 128 * 1024, IPD_E_LIMIT,
                     "transfer: more than 8192 coarse nodes on a non-bigraph level");
         P.nc = Nc;
-        double* maxrow = tmp.alloc<double>((size_t)N);
-        double* diag = tmp.alloc<double>((size_t)N);
-        hipLaunchKernelGGL(k_rowmax, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp, A.ci,
-                           A.va, maxrow, diag);
-        IPD_KERNEL_CHECK();
+        if (!small_done) {
+            hipLaunchKernelGGL(k_rowmax, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp, A.ci,
+                               A.va, maxrow, diag);
+            IPD_KERNEL_CHECK();
+        }
         const size_t dense_elems = (size_t)N * (size_t)Nc;
         IPD_REQUIRE(dense_elems * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
                     "transfer: dense interpolation scratch above 2 GiB");
@@ -829,6 +1371,70 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
                                (size_t)Nc * 16, ctx->stream, N, Nc, A.rp, A.ci, A.va, diag, strong,
                                isC, isF, cidx, dense, rowcnt);
             IPD_KERNEL_CHECK();
+            // small level: everything from here to the coarse operator in ONE launch (k_galerkin_small)
+            const size_t worst = 12 * (2 * (size_t)N * Nc + (size_t)Nc * N + (size_t)Nc * Nc);
+            unsigned ticket = 0;
+            // OPT-IN (IPD_GALERKIN_SMALL=1).  Measured on the m=n=1024 Class 1 run: bit-identical, but the
+            // setups take 0.385 s with it against 0.243 s without -- sixteen waves of one workgroup walk
+            // the rows of the two products one after the other, each term a chain of L2 round trips
+            // (0.50 s before the terms were fetched 64 / 8 at a time), where the launches it replaces run
+            // a hundred workgroups side by side; the launches' latency is the smaller cost.
+            const char* ngs = getenv("IPD_GALERKIN_SMALL");
+            if (small_done && (ngs && ngs[0] == '1') && Nc <= 1024 && worst <= (size_t(24) << 20) &&
+                ctx->mailbox_begin(&ticket)) {
+                GalSmallArgs g;
+                g.N = N;
+                g.Nc = Nc;
+                g.isnsp = o.isnsp;
+                g.wpc = (N + 31) / 32;
+                g.Arp = A.rp;
+                g.Aci = A.ci;
+                g.Ava = A.va;
+                g.dense = dense;
+                g.rowcnt = rowcnt;
+                g.isF = isF;
+                Csr Pt, T1, C;
+                Arena& t1dst = T1out ? dst : tmp;
+                P.rp = g.Prp = dst.alloc<int>((size_t)N + 1);
+                P.ci = g.Pci = dst.alloc<int>((size_t)N * Nc);
+                P.va = g.Pva = dst.alloc<double>((size_t)N * Nc);
+                Pt.rp = g.Qrp = dst.alloc<int>((size_t)Nc + 1);
+                Pt.ci = g.Qci = dst.alloc<int>((size_t)N * Nc);
+                Pt.va = g.Qva = dst.alloc<double>((size_t)N * Nc);
+                T1.rp = g.Trp = t1dst.alloc<int>((size_t)Nc + 1);
+                T1.ci = g.Tci = t1dst.alloc<int>((size_t)Nc * N);
+                T1.va = g.Tva = t1dst.alloc<double>((size_t)Nc * N);
+                C.rp = g.Crp = dst.alloc<int>((size_t)Nc + 1);
+                C.ci = g.Cci = dst.alloc<int>((size_t)Nc * Nc);
+                C.va = g.Cva = dst.alloc<double>((size_t)Nc * Nc);
+                g.bits = tmp.alloc<unsigned>((size_t)Nc * g.wpc);
+                g.pref = tmp.alloc<int>((size_t)Nc * g.wpc);
+                const size_t ldt = (size_t)std::max(N, Nc);
+                g.tci = tmp.alloc<int>((size_t)Nc * ldt);
+                g.tva = tmp.alloc<double>((size_t)Nc * ldt);
+                g.tcnt = tmp.alloc<int>((size_t)Nc + 1);
+                g.box = ctx->mailbox;
+                g.ticket = ticket;
+                IPD_OPTIN_LDS(ctx, k_galerkin_small, 156 * 1024);
+                hipLaunchKernelGGL(k_galerkin_small, dim3(1), dim3(1024), 16 * ldt * 8, ctx->stream, g);
+                IPD_KERNEL_CHECK();
+                unsigned w3[3] = {0, 0, 0};
+                ctx->mailbox_wait(ticket, w3, sizeof(w3));
+                P.nnz = (int)w3[0];
+                Pt.nr = Nc;
+                Pt.nc = N;
+                Pt.nnz = P.nnz;
+                T1.nr = Nc;
+                T1.nc = N;
+                T1.nnz = (int)w3[1];
+                C.nr = C.nc = Nc;
+                C.nnz = (int)w3[2];
+                if (T1out) *T1out = T1;
+                *Ac = C;
+                *Pout = P;
+                *Ptout = Pt;
+                return;
+            }
         }
         P.rp = dst.alloc<int>((size_t)N + 1);
         P.nnz = exclusive_scan_total(ctx, rowcnt, P.rp, N);
