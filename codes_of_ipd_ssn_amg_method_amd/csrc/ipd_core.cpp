@@ -296,6 +296,7 @@ extern "C" void ipd_ctx_destroy(ipd_ctx* ctx) {
     ctx->pool.release_all();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
+    if (ctx->asat_agg) (void)hipFree(ctx->asat_agg);
     if (ctx->mailbox) (void)hipHostFree(const_cast<unsigned*>(ctx->mailbox));
     for (hipEvent_t& ev : ctx->tev)
         if (ev) (void)hipEventDestroy(ev);

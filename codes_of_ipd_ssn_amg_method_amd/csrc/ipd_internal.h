@@ -146,6 +146,7 @@ struct ipd_ctx {
     unsigned mailbox_ticket = 0;
     int num_cu = 256;
     long long asat_nnz_hint = 0;   // entries of the last ASAt result (sizes the next one's arrays)
+    void* asat_agg = nullptr;      // k_asat_small's chained-scan words (ipd_kkt.hip)
     // injected visiting order of the connected components (ipd_ctx_set_component_order): the
     // smallest member of the component to visit k-th; empty = by smallest member ascending
     std::vector<int> comp_order;

@@ -486,6 +486,152 @@ void csr_drop_zeros(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out) {
     *out = o;
 }
 
+
+// Everything after the masks in ONE launch, for small active sets (the drivers' Newton systems:
+// E ~ m + n, tree-like): a thread owns a row of H, counts its mask bits, the row pointers come from
+// a scan inside the workgroup, and the thread then writes its row -- diagonal, off-diagonal entries
+// in ascending column order, the diagonal value summed in ascending index order as ASAt.m:19's
+// products do -- and the entry count goes to the host mailbox with the kernel's last store.  The
+// general path above is six dependent launches and a read-back, 56-79 us whatever E is (launch-
+// bound); this one is k_asat_masks + this kernel.  Same values, same order, same bits.
+struct AsatSmallArgs {
+    AsatPlan pl;
+    const double* p;
+    const double* q;
+    int* rp;          // M + 2: rp[M] = nnz, rp[M+1] = zero-square flag
+    int* ci;
+    double* va;
+    int cap;
+    unsigned long long* agg;   // per workgroup: ticket << 32 | entries of its rows
+    volatile unsigned* box;
+    unsigned ticket;
+};
+// G = ceil(M / 256) workgroups of 256 rows; the row pointers come from a chained scan with look-back:
+// a workgroup publishes the entry count of its rows, tagged with the call's ticket (so the words
+// need no clearing between calls), as soon as it has it, reads the tagged counts of ALL its
+// predecessors in one sweep (lane = predecessor, at most 64 of them) and repeats the sweep until every
+// tag is there.  All workgroups are on the chip together (G <= 64 of 256 CUs); the spin is bounded
+// anyway, and a give-up is reported as an impossible count, which sends the host to the general path.
+__global__ __launch_bounds__(256) void k_asat_small(const AsatSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double asat_pq[];   // p (m), then q (n)
+    __shared__ int wsum[4];
+    __shared__ int s_flag, s_prefix, s_zpred;
+    const AsatPlan& pl = a.pl;
+    const int n = pl.n, m = pl.m, M = n + m, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = blockIdx.x, G = gridDim.x;
+    const int t = g * 256 + tid;
+    const bool frow = t < n, live = t < M;
+    const int r = frow ? t : t - n;                               // column j of Y, or row i
+    const int nw = frow ? pl.nib : pl.njb, stride = frow ? n : m;
+    const unsigned long long* __restrict__ mk = frow ? pl.colmask : pl.rowmask;
+    // one burst: the row's mask words, then p and q into LDS (the gathers of the fill)
+    unsigned long long w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = (live && k < nw) ? mk[(size_t)k * stride + r] : 0ull;
+    double* sp = asat_pq;
+    double* sq = asat_pq + m;
+    for (int i = tid; i < m; i += 256) sp[i] = a.p[i];
+    for (int j = tid; j < n; j += 256) sq[j] = a.q[j];
+    if (tid == 0) s_zpred = 0;
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) run += __popcll(w[k]);
+    const int len = run + (run > 0 ? 1 : 0);
+    int x = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int sgm = wsum[k];
+        if (k < wv) woff += sgm;
+        tot += sgm;
+    }
+    // publish this workgroup's count (bit 31: one of its rows has a zero square), then sum the predecessors'
+    unsigned long long* agg = a.agg;
+    {
+        const double own0 = live ? (frow ? a.q[r] : a.p[r]) : 1.0;
+        const int zs = __syncthreads_or(own0 * own0 == 0.0 ? 1 : 0);
+        if (tid == 0) {
+            s_flag = zs;
+            __hip_atomic_store(&agg[g], ((unsigned long long)a.ticket << 32) | (unsigned)tot | (zs ? 0x80000000u : 0u),
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (wv == 0) {
+        int before = 0;
+        bool ok = false;
+        for (int spin = 0; spin < (1 << 20) && !ok; ++spin) {
+            const unsigned long long v = lane < g ? __hip_atomic_load(&agg[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+                                                  : ((unsigned long long)a.ticket << 32);
+            const bool mine = (unsigned)(v >> 32) == a.ticket;
+            ok = __all(mine);
+            if (ok) {
+                int c = lane < g ? (int)((unsigned)v & 0x7fffffffu) : 0;
+                const int zb = __any(lane < g && ((unsigned)v >> 31)) ? 1 : 0;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+                before = c;
+                if (lane == 0) s_zpred = zb;
+            } else {
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (lane == 0) s_prefix = ok ? before : -1;
+    }
+    __syncthreads();
+    const int carry = s_prefix;
+    const bool gaveup = carry < 0;
+    const int beg = (gaveup ? 0 : carry) + woff + x - len;
+    if (live && !gaveup) a.rp[t] = beg;
+    if (live && len > 0 && !gaveup) {
+        // rows [0,n): diagonal first, then (j, n+i) ascending i;  rows [n,n+m): (n+i, j) ascending j,
+        // diagonal last.  The diagonal value is summed in ascending index order (ASAt.m:19).
+        const double own = frow ? sq[r] : sp[r];
+        const double* other = frow ? sp : sq;
+        int pos = frow ? beg + 1 : beg;
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            unsigned long long ww = w[k];
+            while (ww) {
+                const int o = k * 64 + __builtin_ctzll(ww);
+                ww &= ww - 1ull;
+                const double ov = other[o];
+                sum = sum + ov * ov;                               // (p_i*Y_ij)*p_i  /  (Y_ij*q_j)*q_j
+                if (pos < a.cap) {
+                    a.ci[pos] = frow ? n + o : o;
+                    a.va[pos] = own * ov;                          // q_j*(p_i*Y_ij)  /  p_i*(Y_ij*q_j)
+                }
+                ++pos;
+            }
+        }
+        const int dpos = frow ? beg : pos;
+        if (dpos < a.cap) {
+            a.ci[dpos] = t;
+            a.va[dpos] = sum;
+        }
+    }
+    if (g == G - 1) {   // the last workgroup knows the total and every workgroup's zero-square bit
+        __syncthreads();
+        if (tid == 0) {
+            const int total = gaveup ? 0x7fffffff : carry + tot;
+            const int zs = (s_flag || s_zpred) ? 1 : 0;
+            a.rp[M] = total;
+            a.rp[M + 1] = zs;
+            a.box[16] = (unsigned)total;
+            a.box[17] = (unsigned)zs;
+            __threadfence_system();
+            a.box[0] = a.ticket;
+        }
+    }
+}
+
 void kkt_asat(ipd_ctx* ctx, Arena& dst, const uint8_t* s, const double* p, const double* q, int m,
               int n, Csr* H) {
     IPD_REQUIRE(m > 0 && n > 0, IPD_E_ARG, "ASAt: empty p or q");
@@ -509,12 +655,59 @@ void kkt_asat(ipd_ctx* ctx, Arena& dst, const uint8_t* s, const double* p, const
     const int M = m + n;
     int* rp = dst.alloc<int>((size_t)M + 2);  // rp[M] = nnz, rp[M+1] = zero-square flag
     const int ntiles = pl.nib * pl.njb;
-    IPD_HIP(hipMemsetAsync(rp + M + 1, 0, sizeof(int), ctx->stream));
+    // small active sets (the previous call's count says so): masks + ONE more launch
+    unsigned sticket = 0;
+    const bool small = ctx->asat_nnz_hint > 0 && ctx->asat_nnz_hint <= 65536 && pl.nib <= 16 && pl.njb <= 16 &&
+                       cdiv(M, 256) <= 64 &&
+                       !(getenv("IPD_NO_ASAT_SMALL") && getenv("IPD_NO_ASAT_SMALL")[0] == '1') &&
+                       ctx->mailbox_begin(&sticket);
+    if (!small) IPD_HIP(hipMemsetAsync(rp + M + 1, 0, sizeof(int), ctx->stream));
     if (m % 8 == 0 && (reinterpret_cast<uintptr_t>(s) & 7) == 0)
         hipLaunchKernelGGL(k_asat_masks<true>, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, s, pl);
     else
         hipLaunchKernelGGL(k_asat_masks<false>, dim3(cdiv(ntiles, 4)), dim3(256), 0, ctx->stream, s, pl);
     IPD_KERNEL_CHECK();
+    if (small) {
+        const long long cap = std::min<long long>(2LL * m * n + M, ctx->asat_nnz_hint + ctx->asat_nnz_hint / 4 + 64);
+        Csr hs;
+        hs.nr = hs.nc = M;
+        hs.rp = rp;
+        hs.ci = dst.alloc<int>((size_t)cap);
+        hs.va = dst.alloc<double>((size_t)cap);
+        AsatSmallArgs sa;
+        sa.pl = pl;
+        sa.p = p;
+        sa.q = q;
+        sa.rp = rp;
+        sa.ci = hs.ci;
+        sa.va = hs.va;
+        sa.cap = (int)cap;
+        sa.box = ctx->mailbox;
+        sa.ticket = sticket;
+        if (!ctx->asat_agg) {   // 64 tagged words, kept for the context's lifetime
+            IPD_HIP(hipMalloc(&ctx->asat_agg, 64 * sizeof(unsigned long long)));
+            IPD_HIP(hipMemsetAsync(ctx->asat_agg, 0, 64 * sizeof(unsigned long long), ctx->stream));
+        }
+        sa.agg = static_cast<unsigned long long*>(ctx->asat_agg);
+        hipLaunchKernelGGL(k_asat_small, dim3(cdiv(M, 256)), dim3(256), sizeof(double) * (size_t)M, ctx->stream, sa);
+        IPD_KERNEL_CHECK();
+        unsigned w2[2] = {0, 0};
+        ctx->mailbox_wait(sticket, w2, sizeof(w2));
+        hs.nnz = (int)w2[0];
+        if (hs.nnz != 0x7fffffff) ctx->asat_nnz_hint = hs.nnz;
+        if ((long long)hs.nnz <= cap) {
+            const bool zsq = w2[1] != 0;
+            if (zsq && hs.nnz) {
+                Csr clean;
+                csr_drop_zeros(ctx, dst, hs, &clean);
+                hs = clean;
+            }
+            *H = hs;
+            return;
+        }
+        // the active set grew beyond the guess (or a spin gave up): the general path redoes the assembly
+        IPD_HIP(hipMemsetAsync(rp + M + 1, 0, sizeof(int), ctx->stream));
+    }
     hipLaunchKernelGGL(k_asat_offsets, dim3(cdiv(M, 256)), dim3(256), 0, ctx->stream, pl, p, q,
                        rp + M + 1);
     IPD_KERNEL_CHECK();
