@@ -1520,6 +1520,14 @@ __device__ __forceinline__ void poly_post(SolveCtx& c, int k, LdsLevel& L, AS3 c
 // reciprocal of delta_old is formed beside that trip, and M^-1 r multiplies by the stored reciprocal
 // diagonal.  Measured on 7 / 11 rows: 3.2 / 2.9 -> see DESIGN us per solve.  Same recurrences as
 // tiny_pcg; beta and M^-1 r differ from a true division by one rounding.
+// 1 / x to full double precision without the division's scaling and fix-up steps (the operands here are
+// sums of squares of ordinary magnitude): v_rcp_f64 is good to ~26 bits, two Newton steps take it to 53.
+__device__ __forceinline__ double pcg_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return y;
+}
 __device__ __forceinline__ void tiny_pcg16(SolveCtx& c, int k, const LdsLevel& L) {
     const AS3 SolveDesc* D = (const AS3 SolveDesc*)c.D;
     const double tol = D->pcg.tol;
@@ -1546,7 +1554,7 @@ __device__ __forceinline__ void tiny_pcg16(SolveCtx& c, int k, const LdsLevel& L
         const double delta_old = delta_new;
         if (valid) pv[i] = p;
         tiny_sync();
-        const double rcp_old = 1.0 / delta_old;
+        const double rcp_old = pcg_rcp(delta_old);
         double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
 #pragma unroll
         for (int j = 0; j < 16; j += 4) {
@@ -1560,7 +1568,7 @@ __device__ __forceinline__ void tiny_pcg16(SolveCtx& c, int k, const LdsLevel& L
         }
         const double q = (q0 + q1) + (q2 + q3);
         tiny_sync();
-        const double alpha = delta_old / row16_sum(q * p);
+        const double alpha = delta_old * pcg_rcp(row16_sum(q * p));
         d += alpha * p;
         r -= alpha * q;
         const double w = r * idg;

@@ -551,11 +551,18 @@ __global__ __launch_bounds__(EB) void k_eval_fin(const EvalFin a) {
     const double z2s = scal_total128(a.pt, 1, red);
     const double zmp2 = scal_total128(a.pt, 2, red);
     const double cnt = scal_total128(a.pt, 4, red);
+    // the partials arrive in one burst (one thread walking them was a chain of dependent loads); they
+    // are still added in block order
+    __shared__ double fp_lds[4 * EB];
+    const int nfp = (int)gridDim.x * NFS;
+    for (int e = threadIdx.x; e < nfp && e < 4 * EB; e += EB) fp_lds[e] = a.fpart[e];
+    __syncthreads();
     if (threadIdx.x == 0) {
         double tot[NFS];
         for (int k = 0; k < NFS; ++k) tot[k] = 0.0;
         for (unsigned b = 0; b < gridDim.x; ++b)
-            for (int k = 0; k < NFS; ++k) tot[k] += a.fpart[(size_t)b * NFS + k];
+            for (int k = 0; k < NFS; ++k)
+                tot[k] += ((int)(b * NFS + k) < 4 * EB) ? fp_lds[b * NFS + k] : a.fpart[(size_t)b * NFS + k];
         a.out->normF2 = tot[0];
         a.out->lam2 = tot[1];
         a.out->wlk_lam = tot[2];
@@ -642,27 +649,56 @@ struct MeritFin {
 };
 
 __global__ __launch_bounds__(BT) void k_merit_fin(const MeritFin a) {
-    __shared__ double red[16];
+    // All MK trial points in ONE pass over lam, zeta, wlk and ONE exchange: the per-thread sums, the
+    // wave sums and the order in which the waves' sums are added are those of block_sum / scal_total
+    // value by value (same bits); MK sequential passes with four block sums each took 16.5 us.
+    __shared__ double redm[BT / 64][4 * MK];
+    __shared__ double tot[4 * MK];
     const int M = a.P.m + a.P.n;
     const size_t mn = (size_t)a.P.m * a.P.n;
     const int L = M + (a.P.cls2 ? 1 : 0);
-    for (int k = 0; k < MK; ++k) {
-        double l2 = 0.0, wl = 0.0, tp2 = 0.0;
-        for (int t = threadIdx.x; t < L; t += BT) {
-            const double lt = a.lam[t] + a.step[k] * a.zeta[t];
-            l2 += lt * lt;
-            wl += a.wlk[t] * lt;
-            if (a.P.cls2 && t < M) {
-                const double z = a.itk * (a.w[mn + t] - lt);
+    double acc[4 * MK];
+#pragma unroll
+    for (int k = 0; k < 4 * MK; ++k) acc[k] = 0.0;
+    for (int t = threadIdx.x; t < L; t += BT) {
+        const double l0 = a.lam[t], zt = a.zeta[t], wlt = a.wlk[t];
+        const bool tail = a.P.cls2 && t < M;
+        const double wt = tail ? a.w[mn + t] : 0.0;
+#pragma unroll
+        for (int k = 0; k < MK; ++k) {
+            const double lt = l0 + a.step[k] * zt;
+            acc[k] += lt * lt;
+            acc[MK + k] += wlt * lt;
+            if (tail) {
+                const double z = a.itk * (wt - lt);
                 const double pz = z > 0.0 ? z : 0.0;
-                tp2 += pz * pz;
+                acc[2 * MK + k] += pz * pz;
             }
         }
-        l2 = block_sum(l2, red);
-        wl = block_sum(wl, red);
-        tp2 = block_sum(tp2, red);
-        const double prox2 = scal_total(a.pt, k, red) + tp2;
-        if (threadIdx.x == 0) a.out[k] = a.bk1 / 2.0 * l2 - wl + 0.5 * a.tk * prox2;   // :201-204
+    }
+    for (int b = threadIdx.x; b < a.pt.nblk; b += BT) {
+#pragma unroll
+        for (int k = 0; k < MK; ++k) acc[3 * MK + k] += a.pt.spart[(size_t)b * NSC + k];
+    }
+    const int wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4 * MK; ++k) {
+        const double v = wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) redm[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 * MK) {
+        double sgm = 0.0;
+#pragma unroll
+        for (int w = 0; w < BT / 64; ++w) sgm += redm[w][threadIdx.x];
+        tot[threadIdx.x] = sgm;
+    }
+    __syncthreads();
+    if (threadIdx.x < MK) {
+        const int k = threadIdx.x;
+        const double l2 = tot[k], wl = tot[MK + k], tp2 = tot[2 * MK + k];
+        const double prox2 = tot[3 * MK + k] + tp2;
+        a.out[k] = a.bk1 / 2.0 * l2 - wl + 0.5 * a.tk * prox2;   // :201-204
     }
 }
 
