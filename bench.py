@@ -430,6 +430,12 @@ def main():
     # per level-2 visit nu + nu sweeps and a residual, prolongation; the zero-start first sweeps of
     # level 1 and of level 2's first visit need no matrix row and are formed locally (-2)
     handoffs = (4 * nu + 3 + visits2 * (2 * nu + 1) + 1 - (2 if nu >= 1 else 0)) if h.J == 3 else None
+    # mask-form kernel for level 1 beyond 2048 rows (csrc/ipd_resident_big.h): per cycle the exchange of
+    # ||r||, 1'r (partial sums), 2 per level-1 sweep, the rho-scaled residual of the F rows, 1'r_2, per
+    # level-2 visit nu + nu sweeps and the tail's restriction, the prolongated iterate block by block
+    big = resident and (M > 4096 // 2 + 2048 or os.environ.get("IPD_RESIDENT_BIG") == "1") and h.J == 3
+    if big:
+        handoffs = 1 + 4 * nu + 2 + visits2 * (2 * nu + 1) + 2
     result = {
         "metric": "V-cycle throughput (DoF*cycles/sec), m=n=%d OT grid" % m,
         "value": value, "unit": "DoF*cycles/s", "n_gpus": world, "steps": args.steps,
@@ -453,7 +459,8 @@ def main():
         "cycle_GBps_algorithmic": bytes_per_cycle * args.steps / wall / 1e9,
         "device_ms_per_step_events": ev_ms / args.steps,
         "rel_res_after_steps": rel_res_after,
-        "execution": ({"mode": "level-resident kernel (csrc/ipd_resident.h): the timed steps are ONE launch",
+        "execution": ({"mode": ("level-resident kernel, mask form (csrc/ipd_resident_big.h)" if big else
+                                "level-resident kernel (csrc/ipd_resident.h)") + ": the timed steps are ONE launch",
                        "workgroups": grid_.value, "launches_per_cycle": 1.0 / args.steps,
                        "handoffs_per_cycle": handoffs, "resident_kernel_timeouts": tmo_.value}
                       if resident else

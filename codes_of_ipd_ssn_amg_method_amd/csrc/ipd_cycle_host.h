@@ -64,6 +64,12 @@ struct CycleState {
     unsigned char* res_block = nullptr;   // [gran0 | gran1 | tmo]: zeroed before every launch
     int res_timeouts = 0;    // launches whose bounded spins gave up (then: multi-launch path)
     int res_capacity = -1;   // workgroups of the chosen instantiation the device holds at once (-1: not asked yet)
+    // level 1 of up to 4096 rows: the mask-form resident kernel (ipd_resident_big.h), set up by
+    // amg_attach_maskop once the bit mask of level 1 is there
+    bool resb = false;
+    bool res_off = false;    // IPD_NO_RESIDENT=1 when the hierarchy was set up
+    ResBigDesc resb_desc;
+    int resb_ke2 = 16;
     // whole solve of a realistic hierarchy in one workgroup (ipd_mid.h): levels 1-2 thread-per-row
     // with rows in registers and vectors in LDS, levels 3..J out of the LDS image
     bool mid_ok = false;
@@ -176,7 +182,10 @@ static int pick_blocks(int nrows, int L, int cu) {
 // latency-bound.  IPD_NO_RESIDENT=1 switches it off, IPD_RESIDENT_G overrides the grid.
 static void plan_resident(ipd_amg* h, CycleState* st) {
     st->res_ok = false;
-    if (const char* e = std::getenv("IPD_NO_RESIDENT"); e && e[0] == '1') return;
+    if (const char* e = std::getenv("IPD_NO_RESIDENT"); e && e[0] == '1') {
+        st->res_off = true;   // (remembered: the mask-form kernel is set up later, by amg_attach_maskop)
+        return;
+    }
     if (st->small_ok || h->J < 3 || h->opts.twogrid) return;
     const Level& l1 = h->L[1];
     const Level& l2 = h->L[2];
@@ -451,6 +460,30 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
     // checked against what the device can hold of this instantiation (registers, LDS: one workgroup
     // per CU) before the first launch; an oversized grid takes the multi-launch path for good.
     bool fits = true;
+    if (st->resb) {
+        ResBigDesc B = st->resb_desc;
+        B.dbg_skip_seq = D.dbg_skip_seq;
+#define IPD_RESB_LAUNCH(KE2)                                                                        \
+    do {                                                                                            \
+        IPD_OPTIN_LDS(ctx, (k_resident_big<KE2>), 156 * 1024);                                      \
+        if (st->res_capacity < 0) {                                                                 \
+            int nb_ = 0;                                                                            \
+            IPD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, (k_resident_big<KE2>), BT, st->res_lds)); \
+            st->res_capacity = nb_ * st->num_cu;                                                    \
+        }                                                                                           \
+        if (grid > st->res_capacity) {                                                              \
+            fits = false;                                                                           \
+            break;                                                                                  \
+        }                                                                                           \
+        hipLaunchKernelGGL((k_resident_big<KE2>), dim3(grid), dim3(BT), st->res_lds, ctx->stream, B, b_dev, x, \
+                           st->res_out, fixed_cycles);                                              \
+    } while (0)
+        if (st->resb_ke2 == 16)
+            IPD_RESB_LAUNCH(16);
+        else
+            IPD_RESB_LAUNCH(32);
+#undef IPD_RESB_LAUNCH
+    } else
 #define IPD_RES_LAUNCH(KE, KE3)                                                                     \
     do {                                                                                            \
         IPD_OPTIN_LDS(ctx, (k_resident<KE, KE, KE3>), 156 * 1024);                                  \
@@ -1563,7 +1596,8 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
     const bool for_resident = st->res_ok && !st->res_desc.three && st->res_desc.wident && h->J == 3 &&
                               !(std::getenv("IPD_RES_NO_XMASK") && std::getenv("IPD_RES_NO_XMASK")[0] == '1');
     bool sweeps_too = !transfers_only;
-    if (transfers_only && !for_resident) return false;
+    const bool big_forced = std::getenv("IPD_RESIDENT_BIG") && std::getenv("IPD_RESIDENT_BIG")[0] == '1';
+    if (transfers_only && !for_resident && !big_forced) return false;
     if (policy) {
         const char* off = std::getenv("IPD_NO_MASKOP");
         if (off && off[0] == '1') return false;
@@ -1625,7 +1659,106 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
             D.xm_rho = rho;
         }
     }
-    if (!sweeps_too) return st->res_desc.xm != 0;
+    // Level 1 beyond k_resident's 2048 rows (m = n = 2048: BASELINE config 4's size), three levels with a
+    // one-row tail: the mask-form resident kernel (ipd_resident_big.h).  IPD_RESIDENT_BIG=1 prefers it
+    // wherever it applies (tests), IPD_NO_RESIDENT_BIG=1 switches it off.
+    {
+        const char* nrs = std::getenv("IPD_NO_RESIDENT");
+        const char* nbg = std::getenv("IPD_NO_RESIDENT_BIG");
+        const char* fbg = std::getenv("IPD_RESIDENT_BIG");
+        const bool forced = fbg && fbg[0] == '1';
+        const bool cyc = h->opts.cycle == 'w' || h->opts.cycle == 'v';
+        const int G = cdiv(std::max(n, m), RES_WAVES);
+        if (!(nrs && nrs[0] == '1') && !st->res_off && !(nbg && nbg[0] == '1') &&
+            (forced || (!st->res_ok && n + m > RES_NMAX)) && !st->small_ok &&
+            !st->resb && h->J == 3 && h->L[3].A.nr == 1 && n <= RB_HALF && m <= RB_HALF && h->L[2].A.nr == m && cyc &&
+            !h->opts.twogrid && G <= st->num_cu && G <= std::min(n, m) && h->opts.smoth >= 1) {
+            LevelDev d2 = st->run[2].dev;
+            if (d2.S <= 0 && st->run[2].maxoff > 0) {   // private padded copy, stride = the longest row
+                d2.S = (st->run[2].maxoff + 3) / 4 * 4;
+                const Csr& A2 = h->L[2].A;
+                unsigned short* pci = ar.alloc<unsigned short>((size_t)A2.nr * d2.S);
+                double* pva = ar.alloc<double>((size_t)A2.nr * d2.S);
+                double* dg = ar.alloc<double>((size_t)A2.nr);
+                hipLaunchKernelGGL(k_pad_build, dim3(std::max(1, std::min(cdiv(A2.nr, 4), 4096))), dim3(256), 0,
+                                   ctx->stream, A2.nr, d2.S, A2.rp, A2.ci, A2.va, pci, pva, dg);
+                IPD_KERNEL_CHECK();
+                d2.pci = pci;
+                d2.pva = pva;
+                d2.diag = dg;
+            }
+            double* rho = const_cast<double*>(st->res_desc.xm_rho);
+            bool rho_ok = st->res_desc.xm != 0;
+            if (!rho_ok) {
+                rho = ar.alloc<double>((size_t)n);
+                IPD_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+                hipLaunchKernelGGL(k_res_xmask_rho, dim3(cdiv(n, 4)), dim3(256), 0, ctx->stream, n, m, h->opts.isnsp,
+                                   (const unsigned long long*)fb, mo.nwf, (const double*)alpha, (const double*)beta,
+                                   (const double*)diag, h->L[2].P.rp, h->L[2].P.ci, h->L[2].P.va, rho, bad);
+                IPD_KERNEL_CHECK();
+                rho_ok = ctx->fetch1(bad) == 0;
+            }
+            if (rho_ok && d2.S > 0 && d2.S <= 64 * 32) {
+                ResBigDesc B{};
+                B.nf = n;
+                B.nc = m;
+                B.N2 = m;
+                B.S2 = d2.S;
+                B.pci2 = d2.pci;
+                B.pva2 = d2.pva;
+                B.diag2 = d2.diag;
+                B.dinv2 = d2.dinv;
+                B.Axi2 = d2.Axi;
+                B.xx2 = d2.xx;
+                B.diag1 = diag;
+                B.dinv1 = st->run[1].dev.dinv;
+                B.Axi1 = st->run[1].dev.Axi;
+                B.xx1 = st->run[1].dev.xx;
+                B.fbits = fb;
+                B.cbits = cb;
+                B.nwf = mo.nwf;
+                B.nwc = mo.nwc;
+                B.alpha = alpha;
+                B.beta = beta;
+                B.rho = rho;
+                B.P3.rp = h->L[3].P.rp;
+                B.P3.ci = h->L[3].P.ci;
+                B.P3.va = h->L[3].P.va;
+                B.A3.rp = h->L[3].A.rp;
+                B.A3.ci = h->L[3].A.ci;
+                B.A3.va = h->L[3].A.va;
+                B.nu = h->opts.smoth;
+                B.isnsp = h->opts.isnsp;
+                B.wcycle = h->opts.cycle == 'w';
+                B.anycycle = 1;
+                B.maxit = h->opts.maxit;
+                B.retol = h->opts.retol;
+                B.pcg_maxit = h->opts.pcg_maxit;
+                B.pollsleep = 1;
+                B.presleep = 13;
+                if (const char* e = std::getenv("IPD_RES_PRESLEEP")) B.presleep = std::max(0, std::min(64, std::atoi(e)));
+                const size_t gbytes = (size_t)RB_GRAN * 16;
+                st->res_block_bytes = 2 * gbytes + 16;
+                st->res_block = reinterpret_cast<unsigned char*>(ar.alloc_bytes(st->res_block_bytes));
+                B.gran = st->res_block;
+                B.tmo = reinterpret_cast<unsigned*>(st->res_block + 2 * gbytes);
+                B.dbg_skip_seq = 0;
+                st->resb_desc = B;
+                st->resb_ke2 = d2.S <= 64 * 16 ? 16 : 32;
+                st->resb = true;
+                st->res_remote = false;
+                st->res_ke3 = 0;
+                st->res_G = G;
+                st->res_lds = RB_LDS_BYTES;
+                st->res_capacity = -1;
+                st->res_desc.dbg_skip_seq = 0;
+                if (const char* e = std::getenv("IPD_RES_DEBUG_SKIP_PUBLISH")) st->res_desc.dbg_skip_seq = (unsigned)std::max(0, std::atoi(e));
+                if (!st->res_out) st->res_out = ar.alloc<double>(4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2));
+                st->res_ok = true;
+            }
+        }
+    }
+    if (!sweeps_too) return st->res_desc.xm != 0 || st->resb;
     st->maskop = mo;
     st->mask_ok = true;
     // captured graphs (if any) were recorded with the CSR sweeps

@@ -1,0 +1,111 @@
+"""Mask-form level-resident kernel (csrc/ipd_resident_big.h): level 1 of up to 4096 rows as the bit
+mask, level 2 in registers, LDS holding only gather targets -- the kernel behind `bench.py --n1 2048`
+(BASELINE config 4's size on one GPU).  Reference behaviour: AMG/Class_AMG.m:86-109,
+AMG/MG_Vcycle.m:12-45, AMG/MG_Wcycle.m:13-46, PCG.m:68-87.
+
+Forced (IPD_RESIDENT_BIG=1) on sizes the oracle solves in seconds: residual histories against the
+ORACLE to 1e-10 and A(x - x_oracle) <= 1e-9 |f|, and against k_resident / the multi-launch path; then
+m = n = 2048 itself against the multi-launch path (mask sweeps), K loop bodies and a whole solve."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import bench
+from oracle import ipd_oracle as O
+from tests import problems as PR
+from tests.test_gpu_bench_workload import bench_cycles, env, options, same_history, solve_mode
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ipd():
+    import codes_of_ipd_ssn_amg_method_amd as m
+    return m
+
+
+def _system(m, n, rho, pq_random, seed=5):
+    s = PR.mask_bernoulli(m, n, rho, seed=seed)
+    pd = PR.make_prob(m, n, s, pq_random=pq_random)
+    H0 = O.ASAt(s, pd["p"], pd["q"])
+    Ae = sp.csr_matrix(O.build_Ae(H0, pd["T"], pd["p"], pd["q"], pd["bk1"], pd["tk"])[0])
+    f = np.concatenate([pd["q"], -pd["p"]]) * pd["z"]
+    return pd, Ae, f
+
+
+@pytest.mark.parametrize("m,n,rho,pq,isnsp,cycle", [
+    (512, 512, 1.0, False, 1, "v"),
+    (1024, 1024, 1.0, False, 1, "w"),
+    (700, 900, 1.0, True, 1, "v"),
+    (1000, 1000, 0.9, True, 1, "w"),
+    (1024, 1024, 0.5, True, 0, "v"),
+])
+def test_forced_big_kernel_against_oracle_and_resident(ipd, m, n, rho, pq, isnsp, cycle):
+    pd, Ae, f = _system(m, n, rho, pq)
+    if sp.csgraph.connected_components(Ae)[0] != 1:
+        pytest.skip("mask not connected")
+    guess = pd["bk1"] * pd["tk"] * np.random.RandomState(4).random_sample(m + n)
+    opts = options(cycle, n, isnsp=isnsp)
+    hc = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    if hc.J != 3 or hc.level_sizes()[2] != 1:
+        pytest.skip("hierarchy %s: the big kernel takes three levels with a one-row tail" % (hc.level_sizes(),))
+    with env(IPD_RESIDENT_BIG=1):
+        h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+        assert h.attach_mask_operator(pd["p"], pd["q"], pd["tk"])
+    mode, grid, _ = solve_mode(h)
+    assert mode == 2 and grid == -(-max(m, n) // 8), (mode, grid)
+    x, it, rel, relk, rhok = h.solve(f, guess)
+    assert solve_mode(h)[2] == 0, "no hand-off timed out"
+    xc, itc, relc, relkc, rhokc = hc.solve(f, guess)
+    same_history(it, relk, itc, relkc)
+    A = sp.csr_matrix(Ae)
+    assert np.linalg.norm(A @ (x - xc)) <= 1e-9 * np.linalg.norm(f)
+    o = dict(opts)
+    o.update(guess=guess)
+    xo, ito, relo, relko, _ = O.Class_AMG(Ae, f, o, O.matlab_rng())
+    same_history(it, relk, ito, relko)
+    assert np.linalg.norm(A @ (x - xo)) <= 1e-9 * np.linalg.norm(f)
+    # K loop bodies (what bench.py times) against the same hook of the other hierarchy
+    a = bench_cycles(h, f, guess, 3)[0]
+    b = bench_cycles(hc, f, guess, 3)[0]
+    assert np.linalg.norm(A @ (a - b)) <= 5e-9 * np.linalg.norm(f)
+    assert np.array_equal(a, bench_cycles(h, f, guess, 3)[0])      # run-to-run deterministic
+    # zero right-hand side (Class_AMG.m:91-92)
+    xz, itz, relz, relkz, rhokz = h.solve(np.zeros(m + n), None)
+    assert itz == 0 and relkz[0] == 0.0 and np.isinf(rhokz[0]) and not xz.any()
+    h.close()
+    hc.close()
+
+
+@pytest.mark.parametrize("cycle", ["v", "w"])
+def test_n2048_runs_in_the_big_kernel(ipd, cycle):
+    """m = n = 2048, regime D (M = 4096: levels 4096 / 2048 / 1): the mask-form kernel on 256 workgroups
+    against the multi-launch path with the mask sweeps."""
+    m = n = 2048
+    s = bench.build_mask(m, n, "bernoulli", 1.0)
+    Ae, f, guess, H0 = bench.build_newton_system(ipd, m, n, s)
+    opts = options(cycle, n)
+    h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    assert h.level_sizes() == [4096, 2048, 1] and solve_mode(h)[0] == 0
+    assert h.attach_mask_operator(np.ones(m), np.ones(n), bench.TK)
+    mode, grid, _ = solve_mode(h)
+    assert (mode, grid) == (2, 256), (mode, grid)
+    with env(IPD_NO_RESIDENT_BIG=1):
+        hc = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+        assert hc.attach_mask_operator(np.ones(m), np.ones(n), bench.TK)
+    assert solve_mode(hc)[0] == 0
+    K = 3
+    a = bench_cycles(h, f, guess, K)[0]
+    b = bench_cycles(hc, f, guess, K)[0]
+    A = sp.csr_matrix(Ae)
+    nf_ = np.linalg.norm(f)
+    assert np.linalg.norm(A @ (a - b)) <= 5e-9 * nf_
+    r0 = np.linalg.norm(A @ guess - f)
+    assert np.linalg.norm(A @ a - f) < 1e-6 * r0
+    x, it, rel, relk, rhok = h.solve(f, guess)
+    xc, itc, relc, relkc, rhokc = hc.solve(f, guess)
+    assert solve_mode(h)[2] == 0
+    same_history(it, relk, itc, relkc)
+    assert np.linalg.norm(A @ (x - xc)) <= 1e-9 * nf_
+    h.close()
+    hc.close()

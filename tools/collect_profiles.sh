@@ -21,7 +21,7 @@ W=$(find $OUT/prof_write -name "*counter_collection.csv" | head -1)
 S=$(find $OUT/prof_stats -name "*kernel_stats.csv" | head -1)
 T=$(find $OUT/prof_stats -name "*kernel_trace.csv" | head -1)
 echo "fetch=$F write=$W stats=$S trace=$T"
-python3 tools/summarize_pmc.py $OUT/${R}_pmc_summary.json FETCH_SIZE=$F WRITE_SIZE=$W RESIDENT_CYCLES=5,50 || exit 1
+python3 tools/summarize_pmc.py $OUT/${R}_pmc_summary.json FETCH_SIZE=$F WRITE_SIZE=$W RESIDENT_CYCLES=5,50 WORKLOAD=n1:1024,mask:bernoulli,rho:1,cycle:v || exit 1
 cp $S $OUT/${R}_kernel_stats.csv
 # the dispatches of the dominant kernel, one row each (the 200-cycle one is the timed region)
 python3 - "$T" > $OUT/${R}_resident_dispatches.csv <<'PY'

@@ -29,6 +29,7 @@ def main():
     Ae, f, guess, H0 = bench.build_newton_system(ipd, m, n, s)
     opts = dict(retol=1e-11, bigph=1, maxit=30, theta=0.25, smoth=5, cycle=a.cycle, isnsp=1, inter=1, fnode=n)
     h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    print("level 1 <-> 2 transfers from the bit mask:", h.attach_mask_transfers(np.ones(m), np.ones(n), bench.TK))
     db = _lib.DeviceBuffer.from_array(f)
     dx = _lib.DeviceBuffer.from_array(guess)
     st = (c_int64 * 10)()
@@ -42,7 +43,7 @@ def main():
               % (a.cycles, ms.value, 1e3 * ms.value / a.cycles, nh, nh / a.cycles,
                  1e3 * ms.value / nh, 100.0 * wait / tot, wait / clk_mhz / nh, clk_mhz))
         rest = tot - wait - bar1 - store - bar2 - xfer - tail
-        print("   per cycle (us): transfers (CSR walks of P', P) %.2f | tail level %.2f" % (
+        print("   per cycle (us): transfers P'rr, P e_2 %.2f | tail level %.2f" % (
             xfer / clk_mhz / a.cycles, tail / clk_mhz / a.cycles))
         print("   per hand-off (us): row work %.2f | barrier before publish %.2f | sweep wait %.2f | "
               "store+sums %.2f | closing barrier %.2f" % tuple(v / clk_mhz / nh for v in (rest, bar1, wait, store, bar2)))
