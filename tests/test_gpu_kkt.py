@@ -49,6 +49,26 @@ def test_asat_bit_exact(ipd, m, n, rho):
     assert _csc_equal(H, O.ASAt(s, p, q))
 
 
+def test_asat_small_path_sequences(ipd):
+    """The one-launch assembly of small active sets (k_asat_small) is chosen from the PREVIOUS call's
+    entry count: sequences of calls on one context -- small after small (the path itself), a mask that
+    outgrows the guess (detected, redone by the general path), squares that are exactly zero (their
+    explicit zeros dropped as MATLAB's sparse() drops them), sizes that are no multiple of 64, E = 0."""
+    rs = np.random.RandomState(3)
+    for m, n in [(1024, 1024), (1000, 1024), (130, 257), (65, 63)]:
+        p, q = 0.5 + rs.random_sample(m), 0.5 + rs.random_sample(n)
+        masks = [PR.mask_tree(m, n, seed=4), PR.mask_tree(m, n, seed=5), PR.mask_bernoulli(m, n, 1.0 / 64, seed=6),
+                 np.zeros(m * n, np.uint8), PR.mask_tree(m, n, seed=7), PR.mask_bernoulli(m, n, 0.6, seed=8),
+                 PR.mask_tree(m, n, seed=9)]
+        for s in masks:
+            assert _csc_equal(ipd.ASAt(s, p, q), O.ASAt(s, p, q)), (m, n, int(s.sum()))
+        pz, qz = p.copy(), q.copy()
+        pz[::7] = 0.0
+        qz[3::5] = 0.0
+        for s in (PR.mask_tree(m, n, seed=10), PR.mask_tree(m, n, seed=11)):
+            assert _csc_equal(ipd.ASAt(s, pz, qz), O.ASAt(s, pz, qz)), (m, n, "zero squares")
+
+
 def test_asat_tree_mask_and_unit_pq(ipd):
     m, n = 300, 200
     s = PR.mask_tree(m, n, seed=4)
