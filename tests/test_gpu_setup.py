@@ -122,6 +122,54 @@ def test_transfer_standalone(ipd):
     assert csc_equal(gAc, Ac) and csc_equal(gPro, Pro) and np.array_equal(gC, info["isC"])
 
 
+@pytest.mark.parametrize("N,deg,seed", [(33, 2, 1), (300, 3, 5), (777, 5, 3), (1024, 4, 8)])
+@pytest.mark.parametrize("isnsp", [0, 1])
+def test_transfer_small_level_paths(ipd, N, deg, seed, isnsp):
+    """`transfer` on levels of at most 1024 rows goes through the one-launch mis_set (k_mis_small): the
+    split, Pro, Ac and the NUMBER of random numbers consumed against the oracle, with the launch-per-step
+    form (IPD_NO_MIS_SMALL=1) and the opt-in one-launch Galerkin part (IPD_GALERKIN_SMALL=1) beside it."""
+    import os
+    A = PR.random_sym_graph_laplacian(N, deg=deg, seed=seed)
+    o = O.amg_options_class1("v"); o.update(bigph=0, isnsp=isnsp)
+    rr = O.matlab_rng()
+    Ac, Pro, info = O.transfer(A, o, 2, rr)
+    used = len(info["mis"]["rand"])
+    for kv in ({}, {"IPD_NO_MIS_SMALL": "1"}, {"IPD_GALERKIN_SMALL": "1"}):
+        os.environ.update(kv)
+        try:
+            rng = ipd.MatlabRand()
+            gAc, gPro, gC = ipd.transfer(A, o, 2, rng)
+        finally:
+            for k in kv:
+                os.environ.pop(k)
+        assert csc_equal(gAc, Ac) and csc_equal(gPro, Pro) and np.array_equal(gC, info["isC"]), kv
+        assert rng.consumed == used, (kv, rng.consumed, used)
+
+
+def test_transfer_small_level_degenerate_and_replay(ipd):
+    """(a) hardly any strong connection (mis_set.m:30-34): the one-launch form reports it and the host
+    takes the branch; (b) a replay stream that holds exactly the numbers the level consumes -- fewer than
+    the N the one-launch form peeks at."""
+    N = 100
+    A = sp.diags(np.arange(1.0, N + 1), format="csr") + 1e-9 * PR.random_sym_graph_laplacian(N, deg=2, seed=1)
+    A = sp.csr_matrix(A)
+    o = O.amg_options_class1("v"); o.update(bigph=0, isnsp=0)
+    refC, refF, _, info = O.mis_set(A, 0.25, O.matlab_rng())
+    rng = ipd.MatlabRand()
+    if info["branch"] == "degenerate":
+        try:
+            gAc, gPro, gC = ipd.transfer(A, o, 2, rng)
+            assert np.array_equal(gC, refC) and rng.consumed == len(info["rand"])
+        except RuntimeError as exc:      # the reference itself may index out of range here (SURVEY A-6)
+            assert "coarse" in str(exc) or "mis_set" in str(exc)
+    B = PR.random_sym_graph_laplacian(400, deg=3, seed=2)
+    rr = O.matlab_rng()
+    Ac, Pro, info = O.transfer(B, o, 2, rr)
+    vals = np.asarray(info["mis"]["rand"], float)
+    got = ipd.transfer(B, o, 2, ipd.MatlabRand(replay=vals))
+    assert csc_equal(got[0], Ac) and csc_equal(got[1], Pro)
+
+
 @pytest.mark.parametrize("isnsp", [0, 1])
 def test_transfer_ideal_interpolation(ipd, isnsp):
     """`inter = 2`: W = -Aff \\ Afc (AMG/transfer.m:57-58).  MATLAB and the oracle (SuperLU) solve
