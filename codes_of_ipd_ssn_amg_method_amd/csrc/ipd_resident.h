@@ -624,12 +624,19 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // sum of the LDS vector at `off` over the set bits of `bits` (entry lane + 64 q <-> bit q), n entries
     auto masked_sum = [&](unsigned bits, int off, int n) __attribute__((always_inline)) {
         double s0 = 0.0, s1 = 0.0;
+        for (int q0 = 0; q0 < 16; q0 += 8) {   // eight gathers in flight (sixteen cost registers the row slices need)
+            double x[8];
 #pragma unroll
-        for (int q = 0; q < 16; q += 2) {
-            const int j0 = lane + 64 * q, j1 = lane + 64 * (q + 1);
-            const double x0 = sm[off + (j0 < n ? j0 : 0)], x1 = sm[off + (j1 < n ? j1 : 0)];
-            s0 += ((bits >> q) & 1u) ? x0 : 0.0;
-            s1 += ((bits >> (q + 1)) & 1u) ? x1 : 0.0;
+            for (int q = 0; q < 8; ++q) {
+                const int j = lane + 64 * (q0 + q);
+                x[q] = sm[off + (j < n ? j : 0)];
+            }
+            const unsigned bq = bits >> q0;
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                s0 += ((bq >> q) & 1u) ? x[q] : 0.0;
+                s1 += ((bq >> (q + 1)) & 1u) ? x[q + 1] : 0.0;
+            }
         }
         return wave_sum(s0 + s1);
     };
