@@ -297,71 +297,105 @@ __global__ __launch_bounds__(1024) void k_mis_small(const MisSmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) char mis_raw[];
     __shared__ int wsum[16];
     __shared__ int s_cnt[2];
-    const int N = a.N, i = threadIdx.x;
-    const bool valid = i < N;
+    const int N = a.N;
+    // L lanes per node (the largest of 1, 2, 4, 8 with N L <= 1024): a row's entries -- in memory for the
+    // strength pass, its strong-neighbour list in LDS for the rounds -- are strided over the group, so a
+    // hub row of 60-300 entries is a few trips, not a chain of as many; lane 0 of the group owns the node
+    int L = 1;
+    while (L < 8 && N * (L * 2) <= 1024) L <<= 1;
+    const int i = threadIdx.x / L, sub = threadIdx.x % L;
+    const bool valid = i < N, owner = valid && sub == 0;
     double* maxrow = reinterpret_cast<double*>(mis_raw);            // N
     double* deg = maxrow + MIS_SMALL_ROWS;                          // N
     int* degi = reinterpret_cast<int*>(deg + MIS_SMALL_ROWS);       // N
-    int* srp = degi + MIS_SMALL_ROWS;                               // N + 1
-    uint8_t* fC = reinterpret_cast<uint8_t*>(srp + MIS_SMALL_ROWS + 8);
+    int* scnt = degi + MIS_SMALL_ROWS;                              // N: strong neighbours listed so far
+    uint8_t* fC = reinterpret_cast<uint8_t*>(scnt + MIS_SMALL_ROWS);
     uint8_t* fF = fC + MIS_SMALL_ROWS;
     uint8_t* fU = fF + MIS_SMALL_ROWS;
     uint8_t* fS = fU + MIS_SMALL_ROWS;
     uint8_t* fS2 = fS + MIS_SMALL_ROWS;
-    unsigned short* sci = reinterpret_cast<unsigned short*>(fS2 + MIS_SMALL_ROWS);   // strong neighbours
+    unsigned short* sci = reinterpret_cast<unsigned short*>(fS2 + MIS_SMALL_ROWS);   // strong neighbours, row i at [r0, ..)
     const int r0 = valid ? a.rp[i] : 0, r1 = valid ? a.rp[i + 1] : 0;
-    // ---- strength.m:7-10 (k_rowmax)
+    auto group_or = [&](bool v) {
+        int x = v ? 1 : 0;
+        for (int d = 1; d < L; d <<= 1) x |= __shfl_xor(x, d);
+        return x != 0;
+    };
+    // ---- strength.m:7-10 (k_rowmax); eight entries per lane and trip, all loads of a trip in flight
     {
         double mx = 0.0, dg = 0.0;
-        for (int t = r0; t < r1; ++t) {
-            const int j = a.ci[t];
-            const double v = a.va[t];
-            if (j == i)
-                dg = v;
-            else
-                mx = fmax(mx, -v);
+        for (int t0 = r0 + sub; t0 < r1; t0 += 8 * L) {
+            int jj[8];
+            double vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * L < r1 ? t0 + u * L : r0;
+                jj[u] = a.ci[t];
+                vv[u] = a.va[t];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t0 + u * L < r1) {
+                    if (jj[u] == i)
+                        dg = vv[u];
+                    else
+                        mx = fmax(mx, -vv[u]);
+                }
+            }
         }
-        if (valid) {
+        for (int d = 1; d < L; d <<= 1) {
+            mx = fmax(mx, __shfl_xor(mx, d));
+            dg += __shfl_xor(dg, d);   // at most one lane holds the diagonal
+        }
+        if (owner) {
             const double m = mx > 0.0 ? mx : INFINITY;
             maxrow[i] = m;
             a.maxrow[i] = m;
             a.diag[i] = dg;
             degi[i] = 0;
+            scnt[i] = 0;
         }
     }
     __syncthreads();
-    // ---- mis_set.m:25-29 (k_strong): the mask, its column counts (deg) and row counts
-    int rowcnt = 0;
+    // ---- mis_set.m:25-29 (k_strong): the mask, its column counts (deg) and row counts; the strong
+    // neighbours of row i are listed at sci[r0 ..) in any order (the rounds only ask whether ANY / EVERY
+    // neighbour has a property, so the order of the list does not matter)
     {
         const double mr = valid ? maxrow[i] : 1.0;
-        for (int t = r0; t < r1; ++t) {
-            const int j = a.ci[t];
-            bool f = false;
-            if (j != i) {
-                const double sv = (-a.va[t]) / fmin(mr, maxrow[j]);
-                f = sv >= a.theta;
+        for (int t0 = r0 + sub; t0 < r1; t0 += 8 * L) {
+            int jj[8];
+            double vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * L < r1 ? t0 + u * L : r0;
+                jj[u] = a.ci[t];
+                vv[u] = a.va[t];
             }
-            a.strong[t] = f ? 1 : 0;
-            if (f) {
-                atomicAdd(&degi[j], 1);
-                ++rowcnt;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t0 + u * L < r1) {
+                    const int j = jj[u];
+                    bool f = false;
+                    if (j != i) {
+                        const double sv = (-vv[u]) / fmin(mr, maxrow[j]);
+                        f = sv >= a.theta;
+                    }
+                    a.strong[t0 + u * L] = f ? 1 : 0;
+                    if (f) {
+                        atomicAdd(&degi[j], 1);
+                        sci[r0 + atomicAdd(&scnt[i], 1)] = (unsigned short)j;
+                    }
+                }
             }
         }
     }
-    int total = 0;
-    const int sbeg = mis_block_exscan(rowcnt, wsum, &total);   // (synchronises: degi is final afterwards)
-    if (valid) {
-        srp[i] = sbeg;
-        int o = sbeg;
-        for (int t = r0; t < r1; ++t)
-            if (a.strong[t]) sci[o++] = (unsigned short)a.ci[t];
-    }
-    if (i == 0) srp[N] = total;
+    __syncthreads();   // degi, scnt and the lists are final
+    const int rowcnt = valid ? scnt[i] : 0;
     const int d = valid ? degi[i] : 0;
     int nconn = 0;
-    const int rank = mis_block_exscan(d > 0 ? 1 : 0, wsum, &nconn);
+    const int rank = mis_block_exscan((owner && d > 0) ? 1 : 0, wsum, &nconn);
     if ((double)nconn < 0.25 * sqrt((double)N)) {              // :30-34: the host takes this (rare) branch
-        if (i == 0) {
+        if (threadIdx.x == 0) {
             a.box[16] = 1u;
             a.box[17] = (unsigned)nconn;
             __threadfence_system();
@@ -370,7 +404,7 @@ __global__ __launch_bounds__(1024) void k_mis_small(const MisSmallArgs a) {
         return;
     }
     // ---- :35-40 (k_deg_init)
-    if (valid) {
+    if (owner) {
         double dv = 0.0;
         if (d > 0) {
             const double tie = 0.1 * a.randv[rank];
@@ -384,7 +418,7 @@ __global__ __launch_bounds__(1024) void k_mis_small(const MisSmallArgs a) {
     }
     __syncthreads();
     // ---- :42-65: the rounds
-    const int s0 = valid ? srp[i] : 0, s1 = valid ? srp[i + 1] : 0;
+    const int s0 = r0, s1 = r0 + rowcnt;
     int sumC = 0, sumU = N, rounds = 0;
     uint8_t* cur = fS;
     uint8_t* nxt = fS2;
@@ -393,7 +427,7 @@ __global__ __launch_bounds__(1024) void k_mis_small(const MisSmallArgs a) {
         if (valid) {                                           // k_mis_sel_kill (:49-52)
             const double di = deg[i];
             if (di > 0.0)
-                for (int t = s0; t < s1; ++t) {
+                for (int t = s0 + sub; t < s1; t += L) {
                     const int j = sci[t];
                     if (j > i) {
                         const double dj = deg[j];
@@ -406,15 +440,17 @@ __global__ __launch_bounds__(1024) void k_mis_small(const MisSmallArgs a) {
                     }
                 }
         }
-        if (i < 2) s_cnt[i] = 0;
+        if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
         __syncthreads();
-        int c1 = 0, u1 = 0;
-        if (valid) {                                           // k_mis_settle (:53-59)
-            bool hit = false;
-            for (int t = s0; t < s1; ++t) {
+        bool hit = false;                                      // k_mis_settle (:53-59)
+        if (valid)
+            for (int t = s0 + sub; t < s1; t += L) {
                 const int j = sci[t];
                 if (fC[j] || cur[j]) hit = true;
             }
+        hit = group_or(hit);
+        int c1 = 0, u1 = 0;
+        if (owner) {
             const bool c = fC[i] || cur[i];
             const bool f = fF[i] || hit;
             const bool u = !(c || f);
@@ -432,7 +468,7 @@ __global__ __launch_bounds__(1024) void k_mis_small(const MisSmallArgs a) {
             if (bu) atomicAdd(&s_cnt[1], __popcll(bu));
         }
         __syncthreads();
-        if (valid && c1) fC[i] = 1;
+        if (owner && c1) fC[i] = 1;
         sumC = s_cnt[0];
         sumU = s_cnt[1];
         uint8_t* tsw = cur;
@@ -440,7 +476,7 @@ __global__ __launch_bounds__(1024) void k_mis_small(const MisSmallArgs a) {
         nxt = tsw;
         __syncthreads();
         if (sumU <= a.N0) {                                    // :61-64 (k_mis_absorb)
-            if (valid && fU[i]) {
+            if (owner && fU[i]) {
                 fC[i] = 1;
                 fU[i] = 0;
             }
@@ -450,7 +486,7 @@ __global__ __launch_bounds__(1024) void k_mis_small(const MisSmallArgs a) {
     }
     // ---- :67 (k_mis_iso), then the C index scan and the consistency count of transfer.m:46-47
     int isc = 0, isf = 0;
-    if (valid) {
+    if (owner) {
         isc = fC[i];
         isf = fF[i];
         if (rowcnt == 0) {
@@ -461,10 +497,10 @@ __global__ __launch_bounds__(1024) void k_mis_small(const MisSmallArgs a) {
         a.isF[i] = (uint8_t)isf;
     }
     int Nc = 0, bad = 0;
-    const int cpos = mis_block_exscan(isc, wsum, &Nc);
-    mis_block_exscan((valid && (isc != 0) == (isf != 0)) ? 1 : 0, wsum, &bad);
-    if (valid) a.cidx[i] = cpos;
-    if (i == 0) {
+    const int cpos = mis_block_exscan(owner ? isc : 0, wsum, &Nc);
+    mis_block_exscan((owner && (isc != 0) == (isf != 0)) ? 1 : 0, wsum, &bad);
+    if (owner) a.cidx[i] = cpos;
+    if (threadIdx.x == 0) {
         a.cidx[N] = Nc;
         a.box[16] = 0u;
         a.box[17] = (unsigned)nconn;
@@ -519,7 +555,7 @@ static bool mis_set_small(ipd_ctx* ctx, const Csr& A, double theta, ipd_rng* rng
     a.cidx = cidx;
     a.box = ctx->mailbox;
     a.ticket = ticket;
-    const size_t lds = 16 * (size_t)MIS_SMALL_ROWS + 4 * (size_t)MIS_SMALL_ROWS * 2 + 32 + 5 * (size_t)MIS_SMALL_ROWS +
+    const size_t lds = 16 * (size_t)MIS_SMALL_ROWS + 8 * (size_t)MIS_SMALL_ROWS + 5 * (size_t)MIS_SMALL_ROWS +
                        2 * (size_t)std::max(A.nnz, 1) + 64;
     IPD_OPTIN_LDS(ctx, k_mis_small, 156 * 1024);
     hipLaunchKernelGGL(k_mis_small, dim3(1), dim3(1024), lds, ctx->stream, a);
