@@ -120,6 +120,65 @@ __global__ void k_level_prepare(int N, int nf, const int* __restrict__ rp,
     if (lane == 0 && longest > 0) atomicMax(maxoff, longest);
 }
 
+// All levels of a hierarchy in two launches instead of two per level (the hierarchy is rebuilt at every
+// Newton step): workgroup b of k_levels_prepare belongs to the level whose block range holds b, workgroup
+// k of k_levels_sum adds A*1 of level k in k_vec_sum's order (same bits).
+constexpr int PREP_ML = 24;
+struct PrepLevels {
+    int n;
+    int first_block[PREP_ML + 1];
+    int N[PREP_ML], nf[PREP_ML];
+    const int* rp[PREP_ML];
+    const int* ci[PREP_ML];
+    const double* va[PREP_ML];
+    double* dinv[PREP_ML];
+    double* Axi[PREP_ML];
+    double* xx[PREP_ML];
+    int* maxoff[PREP_ML];
+};
+__global__ void k_levels_prepare(const PrepLevels P) {
+    int k = 0;
+    while (k + 1 < P.n && (int)blockIdx.x >= P.first_block[k + 1]) ++k;
+    const int nb = P.first_block[k + 1] - P.first_block[k], lb = blockIdx.x - P.first_block[k];
+    const int N = P.N[k], nf = P.nf[k];
+    const int* __restrict__ rp = P.rp[k];
+    const int* __restrict__ ci = P.ci[k];
+    const double* __restrict__ va = P.va[k];
+    const int lane = threadIdx.x & 63;
+    const int wave = (lb * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (nb * blockDim.x) >> 6;
+    int longest = 0;
+    for (int r = wave; r < N; r += nwaves) {
+        double s = 0.0, dg = 0.0;
+        int hasd = 0;
+        for (int t = rp[r] + lane; t < rp[r + 1]; t += 64) {
+            s += va[t];
+            if (ci[t] == r) {
+                dg = va[t];
+                hasd = 1;
+            }
+        }
+        s = wave_sum(s);
+        dg = wave_sum(dg);
+        hasd = __any(hasd) ? 1 : 0;
+        longest = max(longest, rp[r + 1] - rp[r] - hasd);
+        if (lane == 0) {
+            P.Axi[k][r] = s;
+            P.dinv[k][r] = nf > 0 ? 1.0 / dg : 0.5 * (1.0 / dg);
+        }
+    }
+    if (lane == 0 && longest > 0) atomicMax(P.maxoff[k], longest);
+}
+__global__ __launch_bounds__(BT) void k_levels_sum(const PrepLevels P) {
+    __shared__ double red[16];
+    const int k = blockIdx.x;
+    const double* v = P.Axi[k];
+    double s = 0.0;
+    for (int t = threadIdx.x; t < P.N[k]; t += BT) s += v[t];
+    const double tot = block_sum(s, red);
+    if (threadIdx.x == 0) P.xx[k][0] = tot;
+}
+
 static int pick_blocks(int nrows, int L, int cu);
 
 // Builds the padded off-diagonal copy when the level is big and regular enough
@@ -583,6 +642,9 @@ void amg_prepare_levels(ipd_amg* h) {
     const ipd_amg* donor = h->donor.get();
     const CycleState* dst_ = donor ? donor->cyc.get() : nullptr;
     auto shared_level = [&](int k) { return dst_ && k <= 2 && k <= donor->J; };
+    PrepLevels prep;
+    prep.n = 0;
+    prep.first_block[0] = 0;
     for (int k = 1; k <= h->J; ++k) {
         Level& lv = h->L[k];
         const int N = lv.A.nr;
@@ -609,12 +671,32 @@ void amg_prepare_levels(ipd_amg* h) {
         lv.e2 = ar.alloc<double>((size_t)N);
         lv.w = ar.alloc<double>((size_t)N);
         lv.rr = ar.alloc<double>((size_t)N);
-        hipLaunchKernelGGL(k_level_prepare, dim3(std::max(1, std::min(cdiv(N, 4), 4096))), dim3(256),
-                           0, ctx->stream, N, lv.nf, lv.A.rp, lv.A.ci, lv.A.va, lv.dinv, lv.Axi,
-                           maxoff + k);
+        if (prep.n < PREP_ML) {
+            const int q = prep.n++;
+            prep.N[q] = N;
+            prep.nf[q] = lv.nf;
+            prep.rp[q] = lv.A.rp;
+            prep.ci[q] = lv.A.ci;
+            prep.va[q] = lv.A.va;
+            prep.dinv[q] = lv.dinv;
+            prep.Axi[q] = lv.Axi;
+            prep.xx[q] = lv.xx;
+            prep.maxoff[q] = maxoff + k;
+            prep.first_block[q + 1] = prep.first_block[q] + std::max(1, std::min(cdiv(N, 4), 4096));
+        } else {
+            hipLaunchKernelGGL(k_level_prepare, dim3(std::max(1, std::min(cdiv(N, 4), 4096))), dim3(256),
+                               0, ctx->stream, N, lv.nf, lv.A.rp, lv.A.ci, lv.A.va, lv.dinv, lv.Axi,
+                               maxoff + k);
+            IPD_KERNEL_CHECK();
+            hipLaunchKernelGGL(k_vec_sum, dim3(1), dim3(BT), 0, ctx->stream, (const double*)lv.Axi, N,
+                               lv.xx);
+            IPD_KERNEL_CHECK();
+        }
+    }
+    if (prep.n > 0) {
+        hipLaunchKernelGGL(k_levels_prepare, dim3(prep.first_block[prep.n]), dim3(256), 0, ctx->stream, prep);
         IPD_KERNEL_CHECK();
-        hipLaunchKernelGGL(k_vec_sum, dim3(1), dim3(BT), 0, ctx->stream, (const double*)lv.Axi, N,
-                           lv.xx);
+        hipLaunchKernelGGL(k_levels_sum, dim3(prep.n), dim3(BT), 0, ctx->stream, prep);
         IPD_KERNEL_CHECK();
     }
     std::vector<int> hmax((size_t)h->J + 1);
