@@ -902,6 +902,10 @@ struct SolveLevel {
     // Thread-per-row levels: lane map (k_pack_lmap, see blk_sweeps) -- BT words {row | sub << 10 |
     // log2(lanes of the row) << 14 | valid << 31} and one word "entries per lane" (0: walk in a loop).
     const unsigned* lmap;
+    // Small, nearly full thread-per-row levels (level 4 of the early Newton systems: 60-100 rows, 50-100 %
+    // full): the image carries the dense copy dA instead of the CSR arrays, and a lane keeps its part of
+    // the row (columns sub, sub + Lr, ...) in registers for the visit (blk_sweeps).
+    int blk_dense;
 };
 struct SolveDesc {
     int J, nu, isnsp, wcycle, anycycle, maxit;
@@ -1038,6 +1042,7 @@ struct LdsLevel {
     bool poly;
     AS3 const unsigned* lmap;
     bool mapped;
+    bool bdense;
     double xx;
     // semi-cached level: a 1024-row level does not fit in LDS beside the deeper ones, but its
     // rows are short (3-7 entries) and L2-resident; only r, e, e2 live in LDS
@@ -1091,6 +1096,7 @@ __device__ __forceinline__ LdsLevel lds_level(const SolveCtx& c, int k) {
     L.poly = G.pMr != nullptr;
     L.lmap = as_lds(G.lmap);
     L.mapped = G.lmap != nullptr;
+    L.bdense = G.blk_dense != 0;
     L.semi = (k == D->k_semi);
     L.grp = G.lv.rp;
     L.gci = G.lv.ci;
@@ -1785,6 +1791,67 @@ __device__ __forceinline__ double lds_rowdot_mapped(AS3 const int* ci, AS3 const
     return subsum_var(s, m.lg);
 }
 
+// dense thread-per-row level: the lane's part of row i (columns sub + Lr q) from the row-major dense copy
+// (leading dimension bdense_ld: whole groups of four q, and rows of a wave on different banks), and its
+// dot product with an LDS vector.  No index tests: the copy's and the vectors' padding are zeros
+// (bdense_pad entries, see build_image), so a group of four q is four loads at constant offsets.
+// 24 values per lane: the register budget of the tail (the resident kernels' worker paths set the
+// kernels' allocation; the tail must stay below it) -- the same storage serves the lane-map entries.
+constexpr int BDENSE_Q = 24;
+struct DenseRow {
+    double v[BDENSE_Q];
+};
+__host__ __device__ __forceinline__ int bdense_lanes(int N) { return N > 64 ? 4 : 8; }   // == lanes_per_row(N), 33..96 rows
+__host__ __device__ __forceinline__ int bdense_pad(int N) {
+    const int g = 4 * bdense_lanes(N);
+    return (N + g - 1) / g * g;
+}
+__host__ __device__ __forceinline__ int bdense_ld(int N) {
+    const int Lr = bdense_lanes(N), p = bdense_pad(N);
+    return p % (2 * Lr) == Lr ? p : p + Lr;   // p is a multiple of 4 Lr
+}
+template <int LR>
+__device__ __forceinline__ void dense_row_load_t(AS3 const double* dA, int N, int i, int sub, DenseRow& R) {
+    const int Q = bdense_pad(N) / LR;   // a multiple of 4
+    AS3 const double* row = dA + i * bdense_ld(N) + sub;
+#pragma unroll
+    for (int q0 = 0; q0 < BDENSE_Q; q0 += 4) {
+        const bool in = q0 < Q;   // uniform
+#pragma unroll
+        for (int u = 0; u < 4; ++u) R.v[q0 + u] = in ? row[LR * (q0 + u)] : 0.0;
+    }
+}
+template <int LR>
+__device__ __forceinline__ double dense_row_dot_t(const DenseRow& R, int N, int sub, AS3 const double* x) {
+    const int Q = bdense_pad(N) / LR;
+    AS3 const double* xs = x + sub;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int q0 = 0; q0 < BDENSE_Q; q0 += 8) {
+        if (q0 >= Q) break;   // uniform
+        const double x0 = xs[LR * q0], x1 = xs[LR * (q0 + 1)], x2 = xs[LR * (q0 + 2)], x3 = xs[LR * (q0 + 3)];
+        s0 += R.v[q0] * x0;
+        s1 += R.v[q0 + 1] * x1;
+        s2 += R.v[q0 + 2] * x2;
+        s3 += R.v[q0 + 3] * x3;
+        if (q0 + 4 >= Q) break;   // uniform
+        const double x4 = xs[LR * (q0 + 4)], x5 = xs[LR * (q0 + 5)], x6 = xs[LR * (q0 + 6)], x7 = xs[LR * (q0 + 7)];
+        s0 += R.v[q0 + 4] * x4;
+        s1 += R.v[q0 + 5] * x5;
+        s2 += R.v[q0 + 6] * x6;
+        s3 += R.v[q0 + 7] * x7;
+    }
+    return subwave_sum((s0 + s1) + (s2 + s3), LR);
+}
+// (row i < N: the caller passes row 0 for lanes without a row and ignores their sum)
+__device__ __forceinline__ void dense_row_load(AS3 const double* dA, int N, int i, int sub, DenseRow& R) {
+    if (bdense_lanes(N) == 4) dense_row_load_t<4>(dA, N, i, sub, R);
+    else dense_row_load_t<8>(dA, N, i, sub, R);
+}
+__device__ __forceinline__ double dense_row_dot(const DenseRow& R, int N, int sub, AS3 const double* x) {
+    return bdense_lanes(N) == 4 ? dense_row_dot_t<4>(R, N, sub, x) : dense_row_dot_t<8>(R, N, sub, x);
+}
+
 __device__ __forceinline__ double blk_total(AS3 const double* part) {
     double s = 0.0;
 #pragma unroll
@@ -1804,7 +1871,8 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
     // thread-per-row with the first entries in registers, long rows are walked from L2 by Lr lanes
     const bool semi_long = L.semi && L.grp[N] > 12 * N;
     const bool semi_regs = L.semi && !semi_long;
-    const bool mapped = L.mapped && !L.semi;
+    const bool bdense = L.bdense && !L.semi;
+    const bool mapped = L.mapped && !L.semi && !bdense;
     LaneSlot ms;
     ms.row = ms.sub = ms.lg = 0;
     ms.valid = false;
@@ -1824,23 +1892,31 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
     SemiRow R;
     if (semi_regs) R = semi_row_load(L, i, valid);
     int rbeg = 0, rend = 0;            // entry range of the row: the same for every sweep of the visit
-    if (!L.semi && valid) {
+    if (!L.semi && !bdense && valid) {
         rbeg = L.rp[i];
         rend = L.rp[i + 1];
     }
+    DenseRow DR;                       // dense levels: the lane's part of the row; lane-map levels: its entries' values
+    double* const mv = DR.v;
+    if (bdense) dense_row_load(L.dA, N, valid ? i : 0, sub, DR);
     if (semi_long && valid) {
         rbeg = L.grp[i];
         rend = L.grp[i + 1];
     }
-    // mapped level with at most eight entries per lane: they stay in registers for the visit
-    const bool mregs = mapped && mapE >= 1 && mapE <= 8;
-    const bool mregs8 = mregs && mapE > 4;
-    int mc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double mv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    // mapped level with at most sixteen entries per lane: they stay in registers for the visit
+    const bool mregs = mapped && mapE >= 1 && mapE <= 16;
+    const bool mregs8 = mregs && mapE > 4, mregs16 = mregs && mapE > 8;
+    int mc[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) mc[u] = 0;
+    if (!bdense) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) mv[u] = 0.0;
+    }
     if (mregs) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (u >= 4 && !mregs8) break;
+        for (int u = 0; u < 16; ++u) {
+            if ((u >= 4 && !mregs8) || (u >= 8 && !mregs16)) break;
             const int t = rbeg + sub + u * Lr;
             const bool in = valid && t < rend;
             mc[u] = in ? L.ci[t] : 0;
@@ -1849,7 +1925,7 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
     }
     // more than two entries per lane on average: four per trip (one dependent LDS round trip less per
     // sweep on such levels; with two or fewer the masked slots of a wider batch only cost issue slots)
-    const bool wide = !L.semi && L.rp[N] > 2 * N * Lr;
+    const bool wide = !L.semi && !bdense && L.rp[N] > 2 * N * Lr;
     const int dskip = c.D->dbg_skip;
     if (dskip & 8) nu = 0;
     for (int s = 0; s < nu; ++s) {
@@ -1859,12 +1935,21 @@ __device__ __forceinline__ void blk_sweeps(SolveCtx& c, int k, LdsLevel& L, int 
         if (isnsp) cc = (sumr - (ez ? 0.0 : blk_total(part + 16 * cur))) / L.xx;
         double sd = 0.0;
         if (!ez) {
-            if (mregs) {
+            if (bdense) {
+                sd = dense_row_dot(DR, N, sub, L.e);
+            } else if (mregs) {
                 const double x0 = L.e[mc[0]], x1 = L.e[mc[1]], x2 = L.e[mc[2]], x3 = L.e[mc[3]];
                 double acc = (mv[0] * x0 + mv[1] * x1) + (mv[2] * x2 + mv[3] * x3);
                 if (mregs8) {
                     const double x4 = L.e[mc[4]], x5 = L.e[mc[5]], x6 = L.e[mc[6]], x7 = L.e[mc[7]];
                     acc += (mv[4] * x4 + mv[5] * x5) + (mv[6] * x6 + mv[7] * x7);
+                }
+                if (mregs16) {
+                    double xx8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xx8[u] = L.e[mc[8 + u]];
+                    acc += ((mv[8] * xx8[0] + mv[9] * xx8[1]) + (mv[10] * xx8[2] + mv[11] * xx8[3])) +
+                           ((mv[12] * xx8[4] + mv[13] * xx8[5]) + (mv[14] * xx8[6] + mv[15] * xx8[7]));
                 }
                 sd = subsum_var(acc, ms.lg);
             } else if (mapped) {
@@ -1955,7 +2040,14 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
             }
             {   // residual, then restriction into the child's right-hand side
                 SOL_DBG_T0(c);
-                if (L.mapped && !L.semi) {
+                if (L.bdense && !L.semi) {
+                    const int Lr = lanes_per_row(L.N), row = i / Lr, sub = i % Lr;
+                    const bool rvld = row < L.N;
+                    DenseRow DR;
+                    dense_row_load(L.dA, L.N, rvld ? row : 0, sub, DR);
+                    const double sd = dense_row_dot(DR, L.N, sub, L.e);
+                    if (rvld && sub == 0) L.e2[row] = L.r[row] - sd;
+                } else if (L.mapped && !L.semi) {
                     const LaneSlot ms = lane_slot(L.lmap);
                     const int rb = ms.valid ? L.rp[ms.row] : 0, re = ms.valid ? L.rp[ms.row + 1] : 0;
                     const double sd = lds_rowdot_mapped(L.ci, L.va, rb, re, ms, L.e);
@@ -2139,16 +2231,21 @@ struct DenseEntry {
     const double* va;
     int rows, cols;
     unsigned dst_off;
+    int ld_row;   // 0: column-major; > 0: row-major with this leading dimension (dense thread-per-row levels)
 };
 // dense column-major copies of the tiny levels' operators (one workgroup per matrix)
 __global__ __launch_bounds__(256) void k_pack_dense(const DenseEntry* __restrict__ ents,
                                                     char* __restrict__ img) {
     const DenseEntry e = ents[blockIdx.x];
     double* dst = reinterpret_cast<double*>(img + e.dst_off);
-    for (int t = threadIdx.x; t < e.rows * e.cols; t += 256) dst[t] = 0.0;
+    const int total = e.ld_row ? e.rows * e.ld_row : e.rows * e.cols;
+    for (int t = threadIdx.x; t < total; t += 256) dst[t] = 0.0;
     __syncthreads();
     for (int r = threadIdx.x; r < e.rows; r += 256)
-        for (int t = e.rp[r]; t < e.rp[r + 1]; ++t) dst[r + (size_t)e.ci[t] * e.rows] = e.va[t];
+        for (int t = e.rp[r]; t < e.rp[r + 1]; ++t) {
+            if (e.ld_row) dst[(size_t)r * e.ld_row + e.ci[t]] = e.va[t];
+            else dst[r + (size_t)e.ci[t] * e.rows] = e.va[t];
+        }
 }
 
 // Lane map of a thread-per-row level (see blk_sweeps): one workgroup per level.
@@ -2219,7 +2316,7 @@ __global__ __launch_bounds__(BT) void k_pack_lmap(const LmapEntry* __restrict__ 
             base[c] = off;
             off += cnt[c] << c;
         }
-        map[BT] = (E <= 8 && maxlen <= 16 * E) ? (unsigned)E : 0u;
+        map[BT] = (E <= 16 && maxlen <= 16 * E) ? (unsigned)E : 0u;
     }
     __syncthreads();
     if (t < e.N) {

@@ -892,6 +892,14 @@ void amg_prepare_levels(ipd_amg* h) {
         if (nb && nb[0] == '1') lean_vectors = false;
     }
     const bool use_lmap = !(std::getenv("IPD_NO_LMAP") && std::getenv("IPD_NO_LMAP")[0] == '1') && lean_vectors;
+    // small, nearly full thread-per-row levels: dense copy instead of the CSR arrays (see SolveLevel::blk_dense)
+    const bool use_bdense = lean_vectors && !(std::getenv("IPD_NO_BLKDENSE") && std::getenv("IPD_NO_BLKDENSE")[0] == '1');
+    auto is_bdense = [&](int k) {
+        if (!use_bdense || k < 2 || k >= h->J || k >= tiny_lo) return false;
+        const long long N = h->L[k].A.nr;
+        return N > 32 && N <= 96 && bdense_pad((int)N) / bdense_lanes((int)N) <= BDENSE_Q &&
+               3LL * h->L[k].A.nnz >= N * N;
+    };
     // LDS cache plan: deepest levels first, while they fit; returns the first cached level
     auto plan_lds = [&](size_t stage, size_t* used_out) {
         size_t used = stage + SOL_HEAD + 256;
@@ -907,14 +915,18 @@ void amg_prepare_levels(ipd_amg* h) {
                 const size_t Nc = (size_t)h->L[k + 1].A.nr, LD = poly_ld(N + Nc);
                 bytes = 2 * (8 * LD * r8(N)) + 8 * LD * r8(Nc) + 8 * LD + 3 * r16(8 * r8(N)) + 32;
             } else {
-                bytes = r16(4 * (N + 1)) + r16(4 * (size_t)lv.A.nnz) + r16(8 * (size_t)lv.A.nnz) +
-                        ((lean_vectors && k >= 2) ? 5 : 7) * r16(8 * (k >= tiny_lo ? r8(N) : N)) + 16;
+                bytes = r16(4 * (N + 1)) +
+                        (is_bdense(k) ? r16(8 * N * (size_t)bdense_ld((int)N))
+                                      : r16(4 * (size_t)lv.A.nnz) + r16(8 * (size_t)lv.A.nnz)) +
+                        ((lean_vectors && k >= 2) ? 5 : 7) *
+                            r16(8 * (k >= tiny_lo ? r8(N) : is_bdense(k) ? (size_t)bdense_pad((int)N) : N)) +
+                        16;
                 if (k < h->J) {
                     const size_t Nc = (size_t)h->L[k + 1].A.nr, np = (size_t)h->L[k + 1].P.nnz;
                     bytes += r16(4 * (Nc + 1)) + r16(4 * (N + 1)) + 2 * (r16(4 * np) + r16(8 * np));
                 }
                 if (k == h->J) bytes += r16(4 * 8 * N);
-                if (use_lmap && k >= 2 && k < tiny_lo && N <= (size_t)BT) bytes += r16(4 * (BT + 1));   // lane map
+                if (use_lmap && !is_bdense(k) && k >= 2 && k < tiny_lo && N <= (size_t)BT) bytes += r16(4 * (BT + 1));   // lane map
                 if (k >= tiny_lo) {   // dense copies of the tiny levels
                     bytes += r16(8 * N * N);
                     if (k < h->J) bytes += 2 * r16(8 * N * (size_t)h->L[k + 1].A.nr);
@@ -983,8 +995,14 @@ void amg_prepare_levels(ipd_amg* h) {
                 continue;
             }
             put(T.lv.rp, N + 1);
-            put(T.lv.ci, (size_t)T.nnzA);
-            put(T.lv.va, (size_t)T.nnzA);
+            if (is_bdense(k) && sd->k_blk <= k && k < sd->k_tiny) {   // dense copy (carved below) instead of ci / va
+                T.blk_dense = 1;
+                T.lv.ci = nullptr;
+                T.lv.va = nullptr;
+            } else {
+                put(T.lv.ci, (size_t)T.nnzA);
+                put(T.lv.va, (size_t)T.nnzA);
+            }
             put(T.lv.dinv, N);
             put(T.lv.Axi, N);
             put(T.lv.xx, 1);
@@ -1000,7 +1018,7 @@ void amg_prepare_levels(ipd_amg* h) {
         }
         std::vector<LmapEntry> lmaps;
         for (int k = std::max(k_from, sd->k_blk); k < std::min(sd->k_tiny, h->J + 1); ++k) {
-            if (!use_lmap || k == sd->k_semi || k < 2 || h->L[k].A.nr > BT || k == h->J) continue;
+            if (!use_lmap || k == sd->k_semi || k < 2 || h->L[k].A.nr > BT || k == h->J || sd->L[k].blk_dense) continue;
             SolveLevel& T = sd->L[k];
             const size_t o = carve(4 * (BT + 1));
             lmaps.push_back(LmapEntry{h->L[k].A.rp, h->L[k].A.nr, (unsigned)(o - stage)});
@@ -1009,6 +1027,14 @@ void amg_prepare_levels(ipd_amg* h) {
         std::vector<DenseEntry> dense;
         std::vector<PolyEntry> polys;
         size_t poly_lds = 0;
+        for (int k = k_from; k <= h->J; ++k) {
+            if (!sd->L[k].blk_dense) continue;
+            const Csr& m = h->L[k].A;
+            const int ld = bdense_ld(m.nr);
+            const size_t o = carve(8 * (size_t)m.nr * ld);
+            dense.push_back(DenseEntry{m.rp, m.ci, m.va, m.nr, m.nc, (unsigned)(o - stage), ld});
+            set_off(sd->L[k].dA, o);
+        }
         for (int k = std::max(k_from, sd->k_tiny); k <= h->J; ++k) {
             SolveLevel& T = sd->L[k];
             const Level& lv = h->L[k];
@@ -1052,7 +1078,7 @@ void amg_prepare_levels(ipd_amg* h) {
             }
             auto add = [&](const double*& field, const Csr& m) {
                 const size_t o = carve(8 * (size_t)m.nr * m.nc);
-                dense.push_back(DenseEntry{m.rp, m.ci, m.va, m.nr, m.nc, (unsigned)(o - stage)});
+                dense.push_back(DenseEntry{m.rp, m.ci, m.va, m.nr, m.nc, (unsigned)(o - stage), 0});
                 set_off(field, o);
             };
             add(T.dA, lv.A);
@@ -1066,7 +1092,10 @@ void amg_prepare_levels(ipd_amg* h) {
         for (int k = k_from; k <= h->J; ++k) {     // work vectors: carved, not copied
             SolveLevel& T = sd->L[k];
             // (one-wave levels: zero-padded to whole 8-entry blocks, see sol_load_image)
-            const size_t N = k >= sd->k_tiny ? r8((size_t)T.lv.N) : (size_t)T.lv.N;
+            // (dense thread-per-row levels: zero-padded to whole groups of four entries per lane, dense_row_dot)
+            const size_t N = k >= sd->k_tiny ? r8((size_t)T.lv.N)
+                             : T.blk_dense   ? (size_t)bdense_pad(T.lv.N)
+                                             : (size_t)T.lv.N;
             set_off(T.lv.r, carve(N * 8));
             set_off(T.e, carve(N * 8));
             set_off(T.e2, carve(N * 8));
