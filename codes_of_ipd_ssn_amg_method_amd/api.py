@@ -268,6 +268,13 @@ class AMGHierarchy:
     def level_sizes(self):
         return [self.level_dims(k)[0] for k in range(1, self.J + 1)]
 
+    def level_forms(self):
+        """forms[k - 1] for level k = 1..J: bit mask of how the level runs inside the single-workgroup
+        LDS images (include/ipd_amg.h, ipd_amg_level_forms); 0 = in no image."""
+        buf = (c_int32 * (self.J + 1))()
+        check(lib.ipd_amg_level_forms(self.handle, buf, c_int32(self.J + 1)))
+        return [int(buf[k]) for k in range(1, self.J + 1)]
+
     def A(self, k: int) -> sp.csc_matrix:
         out = L.ipd_csc_out()
         check(lib.ipd_amg_get_A(self.handle, c_int(k), byref(out)))

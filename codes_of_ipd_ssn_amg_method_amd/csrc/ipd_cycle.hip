@@ -906,6 +906,13 @@ struct SolveLevel {
     // full): the image carries the dense copy dA instead of the CSR arrays, and a lane keeps its part of
     // the row (columns sub, sub + Lr, ...) in registers for the visit (blk_sweeps).
     int blk_dense;
+    // Thread-per-row levels of 49..144 rows in BLOCK-WIDE polynomial form (k_bpoly_*, see bpoly_pass):
+    // the same stacked operators as pMr / pMe / pMc, [Mr | Me | Mc] one behind the other, column-major
+    // with gLD in {128, 256} rows, in GLOBAL memory (they do not fit in LDS: 200-500 KB; the tail's
+    // compute unit streams them from L2 twice per visit).  NULL: sweeps.
+    const double* gM;
+    const double* gW;
+    int gLD;
 };
 struct SolveDesc {
     int J, nu, isnsp, wcycle, anycycle, maxit;
@@ -927,6 +934,7 @@ struct SolveDesc {
     double* root_e;
     long long* dbg;   // optional: wall_clock64 stamps (100 MHz) of k_subcycle's stages
     int stage_bytes;  // size of the gather staging area at the start of dynamic LDS
+    double* bp_part;  // LDS: 8 x gLD partial sums + 8 (block-wide polynomial passes)
     double retol;
     PcgArgs pcg;
     SolveLevel L[SOLVE_ML + 1];
@@ -1043,6 +1051,9 @@ struct LdsLevel {
     AS3 const unsigned* lmap;
     bool mapped;
     bool bdense;
+    const double* gM;   // block-wide polynomial form (global memory); NULL: sweeps
+    const double* gW;
+    int gLD;
     double xx;
     // semi-cached level: a 1024-row level does not fit in LDS beside the deeper ones, but its
     // rows are short (3-7 entries) and L2-resident; only r, e, e2 live in LDS
@@ -1097,6 +1108,9 @@ __device__ __forceinline__ LdsLevel lds_level(const SolveCtx& c, int k) {
     L.lmap = as_lds(G.lmap);
     L.mapped = G.lmap != nullptr;
     L.bdense = G.blk_dense != 0;
+    L.gM = G.gM;
+    L.gW = G.gW;
+    L.gLD = G.gLD;
     L.semi = (k == D->k_semi);
     L.grp = G.lv.rp;
     L.gci = G.lv.ci;
@@ -1852,6 +1866,110 @@ __device__ __forceinline__ double dense_row_dot(const DenseRow& R, int N, int su
     return bdense_lanes(N) == 4 ? dense_row_dot_t<4>(R, N, sub, x) : dense_row_dot_t<8>(R, N, sub, x);
 }
 
+// ---- block-wide polynomial form ----------------------------------------------------------------
+// A visit of a 49..144-row level as ten sweeps, a residual, a restriction and a prolongation is ~13 us
+// of barriers and short row walks (a sweep is ~1 us whatever the row count).  In polynomial form
+// (SolveLevel::gM) it is two passes y = [Mr | Me | Mc] [r; e; e_c] + W (1'r) like the one-wave levels',
+// executed by the whole block: wave w takes the columns 8 b + w, lane l the rows 2 l, 2 l + 1 (and
+// 128 + those), i.e. one 16-byte load per column from L2 -- U of them in flight per lane --, the
+// eight waves' partial sums meet in LDS.  x is read as a wave-uniform broadcast.
+template <int HALVES>
+__device__ __forceinline__ void bpoly_pass_t(SolveCtx& c, int k, const double* __restrict__ M,
+                                             const double* __restrict__ W, int rows, int nb0,
+                                             AS3 const double* x0, int nb1, AS3 const double* x1, int nb2,
+                                             AS3 const double* x2, bool pre, AS3 double* outA, int nA,
+                                             AS3 double* outB) {
+    constexpr int LD = 128 * HALVES, U = HALVES == 1 ? 16 : 8;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    AS3 double* part = as_lds(c.D->bp_part);
+    const bool a0 = 2 * l < rows, a1 = HALVES > 1 && 128 + 2 * l < rows;
+    const int nbt = (c.D->dbg_skip & 1) ? 0 : nb0 + nb1 + nb2;
+    const double wv = t < rows ? W[t] : 0.0;
+    const double* col = M + (size_t)w * LD + 2 * l;   // column 8 b + w starts at col + b * 8 * LD
+    double y00 = 0.0, y01 = 0.0, y10 = 0.0, y11 = 0.0, sx = 0.0;
+    for (int b0 = 0; b0 < nbt; b0 += U) {
+        double2 m0[U], m1[U];
+        double xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u;
+            const bool in = b < nbt;   // uniform
+            const int bb = in ? b : 0;
+            AS3 const double* xs = bb < nb0 ? x0 + 8 * bb : (bb < nb0 + nb1 ? x1 + 8 * (bb - nb0) : x2 + 8 * (bb - nb0 - nb1));
+            xv[u] = in ? xs[w] : 0.0;
+            const double* p = col + (size_t)bb * 8 * LD;
+            m0[u] = (in && a0) ? *reinterpret_cast<const double2*>(p) : make_double2(0.0, 0.0);
+            if (HALVES > 1) m1[u] = (in && a1) ? *reinterpret_cast<const double2*>(p + 128) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            y00 = __builtin_fma(m0[u].x, xv[u], y00);
+            y01 = __builtin_fma(m0[u].y, xv[u], y01);
+            if (HALVES > 1) {
+                y10 = __builtin_fma(m1[u].x, xv[u], y10);
+                y11 = __builtin_fma(m1[u].y, xv[u], y11);
+            }
+            if (pre && b0 + u < nb0) sx += xv[u];
+        }
+    }
+    part[w * LD + 2 * l] = y00;
+    part[w * LD + 2 * l + 1] = y01;
+    if (HALVES > 1) {
+        part[w * LD + 128 + 2 * l] = y10;
+        part[w * LD + 128 + 2 * l + 1] = y11;
+    }
+    if (pre && l == 0) part[8 * LD + w] = sx;
+    __syncthreads();
+    double sumr;
+    if (pre) {
+        sumr = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) sumr += part[8 * LD + g];
+        if (t == 0) as_lds(c.sumr)[k] = sumr;   // 1'r of this visit: the post-smoothing pass needs it again
+    } else {
+        sumr = as_lds(c.sumr)[k];
+    }
+    if (t < rows) {
+        double y = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) y += part[g * LD + t];
+        y = __builtin_fma(wv, sumr, y);
+        if (t < nA)
+            outA[t] = y;
+        else
+            outB[t - nA] = y;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void bpoly_pass(SolveCtx& c, int k, const LdsLevel& L, int rows, int nb0,
+                                           AS3 const double* x0, int nb1, AS3 const double* x1, int nb2,
+                                           AS3 const double* x2, bool pre, AS3 double* outA, int nA,
+                                           AS3 double* outB) {
+    if (L.gLD == 128)
+        bpoly_pass_t<1>(c, k, L.gM, L.gW, rows, nb0, x0, nb1, x1, nb2, x2, pre, outA, nA, outB);
+    else
+        bpoly_pass_t<2>(c, k, L.gM, L.gW, rows, nb0, x0, nb1, x1, nb2, x2, pre, outA, nA, outB);
+}
+// pre-smoothing, residual and restriction: [e2; r_c] <- Mr r (+ Me e when the visit starts from an iterate)
+__device__ __forceinline__ void bpoly_pre(SolveCtx& c, int k, LdsLevel& L, bool keep) {
+    const int N = L.N, nb = (N + 7) >> 3;
+    bpoly_pass(c, k, L, N + L.Nc, nb, L.r, keep ? nb : 0, L.e, 0, L.e, true, L.e2, N, L.rc);
+    AS3 double* tt = L.e;
+    L.e = L.e2;
+    L.e2 = tt;
+    c.swapmask ^= (1u << k);
+    c.zeromask &= ~(1u << k);
+}
+// prolongation + post-smoothing: e2 <- M2a r + M1 e + (M1 P) e_c
+__device__ __forceinline__ void bpoly_post(SolveCtx& c, int k, LdsLevel& L, AS3 const double* ec) {
+    const int N = L.N, nb = (N + 7) >> 3;
+    bpoly_pass(c, k, L, N, nb, L.r, nb, L.e, (L.Nc + 7) >> 3, ec, false, L.e2, N, L.e2);
+    AS3 double* tt = L.e;
+    L.e = L.e2;
+    L.e2 = tt;
+    c.swapmask ^= (1u << k);
+}
+
 __device__ __forceinline__ double blk_total(AS3 const double* part) {
     double s = 0.0;
 #pragma unroll
@@ -2015,6 +2133,15 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
                 continue;
             }
             LdsLevel L = lds_level(c, k);
+            if (L.gM) {   // block-wide polynomial form: sweeps, residual and restriction in one pass
+                SOL_DBG_T0(c);
+                bpoly_pre(c, k, L, keep);
+                SOL_DBG_ADD(c, 5);
+                visited &= ~(1u << (k + 1));
+                k = k + 1;
+                keep = false;
+                continue;
+            }
             const bool valid = i < L.N;
             if (!keep) {
                 c.zeromask |= (1u << k);
@@ -2086,6 +2213,14 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
                 continue;
             }
             LdsLevel L = lds_level(c, k);
+            if (L.gM) {   // prolongation and post-smoothing in one pass
+                SOL_DBG_T0(c);
+                bpoly_post(c, k, L, lds_e(c, k + 1));
+                SOL_DBG_ADD(c, 5);
+                if (k == k0) return;
+                k = k - 1;
+                continue;
+            }
             SOL_DBG_T0(c);
             {
                 const int Lr = lanes_per_row(L.N), row = i / Lr, sub = i % Lr;
@@ -2465,6 +2600,134 @@ __global__ __launch_bounds__(BT) void k_pack_poly(const PolyEntry* __restrict__ 
         }
         W[row] = v;
     }
+}
+
+// Block-wide polynomial form of a 49..144-row level (SolveLevel::gM): the recurrences of k_pack_poly
+// with the N x N operands in global scratch -- one launch for S and the state after the first sweep,
+// one per further sweep (every element of the next M1, M2a, w is an independent dot product; the
+// results ping-pong between two buffers), one for the stacked output.
+struct BPolyEntry {
+    const int* Arp;
+    const int* Aci;
+    const double* Ava;
+    const int* Prp;
+    const int* Pci;
+    const double* Pva;
+    const double* dinv;
+    const double* Axi;
+    const double* xx;
+    int N, Nc, nu, isnsp, LD;
+    double* A;    // N x N, column-major like everything here
+    double* S;
+    double* P;    // N x Nc
+    double* T1;   // Nc x N = P'A
+    double* M1[2];
+    double* M2[2];
+    double* w[2];
+    double* dv;
+    double* u;
+    double* M;    // out: [Mr | Me | Mc], LD rows, 8-padded column counts
+    double* W;    // out: LD
+};
+__global__ __launch_bounds__(BT) void k_bpoly_init(const BPolyEntry e) {
+    __shared__ double cs[256];
+    const int N = e.N, Nc = e.Nc, t = threadIdx.x;
+    for (int i = t; i < N * N; i += BT) e.A[i] = 0.0;
+    for (int i = t; i < N * Nc; i += BT) e.P[i] = 0.0;
+    __syncthreads();
+    for (int r = t; r < N; r += BT) {
+        for (int q = e.Arp[r]; q < e.Arp[r + 1]; ++q) e.A[r + e.Aci[q] * N] = e.Ava[q];
+        for (int q = e.Prp[r]; q < e.Prp[r + 1]; ++q) e.P[r + e.Pci[q] * N] = e.Pva[q];
+        const double d = e.dinv[r];
+        e.dv[r] = d;
+        const double ui = e.isnsp ? (1.0 - d * e.Axi[r]) / e.xx[0] : 0.0;
+        e.u[r] = ui;
+        e.w[0][r] = ui;
+    }
+    __syncthreads();
+    for (int j = t; j < N; j += BT) {
+        double s = 0.0;
+        for (int k = 0; k < N; ++k) s += e.A[k + j * N];
+        cs[j] = s;
+    }
+    __syncthreads();
+    // S = I - Rg A,  (Rg A)[i][j] = dinv_i A[i][j] + u_i (1'A)_j ;  after one sweep: M1 = S, M2a = D^-1, w = u
+    for (int q = t; q < N * N; q += BT) {
+        const int i = q % N, j = q / N;
+        const double sv = (i == j ? 1.0 : 0.0) - (e.dv[i] * e.A[q] + e.u[i] * cs[j]);
+        e.S[q] = sv;
+        e.M1[0][q] = sv;
+        e.M2[0][q] = i == j ? e.dv[i] : 0.0;
+    }
+    for (int q = t; q < Nc * N; q += BT) {   // T1 = P'A
+        const int c = q % Nc, j = q / Nc;
+        double acc = 0.0;
+        for (int k = 0; k < N; ++k) acc += e.P[k + c * N] * e.A[k + j * N];
+        e.T1[q] = acc;
+    }
+}
+// M2a <- D^-1 + S M2a ;  M1 <- S M1 ;  w <- u + S w      (src -> dst)
+__global__ __launch_bounds__(256) void k_bpoly_step(const BPolyEntry e, int src) {
+    const int N = e.N, q = blockIdx.x * 256 + threadIdx.x, dst = src ^ 1;
+    if (q >= 2 * N * N + N) return;
+    if (q >= 2 * N * N) {
+        const int i = q - 2 * N * N;
+        const double* w = e.w[src];
+        double acc = 0.0;
+        for (int k = 0; k < N; ++k) acc += e.S[i + k * N] * w[k];
+        e.w[dst][i] = e.u[i] + acc;
+        return;
+    }
+    const bool second = q >= N * N;
+    const int qq = second ? q - N * N : q;
+    const int i = qq % N, j = qq / N;
+    const double* B = second ? e.M1[src] : e.M2[src];
+    double acc = 0.0;
+    for (int k = 0; k < N; ++k) acc += e.S[i + k * N] * B[k + j * N];
+    if (second)
+        e.M1[dst][qq] = acc;
+    else
+        e.M2[dst][qq] = acc + (i == j ? e.dv[i] : 0.0);
+}
+__global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int fin) {
+    const int N = e.N, Nc = e.Nc, R = N + Nc, LD = e.LD;
+    const int N8 = (N + 7) / 8 * 8, Nc8 = (Nc + 7) / 8 * 8, ncols = 2 * N8 + Nc8;
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (long long)LD * (ncols + 1)) return;
+    const int row = (int)(q % LD), col = (int)(q / LD);
+    const double* M1 = e.M1[fin];
+    const double* M2 = e.M2[fin];
+    const double* w = e.w[fin];
+    double v = 0.0;
+    if (col == ncols) {
+        if (row < N) {
+            v = w[row];
+        } else if (row < R) {
+            const int c = row - N;
+            for (int k = 0; k < N; ++k) v += e.T1[c + k * Nc] * w[k];
+            v = -v;
+        }
+        e.W[row] = v;
+        return;
+    }
+    if (col < 2 * N8) {
+        const bool me = col >= N8;
+        const int j = me ? col - N8 : col;
+        const double* B = me ? M1 : M2;
+        if (j < N && row < N) {
+            v = B[row + j * N];
+        } else if (j < N && row < R) {
+            const int c = row - N;
+            double a = 0.0;
+            for (int k = 0; k < N; ++k) a += e.T1[c + k * Nc] * B[k + j * N];
+            v = me ? -a : e.P[j + c * N] - a;
+        }
+    } else {
+        const int c = col - 2 * N8;
+        if (row < N && c < Nc)
+            for (int k = 0; k < N; ++k) v += M1[row + k * N] * e.P[k + c * N];
+    }
+    e.M[q] = v;
 }
 
 static constexpr int RELOC_MAX = 640;

@@ -43,6 +43,7 @@ struct CycleState {
     // single-workgroup sub-cycle rooted at level k_sub (0 = none), see k_subcycle
     SolveDesc* d_sub = nullptr;
     bool sub_semi_root = false;    // d_sub's root level is semi-cached (rows from L2)
+    std::vector<int> level_forms;  // per level, over all images packed: see ipd_amg_level_forms
     SolveDesc* d_sub4 = nullptr;   // image rooted at level 4 for the resident kernel's `three` mode
     size_t sub4_lds = 0;           // (packed beside d_sub when that one is rooted at level 3)
     SolveDesc* d_sub3 = nullptr;   // image rooted at level 3 for the resident kernel alone (k_sub == 0)
@@ -894,8 +895,77 @@ void amg_prepare_levels(ipd_amg* h) {
     const bool use_lmap = !(std::getenv("IPD_NO_LMAP") && std::getenv("IPD_NO_LMAP")[0] == '1') && lean_vectors;
     // small, nearly full thread-per-row levels: dense copy instead of the CSR arrays (see SolveLevel::blk_dense)
     const bool use_bdense = lean_vectors && !(std::getenv("IPD_NO_BLKDENSE") && std::getenv("IPD_NO_BLKDENSE")[0] == '1');
+    // thread-per-row levels of 49..144 rows in block-wide polynomial form (SolveLevel::gM); use_poly may
+    // still be withdrawn below, hence the reference
+    const bool use_bpoly = lean_vectors && !(std::getenv("IPD_NO_BPOLY") && std::getenv("IPD_NO_BPOLY")[0] == '1');
+    auto bpoly_ld = [&](int k) { return h->L[k].A.nr + h->L[k + 1].A.nr <= 128 ? 128 : 256; };
+    auto is_bpoly = [&](int k) {
+        if (!use_poly || !use_bpoly || k < 2 || k >= h->J || k >= tiny_lo) return false;
+        const long long N = h->L[k].A.nr, Nc = h->L[k + 1].A.nr;
+        return N > 48 && N <= 144 && N + Nc <= 256;
+    };
+    struct BPolyDev {
+        double* M = nullptr;
+        double* W = nullptr;
+        int LD = 0;
+    };
+    std::vector<BPolyDev> bpoly_dev((size_t)h->J + 2);
+    auto ensure_bpoly = [&](int k, int nu, int isnsp) -> const BPolyDev& {
+        BPolyDev& b = bpoly_dev[(size_t)k];
+        if (b.M) return b;
+        const Level& lv = h->L[k];
+        const Csr& P = h->L[k + 1].P;
+        const LevelDev& gd = st->run[(size_t)k].dev;
+        const size_t N = (size_t)lv.A.nr, Nc = (size_t)P.nc, N8 = (N + 7) / 8 * 8, Nc8 = (Nc + 7) / 8 * 8;
+        BPolyEntry e;
+        e.Arp = lv.A.rp;
+        e.Aci = lv.A.ci;
+        e.Ava = lv.A.va;
+        e.Prp = P.rp;
+        e.Pci = P.ci;
+        e.Pva = P.va;
+        e.dinv = gd.dinv;
+        e.Axi = gd.Axi;
+        e.xx = gd.xx;
+        e.N = (int)N;
+        e.Nc = (int)Nc;
+        e.nu = h->opts.smoth;
+        (void)nu;
+        e.isnsp = isnsp;
+        e.LD = bpoly_ld(k);
+        e.A = ctx->scratch->alloc<double>(N * N);
+        e.S = ctx->scratch->alloc<double>(N * N);
+        e.P = ctx->scratch->alloc<double>(N * Nc);
+        e.T1 = ctx->scratch->alloc<double>(N * Nc);
+        for (int i = 0; i < 2; ++i) {
+            e.M1[i] = ctx->scratch->alloc<double>(N * N);
+            e.M2[i] = ctx->scratch->alloc<double>(N * N);
+            e.w[i] = ctx->scratch->alloc<double>(N);
+        }
+        e.dv = ctx->scratch->alloc<double>(N);
+        e.u = ctx->scratch->alloc<double>(N);
+        const size_t ncols = 2 * N8 + Nc8;
+        b.LD = e.LD;
+        b.M = ar.alloc<double>((size_t)e.LD * ncols);
+        b.W = ar.alloc<double>((size_t)e.LD);
+        e.M = b.M;
+        e.W = b.W;
+        hipLaunchKernelGGL(k_bpoly_init, dim3(1), dim3(BT), 0, ctx->stream, e);
+        IPD_KERNEL_CHECK();
+        int cur = 0;
+        for (int s = 1; s < e.nu; ++s) {
+            hipLaunchKernelGGL(k_bpoly_step, dim3((unsigned)((2 * N * N + N + 255) / 256)), dim3(256), 0, ctx->stream,
+                               e, cur);
+            IPD_KERNEL_CHECK();
+            cur ^= 1;
+        }
+        hipLaunchKernelGGL(k_bpoly_final, dim3((unsigned)(((size_t)e.LD * (ncols + 1) + 255) / 256)), dim3(256), 0,
+                           ctx->stream, e, cur);
+        IPD_KERNEL_CHECK();
+        return b;
+    };
     auto is_bdense = [&](int k) {
-        if (!use_bdense || k < 2 || k >= h->J || k >= tiny_lo) return false;
+        if (!use_bdense || k < 2 || k >= h->J || k >= tiny_lo || is_bpoly(k)) return false;
         const long long N = h->L[k].A.nr;
         return N > 32 && N <= 96 && bdense_pad((int)N) / bdense_lanes((int)N) <= BDENSE_Q &&
                3LL * h->L[k].A.nnz >= N * N;
@@ -914,6 +984,10 @@ void amg_prepare_levels(ipd_amg* h) {
                 // vectors; none of the level's CSR arrays (its parent applies the transfers to and from it)
                 const size_t Nc = (size_t)h->L[k + 1].A.nr, LD = poly_ld(N + Nc);
                 bytes = 2 * (8 * LD * r8(N)) + 8 * LD * r8(Nc) + 8 * LD + 3 * r16(8 * r8(N)) + 32;
+            } else if (is_bpoly(k)) {
+                // block-wide polynomial form: the operators stay in global memory; three vectors and the
+                // partial sums of a pass
+                bytes = 3 * r16(8 * r8(N)) + 48 + 8 * (8 * (size_t)bpoly_ld(k) + 8);
             } else {
                 bytes = r16(4 * (N + 1)) +
                         (is_bdense(k) ? r16(8 * N * (size_t)bdense_ld((int)N))
@@ -927,6 +1001,7 @@ void amg_prepare_levels(ipd_amg* h) {
                 }
                 if (k == h->J) bytes += r16(4 * 8 * N);
                 if (use_lmap && !is_bdense(k) && k >= 2 && k < tiny_lo && N <= (size_t)BT) bytes += r16(4 * (BT + 1));   // lane map
+                if (k >= 3 && is_bpoly(k - 1)) bytes += 5 * 64;   // its vectors are padded to whole 8-entry blocks
                 if (k >= tiny_lo) {   // dense copies of the tiny levels
                     bytes += r16(8 * N * N);
                     if (k < h->J) bytes += 2 * r16(8 * N * (size_t)h->L[k + 1].A.nr);
@@ -982,6 +1057,7 @@ void amg_prepare_levels(ipd_amg* h) {
             packs.push_back(PackEntry{(const void*)field, (unsigned)(o - stage), (unsigned)(n * sizeof(E))});
             set_off(field, o);
         };
+        int bp_ld_max = 0;
         for (int k = k_from; k <= h->J; ++k) {     // constants first: they form the image
             SolveLevel& T = sd->L[k];
             const size_t N = (size_t)T.lv.N;
@@ -992,6 +1068,19 @@ void amg_prepare_levels(ipd_amg* h) {
                 T.lv.va = T.lv.dinv = T.lv.Axi = nullptr;
                 T.rest.rp = T.rest.ci = T.prol.rp = T.prol.ci = nullptr;
                 T.rest.va = T.prol.va = nullptr;
+                continue;
+            }
+            if (is_bpoly(k) && sd->k_blk <= k && k < sd->k_tiny) {   // block-wide polynomial form (see plan_lds)
+                put(T.lv.xx, 1);
+                T.lv.rp = T.lv.ci = nullptr;
+                T.lv.va = T.lv.dinv = T.lv.Axi = nullptr;
+                T.rest.rp = T.rest.ci = T.prol.rp = T.prol.ci = nullptr;
+                T.rest.va = T.prol.va = nullptr;
+                const BPolyDev& b = ensure_bpoly(k, sd->nu, sd->isnsp);
+                T.gM = b.M;
+                T.gW = b.W;
+                T.gLD = b.LD;
+                bp_ld_max = std::max(bp_ld_max, b.LD);
                 continue;
             }
             put(T.lv.rp, N + 1);
@@ -1018,7 +1107,7 @@ void amg_prepare_levels(ipd_amg* h) {
         }
         std::vector<LmapEntry> lmaps;
         for (int k = std::max(k_from, sd->k_blk); k < std::min(sd->k_tiny, h->J + 1); ++k) {
-            if (!use_lmap || k == sd->k_semi || k < 2 || h->L[k].A.nr > BT || k == h->J || sd->L[k].blk_dense) continue;
+            if (!use_lmap || k == sd->k_semi || k < 2 || h->L[k].A.nr > BT || k == h->J || sd->L[k].blk_dense || sd->L[k].gM) continue;
             SolveLevel& T = sd->L[k];
             const size_t o = carve(4 * (BT + 1));
             lmaps.push_back(LmapEntry{h->L[k].A.rp, h->L[k].A.nr, (unsigned)(o - stage)});
@@ -1093,9 +1182,9 @@ void amg_prepare_levels(ipd_amg* h) {
             SolveLevel& T = sd->L[k];
             // (one-wave levels: zero-padded to whole 8-entry blocks, see sol_load_image)
             // (dense thread-per-row levels: zero-padded to whole groups of four entries per lane, dense_row_dot)
-            const size_t N = k >= sd->k_tiny ? r8((size_t)T.lv.N)
-                             : T.blk_dense   ? (size_t)bdense_pad(T.lv.N)
-                                             : (size_t)T.lv.N;
+            // (block-wide polynomial levels and their children: whole 8-entry blocks as well, bpoly_pass)
+            const bool pad8 = k >= sd->k_tiny || T.gM || (k > k_from && sd->L[k - 1].gM);
+            const size_t N = T.blk_dense ? (size_t)bdense_pad(T.lv.N) : pad8 ? r8((size_t)T.lv.N) : (size_t)T.lv.N;
             set_off(T.lv.r, carve(N * 8));
             set_off(T.e, carve(N * 8));
             set_off(T.e2, carve(N * 8));
@@ -1109,6 +1198,7 @@ void amg_prepare_levels(ipd_amg* h) {
                 set_off(T.w, carve(N * 8));
             }
         }
+        if (bp_ld_max) set_off(sd->bp_part, carve(8 * (8 * (size_t)bp_ld_max + 8)));
         for (int k = std::max(1, k_from - 1); k < h->J; ++k) {   // vectors that cross levels
             SolveLevel& T = sd->L[k];
             if (k >= k_from) {
@@ -1165,6 +1255,12 @@ void amg_prepare_levels(ipd_amg* h) {
             hipLaunchKernelGGL(k_pack_poly, dim3((unsigned)polys.size()), dim3(BT), poly_lds, ctx->stream,
                                (const PolyEntry*)pp, img);
             IPD_KERNEL_CHECK();
+        }
+        st->level_forms.resize((size_t)h->J + 1, 0);
+        for (int k = std::max(k_from, sd->k_blk); k <= h->J; ++k) {
+            const SolveLevel& T = sd->L[k];
+            if (k == sd->k_semi) continue;
+            st->level_forms[(size_t)k] |= T.gM ? 16 : T.pMr ? 8 : k >= sd->k_tiny ? 4 : T.blk_dense ? 2 : 1;
         }
         return reinterpret_cast<SolveDesc*>(img);
     };
@@ -2353,6 +2449,18 @@ extern "C" int ipd_amg_resident_levels(const ipd_amg* h, int32_t* levels, int32_
         const bool on = st && st->res_ok;
         if (levels) *levels = on ? (st->res_ke3 > 0 ? 3 : 2) : 0;
         if (tail_root) *tail_root = on ? (st->res_ke3 > 0 ? 4 : 3) : 0;
+    });
+}
+
+// How the levels held in the LDS images of this hierarchy run (bit mask over all images packed):
+// 1 thread-per-row sweeps, 2 the same with dense rows in registers, 4 one-wave sweeps, 8 one-wave
+// polynomial form, 16 block-wide polynomial form; 0: the level is in no image.
+extern "C" int ipd_amg_level_forms(const ipd_amg* h, int32_t* forms, int32_t count) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && forms && count >= 0, IPD_E_ARG, "bad argument");
+        const CycleState* st = h->cyc.get();
+        for (int k = 0; k < count; ++k)
+            forms[k] = (st && (size_t)k < st->level_forms.size()) ? st->level_forms[(size_t)k] : 0;
     });
 }
 

@@ -415,6 +415,12 @@ int ipd_amg_solve_mode(const ipd_amg* h, int32_t* mode, int32_t* grid, int32_t* 
 /* Mode 2 only: *levels = levels kept in the registers of the resident workgroups (2 or 3),
  * *tail_root = level at which the rest starts (3, or 4 below a resident level 3); zeros otherwise. */
 int ipd_amg_resident_levels(const ipd_amg* h, int32_t* levels, int32_t* tail_root);
+/* forms[k], k < count (level k = 1..J; forms[0] = 0): how level k runs where it is held in a single
+ * workgroup's LDS image (bit mask over the images packed for this hierarchy): 1 thread-per-row sweeps,
+ * 2 the same with dense rows in registers, 4 one-wave sweeps, 8 one-wave polynomial form (the nu sweeps,
+ * residual and transfers of a visit as two dense passes), 16 block-wide polynomial form (49..144 rows,
+ * operators streamed from L2); 0: in no image (launches or the resident workgroups' registers).      */
+int ipd_amg_level_forms(const ipd_amg* h, int32_t* forms, int32_t count);
 /* Mode 2 only: `cycles` loop bodies in one launch with in-kernel stamps of workgroup 0:
  * stamps[0] shader clocks spent waiting in hand-off sweeps, [1] shader clocks of the launch,
  * [2] hand-offs, [3] 100 MHz ticks of the launch, [4] clocks in the barrier ahead of the

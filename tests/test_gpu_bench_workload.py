@@ -262,24 +262,29 @@ def test_resident_matches_multilaunch(ipd, m, n, rho, isnsp, cycle):
     assert itz == 0 and relkz[0] == 0.0 and np.isinf(rhokz[0]) and not xz.any()
 
 
+@pytest.mark.parametrize("bpoly", [False, True])
 @pytest.mark.parametrize("cycle", ["v", "w"])
-def test_tree_mask_three_resident_levels_with_a_local_tail(ipd, cycle):
+def test_tree_mask_three_resident_levels_with_a_local_tail(ipd, cycle, bpoly):
     """bench.py --mask tree (levels 2048 / 1024 / 141 / 5, level 3 a dense 141 x 141 block that fits no LDS
-    image): levels 1-3 in the resident workgroups' registers, the 5-row coarsest level solved by every
-    workgroup (no tail workgroup), against the multi-launch path."""
+    image as rows): IPD_NO_BPOLY=1 -- levels 1-3 in the resident workgroups' registers, the 5-row coarsest
+    level solved by every workgroup (no tail workgroup); default -- level 3 in block-wide polynomial form
+    (its operators streamed from L2), so an image rooted at level 3 exists and the tail workgroup takes it.
+    Both against the multi-launch path (which runs level 3 as sweeps: IPD_NO_RESIDENT=1 hierarchy built
+    with the polynomial form off)."""
     from codes_of_ipd_ssn_amg_method_amd import _lib
     m = n = 1024
     s = bench.build_mask(m, n, "tree", 1.0)
     Ae, f, guess, H0 = bench.build_newton_system(ipd, m, n, s)
     opts = options(cycle, n)
-    h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
-    with env(IPD_NO_RESIDENT=1):
+    with env(IPD_NO_BPOLY=0 if bpoly else 1):
+        h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    with env(IPD_NO_RESIDENT=1, IPD_NO_BPOLY=1):
         hc = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
     assert h.level_sizes() == hc.level_sizes() and h.J == 4
     mode, grid, _ = solve_mode(h)
     lev, root = c_int32(), c_int32()
     _lib.check(_lib.lib.ipd_amg_resident_levels(h.handle, byref(lev), byref(root)))
-    assert (mode, grid, lev.value) == (2, 128, 3), (mode, grid, lev.value)
+    assert (mode, grid, lev.value) == ((2, 129, 2) if bpoly else (2, 128, 3)), (mode, grid, lev.value)
     x, it, rel, relk, rhok = h.solve(f, guess)
     assert solve_mode(h)[2] == 0
     xc, itc, relc, relkc, rhokc = hc.solve(f, guess)

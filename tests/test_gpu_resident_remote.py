@@ -133,6 +133,7 @@ def _against_oracle(ipd, Ae, f, n, cycle, x0, expect_mode=None, kv=None):
     sens = float(np.max(np.abs(np.asarray(relko[:kk]) - np.asarray(relkp[:kk]))))
     same_history(it, np.asarray(relk), ito, np.asarray(relko), tol=max(1e-10, 8.0 * sens))
     assert np.linalg.norm(Ae @ (x - xo)) <= 1e-9 * np.linalg.norm(f)
+    _against_oracle.forms = h.level_forms()
     h.close()
     return it, ito, relk, relko
 
@@ -149,8 +150,14 @@ def test_realistic_modes_against_the_oracle(ipd, newton_system, cycle):
     if got is None:
         pytest.skip("hierarchy not taken by the resident kernel")
     it, ito, relk, relko = got
+    # level 4 of these systems (60-110 rows) runs in block-wide polynomial form inside the tail's image
+    assert _against_oracle.forms[3] & 16, _against_oracle.forms
     # these systems take several informative cycles (contraction ~0.1-0.3 per cycle), unlike rho = 1
     assert it >= 4 and np.sum(np.asarray(relko[:ito + 1]) > 1e-9) >= 4, relko
+    assert _against_oracle(ipd, Ae, f, n, cycle, x0, kv=dict(IPD_NO_BPOLY=1)) is not None
+    assert not any(v & 16 for v in _against_oracle.forms), _against_oracle.forms
+    assert _against_oracle(ipd, Ae, f, n, cycle, x0, kv=dict(IPD_NO_BPOLY=1, IPD_NO_BLKDENSE=1)) is not None
+    assert not any(v & 2 for v in _against_oracle.forms), _against_oracle.forms
     assert _against_oracle(ipd, Ae, f, n, cycle, x0, kv=dict(IPD_NO_RESIDENT=1)) is not None
     assert _against_oracle(ipd, Ae, f, n, cycle, x0, kv=dict(IPD_NO_RESIDENT=1, IPD_NO_RRC=1)) is not None
     assert _against_oracle(ipd, Ae, f, n, cycle, x0, kv=dict(IPD_NO_RESIDENT_THREE=1)) is not None
