@@ -1874,42 +1874,57 @@ __device__ __forceinline__ double dense_row_dot(const DenseRow& R, int N, int su
 // 128 + those), i.e. one 16-byte load per column from L2 -- U of them in flight per lane --, the
 // eight waves' partial sums meet in LDS.  x is read as a wave-uniform broadcast.
 template <int HALVES>
-__device__ __forceinline__ void bpoly_pass_t(SolveCtx& c, int k, const double* __restrict__ M,
-                                             const double* __restrict__ W, int rows, int nb0,
+__device__ __forceinline__ void bpoly_pass_t(SolveCtx& c, int k, const double* __restrict__ Mgen,
+                                             const double* __restrict__ Wgen, int rows, int nb0,
                                              AS3 const double* x0, int nb1, AS3 const double* x1, int nb2,
                                              AS3 const double* x2, bool pre, AS3 double* outA, int nA,
                                              AS3 double* outB) {
-    constexpr int LD = 128 * HALVES, U = HALVES == 1 ? 16 : 8;
-    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    typedef const __attribute__((address_space(1))) double* gptr;
+    typedef __attribute__((ext_vector_type(2))) double d2;
+    typedef const __attribute__((address_space(1))) d2* gptr2;
+    constexpr int LD = 128 * HALVES, U = HALVES == 1 ? 12 : 8;
+    const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     AS3 double* part = as_lds(c.D->bp_part);
     const bool a0 = 2 * l < rows, a1 = HALVES > 1 && 128 + 2 * l < rows;
     const int nbt = (c.D->dbg_skip & 1) ? 0 : nb0 + nb1 + nb2;
+    gptr W = (gptr)Wgen;
     const double wv = t < rows ? W[t] : 0.0;
-    const double* col = M + (size_t)w * LD + 2 * l;   // column 8 b + w starts at col + b * 8 * LD
-    double y00 = 0.0, y01 = 0.0, y10 = 0.0, y11 = 0.0, sx = 0.0;
-    for (int b0 = 0; b0 < nbt; b0 += U) {
-        double2 m0[U], m1[U];
-        double xv[U];
+    // lane j holds x of this wave's j-th column (8 j + w of the concatenated [x0; x1; x2]): the loop
+    // below reads it back as a scalar -- no branch on the segment, and 1'x0 is one wave sum
+    double xl = 0.0;
+    if (l < nbt) {
+        AS3 const double* xs = l < nb0 ? x0 + 8 * l : (l < nb0 + nb1 ? x1 + 8 * (l - nb0) : x2 + 8 * (l - nb0 - nb1));
+        xl = xs[w];
+    }
+    const double sx = pre ? wave_sum(l < nb0 ? xl : 0.0) : 0.0;
+    const int xlo = __double2loint(xl), xhi = __double2hiint(xl);
+    gptr col = (gptr)Mgen + (size_t)w * LD;   // uniform; column 8 b + w starts at col + b * 8 * LD
+    double y00 = 0.0, y01 = 0.0, y10 = 0.0, y11 = 0.0;
+    if (a0) {
+        for (int b0 = 0; b0 < nbt; b0 += U) {
+            d2 m0[U], m1[U];
+            double xv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int b = b0 + u;
-            const bool in = b < nbt;   // uniform
-            const int bb = in ? b : 0;
-            AS3 const double* xs = bb < nb0 ? x0 + 8 * bb : (bb < nb0 + nb1 ? x1 + 8 * (bb - nb0) : x2 + 8 * (bb - nb0 - nb1));
-            xv[u] = in ? xs[w] : 0.0;
-            const double* p = col + (size_t)bb * 8 * LD;
-            m0[u] = (in && a0) ? *reinterpret_cast<const double2*>(p) : make_double2(0.0, 0.0);
-            if (HALVES > 1) m1[u] = (in && a1) ? *reinterpret_cast<const double2*>(p + 128) : make_double2(0.0, 0.0);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            y00 = __builtin_fma(m0[u].x, xv[u], y00);
-            y01 = __builtin_fma(m0[u].y, xv[u], y01);
-            if (HALVES > 1) {
-                y10 = __builtin_fma(m1[u].x, xv[u], y10);
-                y11 = __builtin_fma(m1[u].y, xv[u], y11);
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + u < nbt ? b0 + u : nbt - 1;   // uniform (the surplus of the last batch: x = 0)
+                const double x = __hiloint2double(__builtin_amdgcn_readlane(xhi, b), __builtin_amdgcn_readlane(xlo, b));
+                xv[u] = b0 + u < nbt ? x : 0.0;
+                gptr p = col + (size_t)b * (8 * LD);
+                m0[u] = *reinterpret_cast<gptr2>(p + 2 * l);
+                if (HALVES > 1) {
+                    m1[u] = (d2)(0.0, 0.0);
+                    if (a1) m1[u] = *reinterpret_cast<gptr2>(p + 128 + 2 * l);
+                }
             }
-            if (pre && b0 + u < nb0) sx += xv[u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                y00 = __builtin_fma(m0[u].x, xv[u], y00);
+                y01 = __builtin_fma(m0[u].y, xv[u], y01);
+                if (HALVES > 1) {
+                    y10 = __builtin_fma(m1[u].x, xv[u], y10);
+                    y11 = __builtin_fma(m1[u].y, xv[u], y11);
+                }
+            }
         }
     }
     part[w * LD + 2 * l] = y00;
@@ -1941,11 +1956,72 @@ __device__ __forceinline__ void bpoly_pass_t(SolveCtx& c, int k, const double* _
     }
     __syncthreads();
 }
+// The same pass with the operators in LDS (SolveLevel::pMr ..., leading dimension 64, one row per lane):
+// levels of <= 48 rows whose stacked operator has more than 32 rows.  In ONE wave such a pass has one
+// lane per row walk ~100 columns (1.5 us, measured); eight waves take 12 columns each.
+__device__ __forceinline__ void lpoly_pass(SolveCtx& c, int k, AS3 const double* M, AS3 const double* W, int rows,
+                                           int nb0, AS3 const double* x0, int nb1, AS3 const double* x1, int nb2,
+                                           AS3 const double* x2, bool pre, AS3 double* outA, int nA,
+                                           AS3 double* outB) {
+    constexpr int LD = 64, U = 8;
+    const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    AS3 double* part = as_lds(c.D->bp_part);
+    const int nbt = (c.D->dbg_skip & 1) ? 0 : nb0 + nb1 + nb2;
+    double xl = 0.0;
+    if (l < nbt) {
+        AS3 const double* xs = l < nb0 ? x0 + 8 * l : (l < nb0 + nb1 ? x1 + 8 * (l - nb0) : x2 + 8 * (l - nb0 - nb1));
+        xl = xs[w];
+    }
+    const double sx = pre ? wave_sum(l < nb0 ? xl : 0.0) : 0.0;
+    const int xlo = __double2loint(xl), xhi = __double2hiint(xl);
+    AS3 const double* col = M + w * LD + l;   // column 8 b + w: col + b * 8 * LD (rows beyond `rows` are zeros)
+    double y0 = 0.0, y1 = 0.0;
+    for (int b0 = 0; b0 < nbt; b0 += U) {
+        double m[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u < nbt ? b0 + u : nbt - 1;   // uniform
+            const double x = __hiloint2double(__builtin_amdgcn_readlane(xhi, b), __builtin_amdgcn_readlane(xlo, b));
+            xv[u] = b0 + u < nbt ? x : 0.0;
+            m[u] = col[b * (8 * LD)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u += 2) {
+            y0 = __builtin_fma(m[u], xv[u], y0);
+            y1 = __builtin_fma(m[u + 1], xv[u + 1], y1);
+        }
+    }
+    part[w * LD + l] = y0 + y1;
+    if (pre && l == 0) part[8 * LD + w] = sx;
+    __syncthreads();
+    double sumr;
+    if (pre) {
+        sumr = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) sumr += part[8 * LD + g];
+        if (t == 0) as_lds(c.sumr)[k] = sumr;
+    } else {
+        sumr = as_lds(c.sumr)[k];
+    }
+    if (t < rows) {
+        double y = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) y += part[g * LD + t];
+        y = __builtin_fma(W[t], sumr, y);
+        if (t < nA)
+            outA[t] = y;
+        else
+            outB[t - nA] = y;
+    }
+    __syncthreads();
+}
 __device__ __forceinline__ void bpoly_pass(SolveCtx& c, int k, const LdsLevel& L, int rows, int nb0,
                                            AS3 const double* x0, int nb1, AS3 const double* x1, int nb2,
                                            AS3 const double* x2, bool pre, AS3 double* outA, int nA,
                                            AS3 double* outB) {
-    if (L.gLD == 128)
+    if (!L.gM)
+        lpoly_pass(c, k, L.pMr, L.pW, rows, nb0, x0, nb1, x1, nb2, x2, pre, outA, nA, outB);
+    else if (L.gLD == 128)
         bpoly_pass_t<1>(c, k, L.gM, L.gW, rows, nb0, x0, nb1, x1, nb2, x2, pre, outA, nA, outB);
     else
         bpoly_pass_t<2>(c, k, L.gM, L.gW, rows, nb0, x0, nb1, x1, nb2, x2, pre, outA, nA, outB);
@@ -2133,7 +2209,7 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
                 continue;
             }
             LdsLevel L = lds_level(c, k);
-            if (L.gM) {   // block-wide polynomial form: sweeps, residual and restriction in one pass
+            if (L.gM || L.poly) {   // block-wide polynomial form: sweeps, residual and restriction in one pass
                 SOL_DBG_T0(c);
                 bpoly_pre(c, k, L, keep);
                 SOL_DBG_ADD(c, 5);
@@ -2213,7 +2289,7 @@ __device__ __forceinline__ void blk_cycle(SolveCtx& c, int k0, bool keep0) {
                 continue;
             }
             LdsLevel L = lds_level(c, k);
-            if (L.gM) {   // prolongation and post-smoothing in one pass
+            if (L.gM || L.poly) {   // prolongation and post-smoothing in one pass
                 SOL_DBG_T0(c);
                 bpoly_post(c, k, L, lds_e(c, k + 1));
                 SOL_DBG_ADD(c, 5);
@@ -2602,10 +2678,12 @@ __global__ __launch_bounds__(BT) void k_pack_poly(const PolyEntry* __restrict__ 
     }
 }
 
-// Block-wide polynomial form of a 49..144-row level (SolveLevel::gM): the recurrences of k_pack_poly
-// with the N x N operands in global scratch -- one launch for S and the state after the first sweep,
-// one per further sweep (every element of the next M1, M2a, w is an independent dot product; the
-// results ping-pong between two buffers), one for the stacked output.
+// Block-wide polynomial form of a 33..144-row level (SolveLevel::gM): the recurrences of k_pack_poly
+// as dense products on the f64 matrix cores.  All operands live in global scratch, column-major, padded
+// with zeros to multiples of 16 (Np rows; no edge cases in the tiles); the state [M2a | M1 | w] is ONE
+// matrix X of 2 Np + 16 columns, so a sweep is X <- S X + [D^-1 | 0 | u].  One wave per 16 x 16 tile
+// (v_mfma_f64_16x16x4_f64: lane l holds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; result
+// register g of lane l is C[(l >> 4) + 4 g][l & 15]), the operand loads of 16 k-steps in flight.
 struct BPolyEntry {
     const int* Arp;
     const int* Aci;
@@ -2616,118 +2694,142 @@ struct BPolyEntry {
     const double* dinv;
     const double* Axi;
     const double* xx;
-    int N, Nc, nu, isnsp, LD;
-    double* A;    // N x N, column-major like everything here
-    double* S;
-    double* P;    // N x Nc
-    double* T1;   // Nc x N = P'A
-    double* M1[2];
-    double* M2[2];
-    double* w[2];
+    int N, Nc, Np, Ncp, nu, isnsp, LD;
+    double* A;    // Np x Np
+    double* S;    // Np x Np
+    double* P;    // Np x Ncp
+    double* T1;   // Ncp x Np = P'A
+    double* X[2]; // Np x (2 Np + 16): [M2a | M1 | w, 15 zero columns]
     double* dv;
     double* u;
-    double* M;    // out: [Mr | Me | Mc], LD rows, 8-padded column counts
+    double* M;    // out: [Mr | Me | Mc], LD rows, 8-padded column counts (zeroed by the host)
     double* W;    // out: LD
 };
-__global__ __launch_bounds__(BT) void k_bpoly_init(const BPolyEntry e) {
-    __shared__ double cs[256];
-    const int N = e.N, Nc = e.Nc, t = threadIdx.x;
-    for (int i = t; i < N * N; i += BT) e.A[i] = 0.0;
-    for (int i = t; i < N * Nc; i += BT) e.P[i] = 0.0;
-    __syncthreads();
-    for (int r = t; r < N; r += BT) {
-        for (int q = e.Arp[r]; q < e.Arp[r + 1]; ++q) e.A[r + e.Aci[q] * N] = e.Ava[q];
-        for (int q = e.Prp[r]; q < e.Prp[r + 1]; ++q) e.P[r + e.Pci[q] * N] = e.Pva[q];
-        const double d = e.dinv[r];
-        e.dv[r] = d;
-        const double ui = e.isnsp ? (1.0 - d * e.Axi[r]) / e.xx[0] : 0.0;
-        e.u[r] = ui;
-        e.w[0][r] = ui;
+typedef double bp_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bp_d4 bp_tile(const double* __restrict__ A, int a_is, int a_ks,
+                                         const double* __restrict__ B, int b_ks, int b_js, int K, int I0, int J0) {
+    const int l = threadIdx.x & 63, r = l & 15, q = l >> 4;
+    const double* ap = A + (size_t)(I0 + r) * a_is + (size_t)q * a_ks;
+    const double* bp = B + (size_t)q * b_ks + (size_t)(J0 + r) * b_js;
+    bp_d4 c = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        double a[16], b[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = k0 + 4 * u;
+            const bool in = k < K;   // uniform
+            a[u] = in ? ap[(size_t)k * a_ks] : 0.0;
+            b[u] = in ? bp[(size_t)k * b_ks] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (k0 + 4 * u < K) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], c, 0, 0, 0);
     }
-    __syncthreads();
-    for (int j = t; j < N; j += BT) {
-        double s = 0.0;
-        for (int k = 0; k < N; ++k) s += e.A[k + j * N];
-        cs[j] = s;
-    }
-    __syncthreads();
-    // S = I - Rg A,  (Rg A)[i][j] = dinv_i A[i][j] + u_i (1'A)_j ;  after one sweep: M1 = S, M2a = D^-1, w = u
-    for (int q = t; q < N * N; q += BT) {
+    return c;
+}
+// dense copies of A and P, D^-1, u, and the parts of the state after the first sweep that are not S:
+// M2a = D^-1, w = u
+__global__ __launch_bounds__(256) void k_bpoly_scatter(const BPolyEntry e) {
+    const int r = blockIdx.x * 256 + threadIdx.x, Np = e.Np;
+    if (r >= e.N) return;
+    for (int q = e.Arp[r]; q < e.Arp[r + 1]; ++q) e.A[r + (size_t)e.Aci[q] * Np] = e.Ava[q];
+    for (int q = e.Prp[r]; q < e.Prp[r + 1]; ++q) e.P[r + (size_t)e.Pci[q] * Np] = e.Pva[q];
+    const double d = e.dinv[r];
+    const double ui = e.isnsp ? (1.0 - d * e.Axi[r]) / e.xx[0] : 0.0;
+    e.dv[r] = d;
+    e.u[r] = ui;
+    e.X[0][r + (size_t)r * Np] = d;
+    e.X[0][r + (size_t)(2 * Np) * Np] = ui;
+}
+// S = I - Rg A with (Rg A)[i][j] = dinv_i A[i][j] + u_i (1'A)_j, also M1 = S after the first sweep
+// (blocks below nS: one thread per entry, the column sum formed by each); T1 = P'A (the tiles behind)
+__global__ __launch_bounds__(256) void k_bpoly_S_T1(const BPolyEntry e, int nS) {
+    const int N = e.N, Np = e.Np;
+    if ((int)blockIdx.x < nS) {
+        const int q = blockIdx.x * 256 + threadIdx.x;
+        if (q >= N * N) return;
         const int i = q % N, j = q / N;
-        const double sv = (i == j ? 1.0 : 0.0) - (e.dv[i] * e.A[q] + e.u[i] * cs[j]);
-        e.S[q] = sv;
-        e.M1[0][q] = sv;
-        e.M2[0][q] = i == j ? e.dv[i] : 0.0;
+        const double* aj = e.A + (size_t)j * Np;
+        double cs = 0.0;
+        for (int k = 0; k < N; ++k) cs += aj[k];
+        const double sv = (i == j ? 1.0 : 0.0) - (e.dv[i] * aj[i] + e.u[i] * cs);
+        e.S[i + (size_t)j * Np] = sv;
+        e.X[0][i + (size_t)(Np + j) * Np] = sv;
+        return;
     }
-    for (int q = t; q < Nc * N; q += BT) {   // T1 = P'A
-        const int c = q % Nc, j = q / Nc;
-        double acc = 0.0;
-        for (int k = 0; k < N; ++k) acc += e.P[k + c * N] * e.A[k + j * N];
-        e.T1[q] = acc;
-    }
+    const int tile = ((int)blockIdx.x - nS) * 4 + (threadIdx.x >> 6), nj = Np / 16, ni = e.Ncp / 16;
+    if (tile >= ni * nj) return;
+    const int I0 = 16 * (tile % ni), J0 = 16 * (tile / ni), l = threadIdx.x & 63;
+    const bp_d4 c = bp_tile(e.P, Np, 1, e.A, 1, Np, Np, I0, J0);   // A-operand (c, k) = P[k + c Np]
+    for (int g = 0; g < 4; ++g) e.T1[(I0 + (l >> 4) + 4 * g) + (size_t)(J0 + (l & 15)) * e.Ncp] = c[g];
 }
-// M2a <- D^-1 + S M2a ;  M1 <- S M1 ;  w <- u + S w      (src -> dst)
+// X[dst] = S X[src] + [D^-1 | 0 | u]
 __global__ __launch_bounds__(256) void k_bpoly_step(const BPolyEntry e, int src) {
-    const int N = e.N, q = blockIdx.x * 256 + threadIdx.x, dst = src ^ 1;
-    if (q >= 2 * N * N + N) return;
-    if (q >= 2 * N * N) {
-        const int i = q - 2 * N * N;
-        const double* w = e.w[src];
-        double acc = 0.0;
-        for (int k = 0; k < N; ++k) acc += e.S[i + k * N] * w[k];
-        e.w[dst][i] = e.u[i] + acc;
-        return;
+    const int Np = e.Np, ni = Np / 16, nj = (2 * Np + 16) / 16;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (tile >= ni * nj) return;
+    const int I0 = 16 * (tile % ni), J0 = 16 * (tile / ni);
+    const bp_d4 c = bp_tile(e.S, 1, Np, e.X[src], 1, Np, Np, I0, J0);
+    double* dst = e.X[src ^ 1];
+    const int j = J0 + (l & 15);
+    for (int g = 0; g < 4; ++g) {
+        const int i = I0 + (l >> 4) + 4 * g;
+        double v = c[g];
+        if (i < e.N) {
+            if (j == i) v += e.dv[i];
+            if (j == 2 * Np) v += e.u[i];
+        }
+        dst[i + (size_t)j * Np] = v;
     }
-    const bool second = q >= N * N;
-    const int qq = second ? q - N * N : q;
-    const int i = qq % N, j = qq / N;
-    const double* B = second ? e.M1[src] : e.M2[src];
-    double acc = 0.0;
-    for (int k = 0; k < N; ++k) acc += e.S[i + k * N] * B[k + j * N];
-    if (second)
-        e.M1[dst][qq] = acc;
-    else
-        e.M2[dst][qq] = acc + (i == j ? e.dv[i] : 0.0);
 }
-__global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int fin) {
-    const int N = e.N, Nc = e.Nc, R = N + Nc, LD = e.LD;
-    const int N8 = (N + 7) / 8 * 8, Nc8 = (Nc + 7) / 8 * 8, ncols = 2 * N8 + Nc8;
-    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= (long long)LD * (ncols + 1)) return;
-    const int row = (int)(q % LD), col = (int)(q / LD);
-    const double* M1 = e.M1[fin];
-    const double* M2 = e.M2[fin];
-    const double* w = e.w[fin];
-    double v = 0.0;
-    if (col == ncols) {
-        if (row < N) {
-            v = w[row];
-        } else if (row < R) {
-            const int c = row - N;
-            for (int k = 0; k < N; ++k) v += e.T1[c + k * Nc] * w[k];
-            v = -v;
+// the stacked output: rows below N from -T1 X (+ P' in the Mr block), Mc = M1 P, copies above
+__global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int fin, int nZ, int nC) {
+    const int N = e.N, Nc = e.Nc, Np = e.Np, Ncp = e.Ncp, LD = e.LD, l = threadIdx.x & 63;
+    const int N8 = (N + 7) / 8 * 8;
+    const double* X = e.X[fin];
+    int blk = blockIdx.x;
+    if (blk < nZ) {   // Z = T1 X: Ncp x (2 Np + 16)
+        const int ni = Ncp / 16, nj = (2 * Np + 16) / 16, tile = blk * 4 + (threadIdx.x >> 6);
+        if (tile >= ni * nj) return;
+        const int I0 = 16 * (tile % ni), J0 = 16 * (tile / ni);
+        const bp_d4 c = bp_tile(e.T1, 1, Ncp, X, 1, Np, Np, I0, J0);
+        const int j = J0 + (l & 15);
+        for (int g = 0; g < 4; ++g) {
+            const int cc = I0 + (l >> 4) + 4 * g;
+            if (cc >= Nc) continue;
+            if (j < Np) {
+                if (j < N) e.M[(N + cc) + (size_t)j * LD] = e.P[j + (size_t)cc * Np] - c[g];
+            } else if (j < 2 * Np) {
+                if (j - Np < N) e.M[(N + cc) + (size_t)(N8 + j - Np) * LD] = -c[g];
+            } else if (j == 2 * Np) {
+                e.W[N + cc] = -c[g];
+            }
         }
-        e.W[row] = v;
         return;
     }
-    if (col < 2 * N8) {
-        const bool me = col >= N8;
-        const int j = me ? col - N8 : col;
-        const double* B = me ? M1 : M2;
-        if (j < N && row < N) {
-            v = B[row + j * N];
-        } else if (j < N && row < R) {
-            const int c = row - N;
-            double a = 0.0;
-            for (int k = 0; k < N; ++k) a += e.T1[c + k * Nc] * B[k + j * N];
-            v = me ? -a : e.P[j + c * N] - a;
+    blk -= nZ;
+    if (blk < nC) {   // Mc = M1 P: Np x Ncp
+        const int ni = Np / 16, nj = Ncp / 16, tile = blk * 4 + (threadIdx.x >> 6);
+        if (tile >= ni * nj) return;
+        const int I0 = 16 * (tile % ni), J0 = 16 * (tile / ni);
+        const bp_d4 c = bp_tile(X + (size_t)Np * Np, 1, Np, e.P, 1, Np, Np, I0, J0);
+        const int j = J0 + (l & 15);
+        for (int g = 0; g < 4; ++g) {
+            const int i = I0 + (l >> 4) + 4 * g;
+            if (i < N && j < Nc) e.M[i + (size_t)(2 * N8 + j) * LD] = c[g];
         }
-    } else {
-        const int c = col - 2 * N8;
-        if (row < N && c < Nc)
-            for (int k = 0; k < N; ++k) v += M1[row + k * N] * e.P[k + c * N];
+        return;
     }
-    e.M[q] = v;
+    blk -= nC;
+    const int q = blk * 256 + threadIdx.x;   // copies: M2a, M1, w
+    if (q < N * N) {
+        const int i = q % N, j = q / N;
+        e.M[i + (size_t)j * LD] = X[i + (size_t)j * Np];
+        e.M[i + (size_t)(N8 + j) * LD] = X[i + (size_t)(Np + j) * Np];
+    } else if (q < N * N + N) {
+        const int i = q - N * N;
+        e.W[i] = X[i + (size_t)(2 * Np) * Np];
+    }
 }
 
 static constexpr int RELOC_MAX = 640;

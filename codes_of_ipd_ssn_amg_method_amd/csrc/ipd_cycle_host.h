@@ -868,6 +868,10 @@ void amg_prepare_levels(ipd_amg* h) {
     bool use_poly = h->opts.smoth >= 1 && (h->opts.cycle == 'w' || h->opts.cycle == 'v') &&
                     !(std::getenv("IPD_NO_POLY") && std::getenv("IPD_NO_POLY")[0] == '1') &&
                     !(std::getenv("IPD_NO_BLK") && std::getenv("IPD_NO_BLK")[0] == '1');
+    // (polynomial form: a level whose stacked operator [e'; r_c] has more than 32 rows -- one lane per row in
+    // a single wave -- runs block-wide instead, out of LDS all the same: is_lpoly below)
+    const bool use_lpoly = !(std::getenv("IPD_NO_LPOLY") && std::getenv("IPD_NO_LPOLY")[0] == '1') &&
+                           !(std::getenv("IPD_NO_BLK") && std::getenv("IPD_NO_BLK")[0] == '1');
     auto find_tiny_lo = [&](int rows_max) {
         int lo = h->J + 1;
         if (const char* e = std::getenv("IPD_TINY_ROWS")) rows_max = std::max(1, std::min(64, std::atoi(e)));
@@ -875,6 +879,7 @@ void amg_prepare_levels(ipd_amg* h) {
         if (!(nt && nt[0] == '1'))
             for (int k = h->J; k >= 2; --k) {
                 if (h->L[k].A.nr > rows_max) break;
+                if (rows_max > 32 && use_lpoly && k < h->J && h->L[k].A.nr + h->L[k + 1].A.nr > 32) break;
                 lo = k;
             }
         return lo;
@@ -895,14 +900,18 @@ void amg_prepare_levels(ipd_amg* h) {
     const bool use_lmap = !(std::getenv("IPD_NO_LMAP") && std::getenv("IPD_NO_LMAP")[0] == '1') && lean_vectors;
     // small, nearly full thread-per-row levels: dense copy instead of the CSR arrays (see SolveLevel::blk_dense)
     const bool use_bdense = lean_vectors && !(std::getenv("IPD_NO_BLKDENSE") && std::getenv("IPD_NO_BLKDENSE")[0] == '1');
-    // thread-per-row levels of 49..144 rows in block-wide polynomial form (SolveLevel::gM); use_poly may
+    auto is_lpoly = [&](int k) {
+        return use_poly && use_lpoly && lean_vectors && k >= 2 && k < tiny_lo && k < h->J && h->L[k].A.nr <= 48 &&
+               h->L[k].A.nr + h->L[k + 1].A.nr <= 64;
+    };
+    // thread-per-row levels of 33..144 rows in block-wide polynomial form (SolveLevel::gM); use_poly may
     // still be withdrawn below, hence the reference
     const bool use_bpoly = lean_vectors && !(std::getenv("IPD_NO_BPOLY") && std::getenv("IPD_NO_BPOLY")[0] == '1');
     auto bpoly_ld = [&](int k) { return h->L[k].A.nr + h->L[k + 1].A.nr <= 128 ? 128 : 256; };
     auto is_bpoly = [&](int k) {
         if (!use_poly || !use_bpoly || k < 2 || k >= h->J || k >= tiny_lo) return false;
         const long long N = h->L[k].A.nr, Nc = h->L[k + 1].A.nr;
-        return N > 48 && N <= 144 && N + Nc <= 256;
+        return N > 32 && N <= 144 && N + Nc <= 256 && !is_lpoly(k);
     };
     struct BPolyDev {
         double* M = nullptr;
@@ -917,6 +926,7 @@ void amg_prepare_levels(ipd_amg* h) {
         const Csr& P = h->L[k + 1].P;
         const LevelDev& gd = st->run[(size_t)k].dev;
         const size_t N = (size_t)lv.A.nr, Nc = (size_t)P.nc, N8 = (N + 7) / 8 * 8, Nc8 = (Nc + 7) / 8 * 8;
+        const size_t Np = (N + 15) / 16 * 16, Ncp = (Nc + 15) / 16 * 16, xcols = 2 * Np + 16;
         BPolyEntry e;
         e.Arp = lv.A.rp;
         e.Aci = lv.A.ci;
@@ -929,38 +939,46 @@ void amg_prepare_levels(ipd_amg* h) {
         e.xx = gd.xx;
         e.N = (int)N;
         e.Nc = (int)Nc;
+        e.Np = (int)Np;
+        e.Ncp = (int)Ncp;
         e.nu = h->opts.smoth;
         (void)nu;
         e.isnsp = isnsp;
         e.LD = bpoly_ld(k);
-        e.A = ctx->scratch->alloc<double>(N * N);
-        e.S = ctx->scratch->alloc<double>(N * N);
-        e.P = ctx->scratch->alloc<double>(N * Nc);
-        e.T1 = ctx->scratch->alloc<double>(N * Nc);
-        for (int i = 0; i < 2; ++i) {
-            e.M1[i] = ctx->scratch->alloc<double>(N * N);
-            e.M2[i] = ctx->scratch->alloc<double>(N * N);
-            e.w[i] = ctx->scratch->alloc<double>(N);
-        }
-        e.dv = ctx->scratch->alloc<double>(N);
-        e.u = ctx->scratch->alloc<double>(N);
+        // one zeroed block of scratch: A, S, P, T1, X[0], X[1], dv, u
+        const size_t sc = 2 * Np * Np + 2 * Np * Ncp + 2 * Np * xcols + 2 * Np;
+        double* blk = ctx->scratch->alloc<double>(sc);
+        IPD_HIP(hipMemsetAsync(blk, 0, sc * sizeof(double), ctx->stream));
+        e.A = blk;
+        e.S = e.A + Np * Np;
+        e.P = e.S + Np * Np;
+        e.T1 = e.P + Np * Ncp;
+        e.X[0] = e.T1 + Np * Ncp;
+        e.X[1] = e.X[0] + Np * xcols;
+        e.dv = e.X[1] + Np * xcols;
+        e.u = e.dv + Np;
         const size_t ncols = 2 * N8 + Nc8;
         b.LD = e.LD;
-        b.M = ar.alloc<double>((size_t)e.LD * ncols);
-        b.W = ar.alloc<double>((size_t)e.LD);
+        b.M = ar.alloc<double>((size_t)e.LD * (ncols + 1));
+        b.W = b.M + (size_t)e.LD * ncols;
+        IPD_HIP(hipMemsetAsync(b.M, 0, (size_t)e.LD * (ncols + 1) * sizeof(double), ctx->stream));
         e.M = b.M;
         e.W = b.W;
-        hipLaunchKernelGGL(k_bpoly_init, dim3(1), dim3(BT), 0, ctx->stream, e);
+        hipLaunchKernelGGL(k_bpoly_scatter, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, e);
+        IPD_KERNEL_CHECK();
+        const int nS = (int)((N * N + 255) / 256), nT1 = (int)(((Ncp / 16) * (Np / 16) + 3) / 4);
+        hipLaunchKernelGGL(k_bpoly_S_T1, dim3((unsigned)(nS + nT1)), dim3(256), 0, ctx->stream, e, nS);
         IPD_KERNEL_CHECK();
         int cur = 0;
+        const unsigned step_blocks = (unsigned)(((Np / 16) * (xcols / 16) + 3) / 4);
         for (int s = 1; s < e.nu; ++s) {
-            hipLaunchKernelGGL(k_bpoly_step, dim3((unsigned)((2 * N * N + N + 255) / 256)), dim3(256), 0, ctx->stream,
-                               e, cur);
+            hipLaunchKernelGGL(k_bpoly_step, dim3(step_blocks), dim3(256), 0, ctx->stream, e, cur);
             IPD_KERNEL_CHECK();
             cur ^= 1;
         }
-        hipLaunchKernelGGL(k_bpoly_final, dim3((unsigned)(((size_t)e.LD * (ncols + 1) + 255) / 256)), dim3(256), 0,
-                           ctx->stream, e, cur);
+        const int nZ = (int)(((Ncp / 16) * (xcols / 16) + 3) / 4), nC = (int)(((Np / 16) * (Ncp / 16) + 3) / 4);
+        const int nK = (int)((N * N + N + 255) / 256);
+        hipLaunchKernelGGL(k_bpoly_final, dim3((unsigned)(nZ + nC + nK)), dim3(256), 0, ctx->stream, e, cur, nZ, nC);
         IPD_KERNEL_CHECK();
         return b;
     };
@@ -984,6 +1002,9 @@ void amg_prepare_levels(ipd_amg* h) {
                 // vectors; none of the level's CSR arrays (its parent applies the transfers to and from it)
                 const size_t Nc = (size_t)h->L[k + 1].A.nr, LD = poly_ld(N + Nc);
                 bytes = 2 * (8 * LD * r8(N)) + 8 * LD * r8(Nc) + 8 * LD + 3 * r16(8 * r8(N)) + 32;
+            } else if (is_lpoly(k)) {
+                const size_t Nc = (size_t)h->L[k + 1].A.nr, LD = 64;
+                bytes = 2 * (8 * LD * r8(N)) + 8 * LD * r8(Nc) + 8 * LD + 3 * r16(8 * r8(N)) + 32 + 8 * (8 * LD + 8);
             } else if (is_bpoly(k)) {
                 // block-wide polynomial form: the operators stay in global memory; three vectors and the
                 // partial sums of a pass
@@ -1001,7 +1022,7 @@ void amg_prepare_levels(ipd_amg* h) {
                 }
                 if (k == h->J) bytes += r16(4 * 8 * N);
                 if (use_lmap && !is_bdense(k) && k >= 2 && k < tiny_lo && N <= (size_t)BT) bytes += r16(4 * (BT + 1));   // lane map
-                if (k >= 3 && is_bpoly(k - 1)) bytes += 5 * 64;   // its vectors are padded to whole 8-entry blocks
+                if (k >= 3 && (is_bpoly(k - 1) || is_lpoly(k - 1))) bytes += 5 * 64;   // its vectors are padded to whole 8-entry blocks
                 if (k >= tiny_lo) {   // dense copies of the tiny levels
                     bytes += r16(8 * N * N);
                     if (k < h->J) bytes += 2 * r16(8 * N * (size_t)h->L[k + 1].A.nr);
@@ -1062,7 +1083,7 @@ void amg_prepare_levels(ipd_amg* h) {
             SolveLevel& T = sd->L[k];
             const size_t N = (size_t)T.lv.N;
             if (k == sd->k_semi) continue;         // matrix, transfers, dinv, Axi stay in global memory
-            if (is_poly(k) && k >= sd->k_tiny && sd->k_blk <= k) {   // polynomial form: no CSR arrays (see plan_lds)
+            if (((is_poly(k) && k >= sd->k_tiny) || (is_lpoly(k) && k < sd->k_tiny)) && sd->k_blk <= k) {   // polynomial form: no CSR arrays (see plan_lds)
                 put(T.lv.xx, 1);
                 T.lv.rp = T.lv.ci = nullptr;
                 T.lv.va = T.lv.dinv = T.lv.Axi = nullptr;
@@ -1107,7 +1128,7 @@ void amg_prepare_levels(ipd_amg* h) {
         }
         std::vector<LmapEntry> lmaps;
         for (int k = std::max(k_from, sd->k_blk); k < std::min(sd->k_tiny, h->J + 1); ++k) {
-            if (!use_lmap || k == sd->k_semi || k < 2 || h->L[k].A.nr > BT || k == h->J || sd->L[k].blk_dense || sd->L[k].gM) continue;
+            if (!use_lmap || k == sd->k_semi || k < 2 || h->L[k].A.nr > BT || k == h->J || sd->L[k].blk_dense || sd->L[k].gM || is_lpoly(k)) continue;
             SolveLevel& T = sd->L[k];
             const size_t o = carve(4 * (BT + 1));
             lmaps.push_back(LmapEntry{h->L[k].A.rp, h->L[k].A.nr, (unsigned)(o - stage)});
@@ -1124,45 +1145,55 @@ void amg_prepare_levels(ipd_amg* h) {
             dense.push_back(DenseEntry{m.rp, m.ci, m.va, m.nr, m.nc, (unsigned)(o - stage), ld});
             set_off(sd->L[k].dA, o);
         }
+        auto add_poly = [&](int k, size_t LD) {
+            SolveLevel& T = sd->L[k];
+            const Level& lv = h->L[k];
+            const size_t N = (size_t)lv.A.nr;
+            const Csr& P = h->L[k + 1].P;
+            const size_t Nc = (size_t)P.nc;
+            const LevelDev& gd = st->run[(size_t)k].dev;   // global pointers (T's are LDS offsets by now)
+            PolyEntry pe;
+            pe.Arp = lv.A.rp;
+            pe.Aci = lv.A.ci;
+            pe.Ava = lv.A.va;
+            pe.Prp = P.rp;
+            pe.Pci = P.ci;
+            pe.Pva = P.va;
+            pe.dinv = gd.dinv;
+            pe.Axi = gd.Axi;
+            pe.xx = gd.xx;
+            pe.N = (int)N;
+            pe.Nc = (int)Nc;
+            pe.nu = sd->nu;
+            pe.isnsp = sd->isnsp;
+            pe.LD = (int)LD;
+            T.pLD = (int)LD;
+            size_t o = carve(8 * LD * r8(N));
+            pe.offMr = (unsigned)(o - stage);
+            set_off(T.pMr, o);
+            o = carve(8 * LD * r8(N));
+            pe.offMe = (unsigned)(o - stage);
+            set_off(T.pMe, o);
+            o = carve(8 * LD * r8(Nc));
+            pe.offMc = (unsigned)(o - stage);
+            set_off(T.pMc, o);
+            o = carve(8 * LD);
+            pe.offW = (unsigned)(o - stage);
+            set_off(T.pW, o);
+            polys.push_back(pe);
+            poly_lds = std::max(poly_lds, 8 * (5 * N * N + 2 * N * Nc + 4 * N) + 64);
+        };
+        for (int k = std::max(k_from, sd->k_blk); k < std::min(sd->k_tiny, h->J); ++k)
+            if (is_lpoly(k) && k != sd->k_semi) {   // block-wide out of LDS: leading dimension 64, one row per lane
+                add_poly(k, 64);
+                bp_ld_max = std::max(bp_ld_max, 64);
+            }
         for (int k = std::max(k_from, sd->k_tiny); k <= h->J; ++k) {
             SolveLevel& T = sd->L[k];
             const Level& lv = h->L[k];
             const size_t N = (size_t)lv.A.nr;
             if (is_poly(k) && sd->k_blk <= k && k != sd->k_semi) {
-                const Csr& P = h->L[k + 1].P;
-                const size_t Nc = (size_t)P.nc;
-                const LevelDev& gd = st->run[(size_t)k].dev;   // global pointers (T's are LDS offsets by now)
-                PolyEntry pe;
-                pe.Arp = lv.A.rp;
-                pe.Aci = lv.A.ci;
-                pe.Ava = lv.A.va;
-                pe.Prp = P.rp;
-                pe.Pci = P.ci;
-                pe.Pva = P.va;
-                pe.dinv = gd.dinv;
-                pe.Axi = gd.Axi;
-                pe.xx = gd.xx;
-                pe.N = (int)N;
-                pe.Nc = (int)Nc;
-                pe.nu = sd->nu;
-                pe.isnsp = sd->isnsp;
-                const size_t LD = poly_ld(N + Nc);
-                pe.LD = (int)LD;
-                T.pLD = (int)LD;
-                size_t o = carve(8 * LD * r8(N));
-                pe.offMr = (unsigned)(o - stage);
-                set_off(T.pMr, o);
-                o = carve(8 * LD * r8(N));
-                pe.offMe = (unsigned)(o - stage);
-                set_off(T.pMe, o);
-                o = carve(8 * LD * r8(Nc));
-                pe.offMc = (unsigned)(o - stage);
-                set_off(T.pMc, o);
-                o = carve(8 * LD);
-                pe.offW = (unsigned)(o - stage);
-                set_off(T.pW, o);
-                polys.push_back(pe);
-                poly_lds = std::max(poly_lds, 8 * (5 * N * N + 2 * N * Nc + 4 * N) + 64);
+                add_poly(k, poly_ld(N + (size_t)h->L[k + 1].P.nc));
                 continue;
             }
             auto add = [&](const double*& field, const Csr& m) {
@@ -1183,7 +1214,7 @@ void amg_prepare_levels(ipd_amg* h) {
             // (one-wave levels: zero-padded to whole 8-entry blocks, see sol_load_image)
             // (dense thread-per-row levels: zero-padded to whole groups of four entries per lane, dense_row_dot)
             // (block-wide polynomial levels and their children: whole 8-entry blocks as well, bpoly_pass)
-            const bool pad8 = k >= sd->k_tiny || T.gM || (k > k_from && sd->L[k - 1].gM);
+            const bool pad8 = k >= sd->k_tiny || T.gM || T.pMr || (k > k_from && (sd->L[k - 1].gM || sd->L[k - 1].pMr));
             const size_t N = T.blk_dense ? (size_t)bdense_pad(T.lv.N) : pad8 ? r8((size_t)T.lv.N) : (size_t)T.lv.N;
             set_off(T.lv.r, carve(N * 8));
             set_off(T.e, carve(N * 8));
@@ -1260,7 +1291,7 @@ void amg_prepare_levels(ipd_amg* h) {
         for (int k = std::max(k_from, sd->k_blk); k <= h->J; ++k) {
             const SolveLevel& T = sd->L[k];
             if (k == sd->k_semi) continue;
-            st->level_forms[(size_t)k] |= T.gM ? 16 : T.pMr ? 8 : k >= sd->k_tiny ? 4 : T.blk_dense ? 2 : 1;
+            st->level_forms[(size_t)k] |= T.gM ? 16 : T.pMr ? (k >= sd->k_tiny ? 8 : 32) : k >= sd->k_tiny ? 4 : T.blk_dense ? 2 : 1;
         }
         return reinterpret_cast<SolveDesc*>(img);
     };
