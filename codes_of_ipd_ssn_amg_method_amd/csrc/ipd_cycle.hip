@@ -2702,8 +2702,13 @@ struct BPolyEntry {
     double* X[2]; // Np x (2 Np + 16): [M2a | M1 | w, 15 zero columns]
     double* dv;
     double* u;
+    double* cs;   // column sums of A
     double* M;    // out: [Mr | Me | Mc], LD rows, 8-padded column counts (zeroed by the host)
     double* W;    // out: LD
+    // out, instead of M: row-major [N + Nc][1024] with Mr in columns 0..N-1 and Me in 512..512+N-1, no
+    // Mc (the resident kernels' third level: a thread holds entries t and 512 + t of its workgroup's
+    // rows, ipd_resident.h POLY3); W then has N + Nc entries
+    double* rows;
 };
 typedef double bp_d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bp_d4 bp_tile(const double* __restrict__ A, int a_is, int a_ks,
@@ -2741,8 +2746,16 @@ __global__ __launch_bounds__(256) void k_bpoly_scatter(const BPolyEntry e) {
     e.X[0][r + (size_t)r * Np] = d;
     e.X[0][r + (size_t)(2 * Np) * Np] = ui;
 }
+__global__ __launch_bounds__(64) void k_bpoly_colsum(const BPolyEntry e) {
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= e.N) return;
+    const double* aj = e.A + (size_t)j * e.Np;
+    double cs = 0.0;
+    for (int k = 0; k < e.N; ++k) cs += aj[k];
+    e.cs[j] = cs;
+}
 // S = I - Rg A with (Rg A)[i][j] = dinv_i A[i][j] + u_i (1'A)_j, also M1 = S after the first sweep
-// (blocks below nS: one thread per entry, the column sum formed by each); T1 = P'A (the tiles behind)
+// (blocks below nS: one thread per entry); T1 = P'A (the tiles behind)
 __global__ __launch_bounds__(256) void k_bpoly_S_T1(const BPolyEntry e, int nS) {
     const int N = e.N, Np = e.Np;
     if ((int)blockIdx.x < nS) {
@@ -2750,9 +2763,7 @@ __global__ __launch_bounds__(256) void k_bpoly_S_T1(const BPolyEntry e, int nS) 
         if (q >= N * N) return;
         const int i = q % N, j = q / N;
         const double* aj = e.A + (size_t)j * Np;
-        double cs = 0.0;
-        for (int k = 0; k < N; ++k) cs += aj[k];
-        const double sv = (i == j ? 1.0 : 0.0) - (e.dv[i] * aj[i] + e.u[i] * cs);
+        const double sv = (i == j ? 1.0 : 0.0) - (e.dv[i] * aj[i] + e.u[i] * e.cs[j]);
         e.S[i + (size_t)j * Np] = sv;
         e.X[0][i + (size_t)(Np + j) * Np] = sv;
         return;
@@ -2787,6 +2798,12 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int fin
     const int N = e.N, Nc = e.Nc, Np = e.Np, Ncp = e.Ncp, LD = e.LD, l = threadIdx.x & 63;
     const int N8 = (N + 7) / 8 * 8;
     const double* X = e.X[fin];
+    auto put = [&](int row, bool me, int j, double v) {
+        if (e.rows)
+            e.rows[(size_t)row * 1024 + (me ? 512 : 0) + j] = v;
+        else
+            e.M[row + (size_t)((me ? N8 : 0) + j) * LD] = v;
+    };
     int blk = blockIdx.x;
     if (blk < nZ) {   // Z = T1 X: Ncp x (2 Np + 16)
         const int ni = Ncp / 16, nj = (2 * Np + 16) / 16, tile = blk * 4 + (threadIdx.x >> 6);
@@ -2798,9 +2815,9 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int fin
             const int cc = I0 + (l >> 4) + 4 * g;
             if (cc >= Nc) continue;
             if (j < Np) {
-                if (j < N) e.M[(N + cc) + (size_t)j * LD] = e.P[j + (size_t)cc * Np] - c[g];
+                if (j < N) put(N + cc, false, j, e.P[j + (size_t)cc * Np] - c[g]);
             } else if (j < 2 * Np) {
-                if (j - Np < N) e.M[(N + cc) + (size_t)(N8 + j - Np) * LD] = -c[g];
+                if (j - Np < N) put(N + cc, true, j - Np, -c[g]);
             } else if (j == 2 * Np) {
                 e.W[N + cc] = -c[g];
             }
@@ -2809,6 +2826,7 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int fin
     }
     blk -= nZ;
     if (blk < nC) {   // Mc = M1 P: Np x Ncp
+        if (e.rows) return;
         const int ni = Np / 16, nj = Ncp / 16, tile = blk * 4 + (threadIdx.x >> 6);
         if (tile >= ni * nj) return;
         const int I0 = 16 * (tile % ni), J0 = 16 * (tile / ni);
@@ -2824,8 +2842,8 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int fin
     const int q = blk * 256 + threadIdx.x;   // copies: M2a, M1, w
     if (q < N * N) {
         const int i = q % N, j = q / N;
-        e.M[i + (size_t)j * LD] = X[i + (size_t)j * Np];
-        e.M[i + (size_t)(N8 + j) * LD] = X[i + (size_t)(Np + j) * Np];
+        put(i, false, j, X[i + (size_t)j * Np]);
+        put(i, true, j, X[i + (size_t)(Np + j) * Np]);
     } else if (q < N * N + N) {
         const int i = q - N * N;
         e.W[i] = X[i + (size_t)(2 * Np) * Np];

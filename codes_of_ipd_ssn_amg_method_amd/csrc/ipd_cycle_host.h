@@ -235,6 +235,82 @@ static int pick_blocks(int nrows, int L, int cu) {
 }
 
 
+// Packs the polynomial form of level k (k_bpoly_*, ipd_cycle.hip) into the hierarchy's arena: LD-row
+// column-major [Mr | Me | Mc] for the single-workgroup images, or (rows) the row-major layout the
+// resident kernels' third level takes.
+struct BPolyDev {
+    double* M = nullptr;
+    double* W = nullptr;
+    int LD = 0;
+};
+static BPolyDev pack_bpoly(ipd_ctx* ctx, ipd_amg* h, CycleState* st, int k, int isnsp, int LD, bool rows) {
+    Arena& ar = *h->arena;
+    BPolyDev b;
+    const Level& lv = h->L[k];
+    const Csr& P = h->L[k + 1].P;
+    const LevelDev& gd = st->run[(size_t)k].dev;
+    const size_t N = (size_t)lv.A.nr, Nc = (size_t)P.nc, N8 = (N + 7) / 8 * 8, Nc8 = (Nc + 7) / 8 * 8;
+    const size_t Np = (N + 15) / 16 * 16, Ncp = (Nc + 15) / 16 * 16, xcols = 2 * Np + 16;
+    BPolyEntry e;
+    e.Arp = lv.A.rp;
+    e.Aci = lv.A.ci;
+    e.Ava = lv.A.va;
+    e.Prp = P.rp;
+    e.Pci = P.ci;
+    e.Pva = P.va;
+    e.dinv = gd.dinv;
+    e.Axi = gd.Axi;
+    e.xx = gd.xx;
+    e.N = (int)N;
+    e.Nc = (int)Nc;
+    e.Np = (int)Np;
+    e.Ncp = (int)Ncp;
+    e.nu = h->opts.smoth;
+    e.isnsp = isnsp;
+    e.LD = LD;
+    // one zeroed block of scratch: A, S, P, T1, X[0], X[1], dv, u, cs
+    const size_t sc = 2 * Np * Np + 2 * Np * Ncp + 2 * Np * xcols + 3 * Np;
+    double* blk = ctx->scratch->alloc<double>(sc);
+    IPD_HIP(hipMemsetAsync(blk, 0, sc * sizeof(double), ctx->stream));
+    e.A = blk;
+    e.S = e.A + Np * Np;
+    e.P = e.S + Np * Np;
+    e.T1 = e.P + Np * Ncp;
+    e.X[0] = e.T1 + Np * Ncp;
+    e.X[1] = e.X[0] + Np * xcols;
+    e.dv = e.X[1] + Np * xcols;
+    e.u = e.dv + Np;
+    e.cs = e.u + Np;
+    const size_t ncols = 2 * N8 + Nc8;
+    const size_t out = rows ? (N + Nc) * 1024 + (N + Nc) : (size_t)LD * (ncols + 1);
+    b.LD = LD;
+    b.M = ar.alloc<double>(out);
+    b.W = rows ? b.M + (N + Nc) * 1024 : b.M + (size_t)LD * ncols;
+    IPD_HIP(hipMemsetAsync(b.M, 0, out * sizeof(double), ctx->stream));
+    e.M = b.M;
+    e.W = b.W;
+    e.rows = rows ? b.M : nullptr;
+    hipLaunchKernelGGL(k_bpoly_scatter, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, e);
+    IPD_KERNEL_CHECK();
+    hipLaunchKernelGGL(k_bpoly_colsum, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, ctx->stream, e);
+    IPD_KERNEL_CHECK();
+    const int nS = (int)((N * N + 255) / 256), nT1 = (int)(((Ncp / 16) * (Np / 16) + 3) / 4);
+    hipLaunchKernelGGL(k_bpoly_S_T1, dim3((unsigned)(nS + nT1)), dim3(256), 0, ctx->stream, e, nS);
+    IPD_KERNEL_CHECK();
+    int cur = 0;
+    const unsigned step_blocks = (unsigned)(((Np / 16) * (xcols / 16) + 3) / 4);
+    for (int s = 1; s < e.nu; ++s) {
+        hipLaunchKernelGGL(k_bpoly_step, dim3(step_blocks), dim3(256), 0, ctx->stream, e, cur);
+        IPD_KERNEL_CHECK();
+        cur ^= 1;
+    }
+    const int nZ = (int)(((Ncp / 16) * (xcols / 16) + 3) / 4), nC = (int)(((Np / 16) * (Ncp / 16) + 3) / 4);
+    const int nK = (int)((N * N + N + 255) / 256);
+    hipLaunchKernelGGL(k_bpoly_final, dim3((unsigned)(nZ + nC + nK)), dim3(256), 0, ctx->stream, e, cur, nZ, nC);
+    IPD_KERNEL_CHECK();
+    return b;
+}
+
 // ---- level-resident solve kernel: eligibility and launch ---------------------------------
 // Eligible: three levels -- a bigraph Gauss-Seidel level 1 and a Jacobi level 2 with padded
 // rows of at most 1024 entries, at most 2048 rows each, and a tail level of at most 64 rows --
@@ -333,6 +409,12 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     const int Nin = three ? h->L[4].A.nr : Nt;   // rows of the remote tail's root level / of the local tail
     if (remote && Nin > RES_WAVES * G) return;   // one row of the restriction to it per wave
     if (three && Nt + G > 2 * BT) return;        // level-3 hand-offs: N3 + G granules, two per thread
+    // level 3 in polynomial form (ResDesc::p3rows): remote tail, one restriction row per workgroup at most,
+    // at most four rows of level 3 per workgroup
+    const bool poly3 = three && remote && h->opts.smoth >= 1 && h->L[4].A.nr <= G && Nt <= 4 * G && Nt <= BT &&
+                       !(std::getenv("IPD_NO_RES_POLY3") && std::getenv("IPD_NO_RES_POLY3")[0] == '1') &&
+                       !(std::getenv("IPD_NO_POLY") && std::getenv("IPD_NO_POLY")[0] == '1');
+    if (poly3) ke3 = 1;
     const size_t lds = remote ? std::max<size_t>(RES_LDS_BYTES, tail_lds) : RES_LDS_BYTES;
     if (lds > 156 * 1024) return;
     Arena& ar = *h->arena;
@@ -383,7 +465,13 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     D.A4 = csr(three ? h->L[4].A : l3.A);
     if (three) {
         LevelDev d3 = st->run[3].dev;
-        if (d3.S <= 0) {   // private padded copy of level 3, stride = its longest row
+        if (poly3) {
+            const BPolyDev pb = pack_bpoly(h->ctx, h, st, 3, h->opts.isnsp, 0, true);
+            D.p3rows = pb.M;
+            D.p3w = pb.W;
+            st->level_forms.resize((size_t)h->J + 1, 0);
+            st->level_forms[3] |= 64;
+        } else if (d3.S <= 0) {   // private padded copy of level 3, stride = its longest row
             d3.S = (st->run[3].maxoff + 3) / 4 * 4;
             private_pad(l3.A, d3);
         }
@@ -566,6 +654,11 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
             IPD_RES_LAUNCH(8, 0);
         else
             IPD_RES_LAUNCH(16, 0);
+    } else if (st->res_ke3 == 1) {
+        if (st->res_ke == 4)
+            IPD_RES_LAUNCH(4, 1);
+        else
+            IPD_RES_LAUNCH(8, 1);
     } else if (st->res_ke == 4) {
         if (st->res_ke3 == 4)
             IPD_RES_LAUNCH(4, 4);
@@ -913,73 +1006,11 @@ void amg_prepare_levels(ipd_amg* h) {
         const long long N = h->L[k].A.nr, Nc = h->L[k + 1].A.nr;
         return N > 32 && N <= 144 && N + Nc <= 256 && !is_lpoly(k);
     };
-    struct BPolyDev {
-        double* M = nullptr;
-        double* W = nullptr;
-        int LD = 0;
-    };
     std::vector<BPolyDev> bpoly_dev((size_t)h->J + 2);
     auto ensure_bpoly = [&](int k, int nu, int isnsp) -> const BPolyDev& {
-        BPolyDev& b = bpoly_dev[(size_t)k];
-        if (b.M) return b;
-        const Level& lv = h->L[k];
-        const Csr& P = h->L[k + 1].P;
-        const LevelDev& gd = st->run[(size_t)k].dev;
-        const size_t N = (size_t)lv.A.nr, Nc = (size_t)P.nc, N8 = (N + 7) / 8 * 8, Nc8 = (Nc + 7) / 8 * 8;
-        const size_t Np = (N + 15) / 16 * 16, Ncp = (Nc + 15) / 16 * 16, xcols = 2 * Np + 16;
-        BPolyEntry e;
-        e.Arp = lv.A.rp;
-        e.Aci = lv.A.ci;
-        e.Ava = lv.A.va;
-        e.Prp = P.rp;
-        e.Pci = P.ci;
-        e.Pva = P.va;
-        e.dinv = gd.dinv;
-        e.Axi = gd.Axi;
-        e.xx = gd.xx;
-        e.N = (int)N;
-        e.Nc = (int)Nc;
-        e.Np = (int)Np;
-        e.Ncp = (int)Ncp;
-        e.nu = h->opts.smoth;
         (void)nu;
-        e.isnsp = isnsp;
-        e.LD = bpoly_ld(k);
-        // one zeroed block of scratch: A, S, P, T1, X[0], X[1], dv, u
-        const size_t sc = 2 * Np * Np + 2 * Np * Ncp + 2 * Np * xcols + 2 * Np;
-        double* blk = ctx->scratch->alloc<double>(sc);
-        IPD_HIP(hipMemsetAsync(blk, 0, sc * sizeof(double), ctx->stream));
-        e.A = blk;
-        e.S = e.A + Np * Np;
-        e.P = e.S + Np * Np;
-        e.T1 = e.P + Np * Ncp;
-        e.X[0] = e.T1 + Np * Ncp;
-        e.X[1] = e.X[0] + Np * xcols;
-        e.dv = e.X[1] + Np * xcols;
-        e.u = e.dv + Np;
-        const size_t ncols = 2 * N8 + Nc8;
-        b.LD = e.LD;
-        b.M = ar.alloc<double>((size_t)e.LD * (ncols + 1));
-        b.W = b.M + (size_t)e.LD * ncols;
-        IPD_HIP(hipMemsetAsync(b.M, 0, (size_t)e.LD * (ncols + 1) * sizeof(double), ctx->stream));
-        e.M = b.M;
-        e.W = b.W;
-        hipLaunchKernelGGL(k_bpoly_scatter, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, e);
-        IPD_KERNEL_CHECK();
-        const int nS = (int)((N * N + 255) / 256), nT1 = (int)(((Ncp / 16) * (Np / 16) + 3) / 4);
-        hipLaunchKernelGGL(k_bpoly_S_T1, dim3((unsigned)(nS + nT1)), dim3(256), 0, ctx->stream, e, nS);
-        IPD_KERNEL_CHECK();
-        int cur = 0;
-        const unsigned step_blocks = (unsigned)(((Np / 16) * (xcols / 16) + 3) / 4);
-        for (int s = 1; s < e.nu; ++s) {
-            hipLaunchKernelGGL(k_bpoly_step, dim3(step_blocks), dim3(256), 0, ctx->stream, e, cur);
-            IPD_KERNEL_CHECK();
-            cur ^= 1;
-        }
-        const int nZ = (int)(((Ncp / 16) * (xcols / 16) + 3) / 4), nC = (int)(((Np / 16) * (Ncp / 16) + 3) / 4);
-        const int nK = (int)((N * N + N + 255) / 256);
-        hipLaunchKernelGGL(k_bpoly_final, dim3((unsigned)(nZ + nC + nK)), dim3(256), 0, ctx->stream, e, cur, nZ, nC);
-        IPD_KERNEL_CHECK();
+        BPolyDev& b = bpoly_dev[(size_t)k];
+        if (!b.M) b = pack_bpoly(ctx, h, st.get(), k, isnsp, bpoly_ld(k), false);
         return b;
     };
     auto is_bdense = [&](int k) {
@@ -1450,7 +1481,14 @@ void amg_prepare_levels(ipd_amg* h) {
     // 0.50-0.51 against 0.57-0.61 ms per W cycle on the Newton systems of the m=n=1024 Class 1 run), so a
     // second image rooted at level 4 is packed for it.  (Where levels 3..J fit the image as they are,
     // the tail rooted at level 3 stays 3-6 % ahead: 0.49-0.51 against 0.51-0.54 ms.)
-    if (st->k_sub == 3 && st->sub_semi_root && st->d_sub && h->J >= 5 && h->J <= SOLVE_ML && h->L[3].A.nr <= BT &&
+    // With level 3 in polynomial form (plan_resident, poly3: a visit of it is three hand-offs instead of
+    // thirteen) the same holds wherever that form applies, semi-cached root or not: 0.33-0.36 -> see DESIGN.
+    const bool poly3_likely =
+        h->J >= 5 && h->opts.smoth >= 1 && h->L[1].nf > 0 &&
+        h->L[4].A.nr <= std::max(cdiv(std::max(h->L[1].nf, h->L[1].A.nr - h->L[1].nf), RES_WAVES), cdiv(h->L[2].A.nr, RES_WAVES)) &&
+        !(std::getenv("IPD_NO_RES_POLY3") && std::getenv("IPD_NO_RES_POLY3")[0] == '1') &&
+        !(std::getenv("IPD_NO_POLY") && std::getenv("IPD_NO_POLY")[0] == '1');
+    if (st->k_sub == 3 && (st->sub_semi_root || poly3_likely) && st->d_sub && h->J >= 5 && h->J <= SOLVE_ML && h->L[3].A.nr <= BT &&
         h->L[4].A.nr <= BT && st->run[3].maxoff <= 512 && h->L[1].nf > 0 &&
         !(std::getenv("IPD_NO_RESIDENT_THREE") && std::getenv("IPD_NO_RESIDENT_THREE")[0] == '1') &&
         !(std::getenv("IPD_NO_RESIDENT") && std::getenv("IPD_NO_RESIDENT")[0] == '1')) {

@@ -68,6 +68,13 @@ struct ResDesc {
     ResCsr A4;        // ... when level 3 is resident too and level 4 is the (local) tail
     int three;        // levels 1-3 resident (hierarchies whose level 3 does not fit the tail's LDS)
     int tail_root;    // remote tail: 3 or 4
+    // Level 3 in polynomial form (template argument KE3 == 1, remote tail only; pack_bpoly with rows):
+    // row i < N3 of p3rows is [M2a | M1](i,:) and row N3 + c is the restriction row c stacked on it,
+    // entries 0..N3-1 applied to r_3 and 512..512+N3-1 to e_3; p3w their factors of 1'r_3.  A visit of
+    // level 3 is then THREE hand-offs (e' and the restricted residual; the tail's answer; e'') instead of
+    // thirteen (ten sweeps, the residual, the restriction, the prolongation).
+    const double* p3rows;
+    const double* p3w;
     // Remote tail (hierarchies with more than three levels): workgroup gridDim.x - 1 holds the LDS
     // image of the single-workgroup sub-cycle rooted at level 3 (k_subcycle's code and data) and
     // serves the visits of everything below level 2: the other workgroups hand it r_3 = P3' rr_2
@@ -376,7 +383,8 @@ template <int KE1, int KE2, int KE3 = 0>
 __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const double* __restrict__ bvec,
                                                     double* xg, double* out, int fixed_cycles) {
     constexpr bool THREE = KE3 > 0;
-    constexpr int K3 = THREE ? KE3 : 2;
+    constexpr bool POLY3 = KE3 == 1;   // level 3 in polynomial form (ResDesc::p3rows)
+    constexpr int K3 = (THREE && !POLY3) ? KE3 : 2;
     extern __shared__ __attribute__((aligned(16))) char res_smem[];
     double* sm = reinterpret_cast<double*>(res_smem);
     const char* smb = res_smem;
@@ -435,7 +443,27 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     res_load_slice<KE2>(D.L2, r2, v2, lane, c2, a2);
     unsigned c3[K3 / 2];
     double a3[K3];
-    if (THREE) res_load_slice<K3>(D.L3, r3, v3, lane, c3, a3);
+    if (THREE && !POLY3) res_load_slice<K3>(D.L3, r3, v3, lane, c3, a3);
+    // polynomial form: entries tid and 512 + tid of the workgroup's rows lo3..hi3-1 (at most four) and of
+    // restriction row b (the remote tail's root level has at most G rows: one per workgroup)
+    double m3r[5], m3e[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) m3r[q] = m3e[q] = 0.0;
+    if (POLY3) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int row = q < 4 ? lo3 + q : N3 + b;
+            const bool ok = (q < 4 ? row < hi3 : b < Nt) && tid < N3;
+            if (ok) {
+                m3r[q] = D.p3rows[(size_t)row * 1024 + tid];
+                m3e[q] = D.p3rows[(size_t)row * 1024 + 512 + tid];
+            }
+        }
+        if (tid < 5) {
+            const int row = tid < 4 ? lo3 + tid : N3 + b;
+            sm[oE3 + tid] = (tid < 4 ? row < hi3 : b < Nt) ? D.p3w[row] : 0.0;
+        }
+    }
     // the rows' own scalars live in LDS (a register pair each would stay live for the whole solve)
     if (lane == 0) {
         sm[oOWN + 0 * RES_WAVES + w] = D.L1.diag[rF];
@@ -446,8 +474,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         sm[oOWN + 5 * RES_WAVES + w] = bvec[rC];
         sm[oOWN + 6 * RES_WAVES + w] = D.L2.diag[r2];
         sm[oOWN + 7 * RES_WAVES + w] = D.L2.dinv[r2];
-        sm[oOWN + 8 * RES_WAVES + w] = THREE ? D.L3.diag[r3] : 0.0;
-        sm[oOWN + 9 * RES_WAVES + w] = THREE ? D.L3.dinv[r3] : 0.0;
+        sm[oOWN + 8 * RES_WAVES + w] = (THREE && !POLY3) ? D.L3.diag[r3] : 0.0;
+        sm[oOWN + 9 * RES_WAVES + w] = (THREE && !POLY3) ? D.L3.dinv[r3] : 0.0;
         rowp[12 * w + 0] = D.Pt2.rp[r2];
         rowp[12 * w + 1] = v2 ? D.Pt2.rp[r2 + 1] - D.wident : D.Pt2.rp[r2];
         rowp[12 * w + 2] = D.P2.rp[rF];
@@ -906,7 +934,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // workgroups (0-4 rows each).  A workgroup without a row still has to say that it has finished a
     // step (the two-buffer protocol lets a buffer be rewritten once everybody has published the step in
     // between), so every workgroup publishes one extra "ack" granule, N3 + b, with its rows.
-    double c3s = 0.0;
+    double c3s = 0.0, sumr3 = 0.0;
 #define RES_HANDOFF3(STORE3, want_sums, t0)                                                              \
     do {                                                                                                 \
         if (w == 0 && lane == 0) sm[oPUB + RES_WAVES] = 0.0;                                             \
@@ -935,8 +963,56 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         }
     };
     // one visit of level 3 and, through the remote tail rooted at level 4, of everything below it
+    // polynomial form: the sums of this workgroup's rows against [r_3; e_3] (+ their factor of 1'r_3)
+    // -> sm[oR3 + 40 + q]; the caller's next barrier publishes them
+    auto poly3_rows = [&](int nrows) __attribute__((always_inline)) {
+        const double xr = tid < N3 ? sm[oR3L + tid] : 0.0, xe = tid < N3 ? sm[oE3L + tid] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            if (q < nrows) {
+                const double pq = wave_sum(__builtin_fma(m3e[q], xe, m3r[q] * xr));
+                if (lane == 0) sm[oR3 + 8 * q + w] = pq;
+            }
+        }
+        __syncthreads();
+        if (tid < nrows) {
+            double sq = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < RES_WAVES; ++ww) sq += sm[oR3 + 8 * tid + ww];
+            sm[oR3 + 40 + tid] = __builtin_fma(sm[oE3 + tid], sumr3, sq);
+        }
+        __syncthreads();
+    };
     auto visit3 = [&](bool keep) __attribute__((always_inline)) {
-        if (THREE) {
+        if (POLY3) {
+            ++tseq;
+            // e' = M2a r + M1 e and the restricted residual of e' in one pass                 MG_Vcycle.m:20-29
+            poly3_rows(5);
+            if (tid == 0 && b < Nt)
+                __builtin_amdgcn_raw_buffer_store_b128(res_pack(sm[oR3 + 44], tseq), rtin,
+                                                       (int)(tseq & 1) * (RES_GRAN_MAX * 16) + b * 16, 0,
+                                                       16 /* sc1 */);
+            if (tid < 4) sm[oPUB + tid] = sm[oR3 + 40 + tid];
+            RES_HANDOFF3({ sm[oE3L + j] = v; }, 0, dum0);
+            double hv[4];
+            int st = 0;
+            if (!dead) st = res_wait_slow<4>(rtout, tseq, N3, D.tmo, nullptr, hv);
+            if (st) {
+                *fail = 1;
+                if (lane == 0) __hip_atomic_store(D.tmo, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = tid + u * BT;
+                if (j < N3 && !dead && !st) sm[oE3L + j] = sm[oE3L + j] + hv[u];     // e' + P4 e_4    :31
+            }
+            __syncthreads();
+            if (*fail) dead = true;
+            poly3_rows(4);                                                            // e'' = M2a r + M1 (e' + P4 e_4)
+            if (tid < 4) sm[oPUB + tid] = sm[oR3 + 40 + tid];
+            RES_HANDOFF3({ sm[oE3L + j] = v; }, 0, dum0);
+            (void)keep;
+        } else if (THREE) {
             const int nu = D.nu;
             for (int s = 0; s < nu; ++s) sweep3(!keep && s == 0);
             {   // rr = r - A e                                                       MG_Vcycle.m:27
@@ -970,6 +1046,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
                 double sumr = 0.0;
                 RES_HANDOFF3({ sm[oR3L + j] = v; sm[oE3L + j] = 0.0; p0 += v; }, (nsp ? 1 : 0), sumr);
                 c3s = nsp ? sumr / xx3 : 0.0;
+                sumr3 = sumr;
             }
             for (int leg = 0; leg < (D.wcycle ? 2 : 1); ++leg) visit3(leg == 1);   // MG_Wcycle.m:28-30
             {   // e_2 += P3 e_3                                                     MG_Vcycle.m:31
