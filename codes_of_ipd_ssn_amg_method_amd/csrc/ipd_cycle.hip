@@ -2680,10 +2680,12 @@ __global__ __launch_bounds__(BT) void k_pack_poly(const PolyEntry* __restrict__ 
 
 // Block-wide polynomial form of a 33..144-row level (SolveLevel::gM): the recurrences of k_pack_poly
 // as dense products on the f64 matrix cores.  All operands live in global scratch, column-major, padded
-// with zeros to multiples of 16 (Np rows; no edge cases in the tiles); the state [M2a | M1 | w] is ONE
-// matrix X of 2 Np + 16 columns, so a sweep is X <- S X + [D^-1 | 0 | u].  One wave per 16 x 16 tile
+// with zeros to multiples of 16 (Np rows; no edge cases in the tiles).  M1 = S^nu by nu - 1 products
+// S^j = S S^(j-1); their running sum I + S + ... + S^(nu-1) gives M2a (columns scaled by D^-1) and w
+// (applied to u).  Y = [sum | S^nu | w, 15 zero columns] is one matrix of 2 Np + 16 columns, so that the
+// rows below N of the output are one more product, T1 Y.  One wave per 16 x 16 tile
 // (v_mfma_f64_16x16x4_f64: lane l holds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; result
-// register g of lane l is C[(l >> 4) + 4 g][l & 15]), the operand loads of 16 k-steps in flight.
+// register g of lane l is C[(l >> 4) + 4 g][l & 15]), the operand loads of 64 k in flight.
 struct BPolyEntry {
     const int* Arp;
     const int* Aci;
@@ -2699,7 +2701,8 @@ struct BPolyEntry {
     double* S;    // Np x Np
     double* P;    // Np x Ncp
     double* T1;   // Ncp x Np = P'A
-    double* X[2]; // Np x (2 Np + 16): [M2a | M1 | w, 15 zero columns]
+    double* Pw[2]; // Np x Np: the powers of S, ping-pong
+    double* Y;     // Np x (2 Np + 16): [I + S + ... + S^(nu-1) | S^nu | w, 15 zero columns]
     double* dv;
     double* u;
     double* cs;   // column sums of A
@@ -2711,50 +2714,91 @@ struct BPolyEntry {
     double* rows;
 };
 typedef double bp_d4 __attribute__((ext_vector_type(4)));
+// (the k index of MFMA u in a group of four is k0 + 4 (l >> 4) + u, not k0 + 4 u + (l >> 4): a lane's four
+// B values are then 32 contiguous bytes and the four lanes of a column share one 128-byte line -- with
+// the natural order every load touched sixteen lines for 32 bytes each and a product of 288^3 took 14 us)
+// One tile per WORKGROUP: wave w takes the 16-k groups w, w + 4, ... (a product is a chain of dependent
+// batches of loads otherwise: 288 / 64 = 5 round trips to L2), the four partial tiles are added in wave
+// order through LDS; the sum is returned to wave 0 only.
 __device__ __forceinline__ bp_d4 bp_tile(const double* __restrict__ A, int a_is, int a_ks,
                                          const double* __restrict__ B, int b_ks, int b_js, int K, int I0, int J0) {
-    const int l = threadIdx.x & 63, r = l & 15, q = l >> 4;
-    const double* ap = A + (size_t)(I0 + r) * a_is + (size_t)q * a_ks;
-    const double* bp = B + (size_t)q * b_ks + (size_t)(J0 + r) * b_js;
+    typedef double bp_v2 __attribute__((ext_vector_type(2)));
+    __shared__ double bp_part[3][4][64];
+    const int l = threadIdx.x & 63, r = l & 15, q = l >> 4, wv = threadIdx.x >> 6;
+    const double* ap = A + (size_t)(I0 + r) * a_is + (size_t)(4 * q) * a_ks;
+    const double* bp = B + (size_t)(4 * q) * b_ks + (size_t)(J0 + r) * b_js;   // b_ks == 1
     bp_d4 c = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < K; k0 += 64) {
+    for (int k0 = 0; k0 < K; k0 += 256) {
         double a[16], b[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int k = k0 + 4 * u;
-            const bool in = k < K;   // uniform
-            a[u] = in ? ap[(size_t)k * a_ks] : 0.0;
-            b[u] = in ? bp[(size_t)k * b_ks] : 0.0;
+        for (int g = 0; g < 4; ++g) {
+            const int k = k0 + 16 * (4 * g + wv);
+            const bool in = k < K;   // uniform (K is a multiple of 16)
+            if (in) {
+                const bp_v2 b01 = *reinterpret_cast<const bp_v2*>(bp + k);
+                const bp_v2 b23 = *reinterpret_cast<const bp_v2*>(bp + k + 2);
+                b[4 * g] = b01.x;
+                b[4 * g + 1] = b01.y;
+                b[4 * g + 2] = b23.x;
+                b[4 * g + 3] = b23.y;
+                if (a_ks == 1) {
+                    const bp_v2 a01 = *reinterpret_cast<const bp_v2*>(ap + k);
+                    const bp_v2 a23 = *reinterpret_cast<const bp_v2*>(ap + k + 2);
+                    a[4 * g] = a01.x;
+                    a[4 * g + 1] = a01.y;
+                    a[4 * g + 2] = a23.x;
+                    a[4 * g + 3] = a23.y;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[4 * g + u] = ap[(size_t)(k + u) * a_ks];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[4 * g + u] = b[4 * g + u] = 0.0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (k0 + 4 * u < K) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], c, 0, 0, 0);
+            if (k0 + 16 * (4 * (u / 4) + wv) < K) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], c, 0, 0, 0);
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bp_part[wv - 1][g][l] = c[g];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int ww = 0; ww < 3; ++ww)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) c[g] += bp_part[ww][g][l];
     }
     return c;
 }
 // dense copies of A and P, D^-1, u, and the parts of the state after the first sweep that are not S:
 // M2a = D^-1, w = u
-__global__ __launch_bounds__(256) void k_bpoly_scatter(const BPolyEntry e) {
-    const int r = blockIdx.x * 256 + threadIdx.x, Np = e.Np;
+__global__ __launch_bounds__(256) void k_bpoly_scatter(const BPolyEntry e) {   // one wave per row
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, Np = e.Np;
     if (r >= e.N) return;
-    for (int q = e.Arp[r]; q < e.Arp[r + 1]; ++q) e.A[r + (size_t)e.Aci[q] * Np] = e.Ava[q];
-    for (int q = e.Prp[r]; q < e.Prp[r + 1]; ++q) e.P[r + (size_t)e.Pci[q] * Np] = e.Pva[q];
-    const double d = e.dinv[r];
-    const double ui = e.isnsp ? (1.0 - d * e.Axi[r]) / e.xx[0] : 0.0;
-    e.dv[r] = d;
-    e.u[r] = ui;
-    e.X[0][r + (size_t)r * Np] = d;
-    e.X[0][r + (size_t)(2 * Np) * Np] = ui;
+    for (int q = e.Arp[r] + lane; q < e.Arp[r + 1]; q += 64) e.A[r + (size_t)e.Aci[q] * Np] = e.Ava[q];
+    for (int q = e.Prp[r] + lane; q < e.Prp[r + 1]; q += 64) e.P[r + (size_t)e.Pci[q] * Np] = e.Pva[q];
+    if (lane == 0) {
+        const double d = e.dinv[r];
+        const double ui = e.isnsp ? (1.0 - d * e.Axi[r]) / e.xx[0] : 0.0;
+        e.dv[r] = d;
+        e.u[r] = ui;
+        if (e.nu == 1) e.Y[r + (size_t)(2 * Np) * Np] = ui;   // w = u
+    }
 }
-__global__ __launch_bounds__(64) void k_bpoly_colsum(const BPolyEntry e) {
-    const int j = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_bpoly_colsum(const BPolyEntry e) {   // one wave per column
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= e.N) return;
     const double* aj = e.A + (size_t)j * e.Np;
     double cs = 0.0;
-    for (int k = 0; k < e.N; ++k) cs += aj[k];
-    e.cs[j] = cs;
+    for (int k = lane; k < e.N; k += 64) cs += aj[k];
+    cs = wave_sum(cs);
+    if (lane == 0) e.cs[j] = cs;
 }
-// S = I - Rg A with (Rg A)[i][j] = dinv_i A[i][j] + u_i (1'A)_j, also M1 = S after the first sweep
+// S = I - Rg A with (Rg A)[i][j] = dinv_i A[i][j] + u_i (1'A)_j, the first power and the sum so far
 // (blocks below nS: one thread per entry); T1 = P'A (the tiles behind)
 __global__ __launch_bounds__(256) void k_bpoly_S_T1(const BPolyEntry e, int nS) {
     const int N = e.N, Np = e.Np;
@@ -2762,42 +2806,51 @@ __global__ __launch_bounds__(256) void k_bpoly_S_T1(const BPolyEntry e, int nS) 
         const int q = blockIdx.x * 256 + threadIdx.x;
         if (q >= N * N) return;
         const int i = q % N, j = q / N;
-        const double* aj = e.A + (size_t)j * Np;
-        const double sv = (i == j ? 1.0 : 0.0) - (e.dv[i] * aj[i] + e.u[i] * e.cs[j]);
-        e.S[i + (size_t)j * Np] = sv;
-        e.X[0][i + (size_t)(Np + j) * Np] = sv;
+        const size_t at = i + (size_t)j * Np;
+        const double id = i == j ? 1.0 : 0.0;
+        const double sv = id - (e.dv[i] * e.A[at] + e.u[i] * e.cs[j]);
+        e.S[at] = sv;
+        e.Pw[0][at] = sv;
+        e.Y[at] = e.nu >= 2 ? id + sv : id;
+        if (e.nu == 1) e.Y[at + (size_t)Np * Np] = sv;
         return;
     }
-    const int tile = ((int)blockIdx.x - nS) * 4 + (threadIdx.x >> 6), nj = Np / 16, ni = e.Ncp / 16;
-    if (tile >= ni * nj) return;
+    const int tile = (int)blockIdx.x - nS, ni = e.Ncp / 16;
     const int I0 = 16 * (tile % ni), J0 = 16 * (tile / ni), l = threadIdx.x & 63;
     const bp_d4 c = bp_tile(e.P, Np, 1, e.A, 1, Np, Np, I0, J0);   // A-operand (c, k) = P[k + c Np]
+    if (threadIdx.x >= 64) return;
     for (int g = 0; g < 4; ++g) e.T1[(I0 + (l >> 4) + 4 * g) + (size_t)(J0 + (l & 15)) * e.Ncp] = c[g];
 }
-// X[dst] = S X[src] + [D^-1 | 0 | u]
-__global__ __launch_bounds__(256) void k_bpoly_step(const BPolyEntry e, int src) {
-    const int Np = e.Np, ni = Np / 16, nj = (2 * Np + 16) / 16;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
-    if (tile >= ni * nj) return;
+// S^s = S S^(s-1) (s = 2 .. nu; the last one lands in Y's second block), added to the sum while s < nu;
+// beside the last product: w = (I + ... + S^(nu-1)) u, one wave per row
+__global__ __launch_bounds__(256) void k_bpoly_step(const BPolyEntry e, int s, int src, int nT) {
+    const int Np = e.Np, ni = Np / 16, l = threadIdx.x & 63;
+    if ((int)blockIdx.x >= nT) {
+        const int i = ((int)blockIdx.x - nT) * 4 + (threadIdx.x >> 6);
+        if (i >= e.N) return;
+        double acc = 0.0;
+        for (int j = l; j < e.N; j += 64) acc += e.Y[i + (size_t)j * Np] * e.u[j];
+        acc = wave_sum(acc);
+        if (l == 0) e.Y[i + (size_t)(2 * Np) * Np] = acc;
+        return;
+    }
+    const int tile = blockIdx.x;
     const int I0 = 16 * (tile % ni), J0 = 16 * (tile / ni);
-    const bp_d4 c = bp_tile(e.S, 1, Np, e.X[src], 1, Np, Np, I0, J0);
-    double* dst = e.X[src ^ 1];
+    const bp_d4 c = bp_tile(e.S, 1, Np, e.Pw[src], 1, Np, Np, I0, J0);
+    if (threadIdx.x >= 64) return;
+    double* dst = s == e.nu ? e.Y + (size_t)Np * Np : e.Pw[src ^ 1];
     const int j = J0 + (l & 15);
     for (int g = 0; g < 4; ++g) {
-        const int i = I0 + (l >> 4) + 4 * g;
-        double v = c[g];
-        if (i < e.N) {
-            if (j == i) v += e.dv[i];
-            if (j == 2 * Np) v += e.u[i];
-        }
-        dst[i + (size_t)j * Np] = v;
+        const size_t at = (size_t)(I0 + (l >> 4) + 4 * g) + (size_t)j * Np;
+        dst[at] = c[g];
+        if (s < e.nu) e.Y[at] += c[g];
     }
 }
-// the stacked output: rows below N from -T1 X (+ P' in the Mr block), Mc = M1 P, copies above
-__global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int fin, int nZ, int nC) {
+// the stacked output: rows below N from -T1 Y (+ P' in the Mr block), Mc = M1 P, copies above
+__global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int nZ, int nC) {
     const int N = e.N, Nc = e.Nc, Np = e.Np, Ncp = e.Ncp, LD = e.LD, l = threadIdx.x & 63;
     const int N8 = (N + 7) / 8 * 8;
-    const double* X = e.X[fin];
+    const double* Y = e.Y;
     auto put = [&](int row, bool me, int j, double v) {
         if (e.rows)
             e.rows[(size_t)row * 1024 + (me ? 512 : 0) + j] = v;
@@ -2805,17 +2858,17 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int fin
             e.M[row + (size_t)((me ? N8 : 0) + j) * LD] = v;
     };
     int blk = blockIdx.x;
-    if (blk < nZ) {   // Z = T1 X: Ncp x (2 Np + 16)
-        const int ni = Ncp / 16, nj = (2 * Np + 16) / 16, tile = blk * 4 + (threadIdx.x >> 6);
-        if (tile >= ni * nj) return;
+    if (blk < nZ) {   // Z = T1 Y: Ncp x (2 Np + 16)
+        const int ni = Ncp / 16, tile = blk;
         const int I0 = 16 * (tile % ni), J0 = 16 * (tile / ni);
-        const bp_d4 c = bp_tile(e.T1, 1, Ncp, X, 1, Np, Np, I0, J0);
+        const bp_d4 c = bp_tile(e.T1, 1, Ncp, Y, 1, Np, Np, I0, J0);
+        if (threadIdx.x >= 64) return;
         const int j = J0 + (l & 15);
         for (int g = 0; g < 4; ++g) {
             const int cc = I0 + (l >> 4) + 4 * g;
             if (cc >= Nc) continue;
             if (j < Np) {
-                if (j < N) put(N + cc, false, j, e.P[j + (size_t)cc * Np] - c[g]);
+                if (j < N) put(N + cc, false, j, e.P[j + (size_t)cc * Np] - c[g] * e.dv[j]);
             } else if (j < 2 * Np) {
                 if (j - Np < N) put(N + cc, true, j - Np, -c[g]);
             } else if (j == 2 * Np) {
@@ -2827,10 +2880,10 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int fin
     blk -= nZ;
     if (blk < nC) {   // Mc = M1 P: Np x Ncp
         if (e.rows) return;
-        const int ni = Np / 16, nj = Ncp / 16, tile = blk * 4 + (threadIdx.x >> 6);
-        if (tile >= ni * nj) return;
+        const int ni = Np / 16, tile = blk;
         const int I0 = 16 * (tile % ni), J0 = 16 * (tile / ni);
-        const bp_d4 c = bp_tile(X + (size_t)Np * Np, 1, Np, e.P, 1, Np, Np, I0, J0);
+        const bp_d4 c = bp_tile(Y + (size_t)Np * Np, 1, Np, e.P, 1, Np, Np, I0, J0);
+        if (threadIdx.x >= 64) return;
         const int j = J0 + (l & 15);
         for (int g = 0; g < 4; ++g) {
             const int i = I0 + (l >> 4) + 4 * g;
@@ -2839,14 +2892,14 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int fin
         return;
     }
     blk -= nC;
-    const int q = blk * 256 + threadIdx.x;   // copies: M2a, M1, w
+    const int q = blk * 256 + threadIdx.x;   // copies: M2a = sum D^-1, M1, w
     if (q < N * N) {
         const int i = q % N, j = q / N;
-        put(i, false, j, X[i + (size_t)j * Np]);
-        put(i, true, j, X[i + (size_t)(Np + j) * Np]);
+        put(i, false, j, Y[i + (size_t)j * Np] * e.dv[j]);
+        put(i, true, j, Y[i + (size_t)(Np + j) * Np]);
     } else if (q < N * N + N) {
         const int i = q - N * N;
-        e.W[i] = X[i + (size_t)(2 * Np) * Np];
+        e.W[i] = Y[i + (size_t)(2 * Np) * Np];
     }
 }
 

@@ -268,17 +268,18 @@ static BPolyDev pack_bpoly(ipd_ctx* ctx, ipd_amg* h, CycleState* st, int k, int 
     e.nu = h->opts.smoth;
     e.isnsp = isnsp;
     e.LD = LD;
-    // one zeroed block of scratch: A, S, P, T1, X[0], X[1], dv, u, cs
-    const size_t sc = 2 * Np * Np + 2 * Np * Ncp + 2 * Np * xcols + 3 * Np;
+    // one zeroed block of scratch: A, S, P, T1, Pw[0], Pw[1], Y, dv, u, cs
+    const size_t sc = 4 * Np * Np + 2 * Np * Ncp + Np * xcols + 3 * Np;
     double* blk = ctx->scratch->alloc<double>(sc);
     IPD_HIP(hipMemsetAsync(blk, 0, sc * sizeof(double), ctx->stream));
     e.A = blk;
     e.S = e.A + Np * Np;
     e.P = e.S + Np * Np;
     e.T1 = e.P + Np * Ncp;
-    e.X[0] = e.T1 + Np * Ncp;
-    e.X[1] = e.X[0] + Np * xcols;
-    e.dv = e.X[1] + Np * xcols;
+    e.Pw[0] = e.T1 + Np * Ncp;
+    e.Pw[1] = e.Pw[0] + Np * Np;
+    e.Y = e.Pw[1] + Np * Np;
+    e.dv = e.Y + Np * xcols;
     e.u = e.dv + Np;
     e.cs = e.u + Np;
     const size_t ncols = 2 * N8 + Nc8;
@@ -290,23 +291,24 @@ static BPolyDev pack_bpoly(ipd_ctx* ctx, ipd_amg* h, CycleState* st, int k, int 
     e.M = b.M;
     e.W = b.W;
     e.rows = rows ? b.M : nullptr;
-    hipLaunchKernelGGL(k_bpoly_scatter, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, e);
+    hipLaunchKernelGGL(k_bpoly_scatter, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream, e);
     IPD_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_bpoly_colsum, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, ctx->stream, e);
+    hipLaunchKernelGGL(k_bpoly_colsum, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream, e);
     IPD_KERNEL_CHECK();
-    const int nS = (int)((N * N + 255) / 256), nT1 = (int)(((Ncp / 16) * (Np / 16) + 3) / 4);
+    const int nS = (int)((N * N + 255) / 256), nT1 = (int)((Ncp / 16) * (Np / 16));   // one tile per workgroup
     hipLaunchKernelGGL(k_bpoly_S_T1, dim3((unsigned)(nS + nT1)), dim3(256), 0, ctx->stream, e, nS);
     IPD_KERNEL_CHECK();
     int cur = 0;
-    const unsigned step_blocks = (unsigned)(((Np / 16) * (xcols / 16) + 3) / 4);
-    for (int s = 1; s < e.nu; ++s) {
-        hipLaunchKernelGGL(k_bpoly_step, dim3(step_blocks), dim3(256), 0, ctx->stream, e, cur);
+    const int nT = (int)((Np / 16) * (Np / 16));
+    for (int s = 2; s <= e.nu; ++s) {
+        const int nw = s == e.nu ? (int)((N + 3) / 4) : 0;
+        hipLaunchKernelGGL(k_bpoly_step, dim3((unsigned)(nT + nw)), dim3(256), 0, ctx->stream, e, s, cur, nT);
         IPD_KERNEL_CHECK();
         cur ^= 1;
     }
-    const int nZ = (int)(((Ncp / 16) * (xcols / 16) + 3) / 4), nC = (int)(((Np / 16) * (Ncp / 16) + 3) / 4);
+    const int nZ = (int)((Ncp / 16) * (xcols / 16)), nC = (int)((Np / 16) * (Ncp / 16));
     const int nK = (int)((N * N + N + 255) / 256);
-    hipLaunchKernelGGL(k_bpoly_final, dim3((unsigned)(nZ + nC + nK)), dim3(256), 0, ctx->stream, e, cur, nZ, nC);
+    hipLaunchKernelGGL(k_bpoly_final, dim3((unsigned)(nZ + nC + nK)), dim3(256), 0, ctx->stream, e, nZ, nC);
     IPD_KERNEL_CHECK();
     return b;
 }
