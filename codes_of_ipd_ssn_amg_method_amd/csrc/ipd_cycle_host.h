@@ -118,7 +118,10 @@ __global__ void k_level_prepare(int N, int nf, const int* __restrict__ rp,
             dinv[r] = nf > 0 ? 1.0 / dg : 0.5 * (1.0 / dg);
         }
     }
-    if (lane == 0 && longest > 0) atomicMax(maxoff, longest);
+    // (thousands of waves on one address: 35 of the kernel's 41 us were this atomic; most waves find the
+    // maximum already there)
+    if (lane == 0 && longest > 0 && longest > __hip_atomic_load(maxoff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(maxoff, longest);
 }
 
 // All levels of a hierarchy in two launches instead of two per level (the hierarchy is rebuilt at every
@@ -168,7 +171,13 @@ __global__ void k_levels_prepare(const PrepLevels P) {
             P.dinv[k][r] = nf > 0 ? 1.0 / dg : 0.5 * (1.0 / dg);
         }
     }
-    if (lane == 0 && longest > 0) atomicMax(P.maxoff[k], longest);
+    // one atomic per workgroup (one per wave on one address cost 35 of the kernel's 41 us)
+    __shared__ int bmax;
+    if (threadIdx.x == 0) bmax = 0;
+    __syncthreads();
+    if (lane == 0 && longest > 0) atomicMax(&bmax, longest);
+    __syncthreads();
+    if (threadIdx.x == 0 && bmax > 0) atomicMax(P.maxoff[k], bmax);
 }
 __global__ __launch_bounds__(BT) void k_levels_sum(const PrepLevels P) {
     __shared__ double red[16];
@@ -778,7 +787,7 @@ void amg_prepare_levels(ipd_amg* h) {
             prep.Axi[q] = lv.Axi;
             prep.xx[q] = lv.xx;
             prep.maxoff[q] = maxoff + k;
-            prep.first_block[q + 1] = prep.first_block[q] + std::max(1, std::min(cdiv(N, 4), 4096));
+            prep.first_block[q + 1] = prep.first_block[q] + std::max(1, std::min(cdiv(N, 16), 4096));
         } else {
             hipLaunchKernelGGL(k_level_prepare, dim3(std::max(1, std::min(cdiv(N, 4), 4096))), dim3(256),
                                0, ctx->stream, N, lv.nf, lv.A.rp, lv.A.ci, lv.A.va, lv.dinv, lv.Axi,

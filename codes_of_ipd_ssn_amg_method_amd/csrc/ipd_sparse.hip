@@ -559,6 +559,131 @@ __global__ __launch_bounds__(256) void k_dense_rowcount(int nr, int nc, int ld,
     }
 }
 
+// The same product for short rows of Y, one WAVE per output row.  k_spgemm_rows pays three dependent
+// global round trips and a barrier per entry of X's row (a hub row of P' with 300 entries: 85 us).
+// Here the lanes read the metadata of 64 entries at once (column, value, row range of Y), the rows of Y
+// of the next D entries are in flight while the current D are applied, and an entry costs one LDS
+// read-modify-write: the wave's LDS operations execute in program order, so every C(i,j) still
+// receives its terms one at a time in ascending k.  Rows of Y longer than 64 entries finish in a loop.
+__device__ __forceinline__ double sp_readlane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <int D>
+__global__ __launch_bounds__(64) void k_spgemm_rows_w(int nr, int nc, const int* __restrict__ xrp,
+                                                      const int* __restrict__ xci,
+                                                      const double* __restrict__ xva,
+                                                      const int* __restrict__ yrp,
+                                                      const int* __restrict__ yci,
+                                                      const double* __restrict__ yva,
+                                                      double* __restrict__ dense,
+                                                      int* __restrict__ rowcnt,
+                                                      unsigned long long* __restrict__ rowbits) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ unsigned long long touched[4];   // nc <= 16384: at most 256 blocks
+    double* acc = reinterpret_cast<double*>(smem_raw);
+    const int lane = threadIdx.x;
+    const int nb = (nc + 63) >> 6, nw = (nb + 63) >> 6;
+    for (int j = lane; j < nc; j += 64) acc[j] = 0.0;
+    if (lane < 4) touched[lane] = 0ull;
+    __syncthreads();
+    for (int i = blockIdx.x; i < nr; i += gridDim.x) {
+        const int xb = xrp[i], xe = xrp[i + 1];
+        unsigned long long mybits = 0ull;
+        for (int e0 = xb; e0 < xe; e0 += 64) {
+            const int cnt = min(64, xe - e0);
+            const bool mine = lane < cnt;
+            const int kk = mine ? xci[e0 + lane] : 0;
+            const double aa = mine ? xva[e0 + lane] : 0.0;
+            const int yb = yrp[kk];
+            const int yn = mine ? yrp[kk + 1] - yb : 0;
+            int jA[D], jB[D];
+            double vA[D], vB[D];
+            auto load = [&](int u0, int* jj, double* vv) __attribute__((always_inline)) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int u = u0 + d;   // uniform
+                    jj[d] = -1;
+                    vv[d] = 0.0;
+                    if (u < cnt) {
+                        const int b = __builtin_amdgcn_readlane(yb, u), n = __builtin_amdgcn_readlane(yn, u);
+                        if (lane < n) {
+                            jj[d] = yci[b + lane];
+                            vv[d] = yva[b + lane];
+                        }
+                    }
+                }
+            };
+            auto add = [&](int j, double prod) __attribute__((always_inline)) {
+                acc[j] = acc[j] + prod;
+                const unsigned long long bit = 1ull << ((j >> 6) & 63);
+                if (nw == 1)
+                    mybits |= bit;   // (one word: kept per lane, OR-ed over the wave at the end of the row)
+                else if (!(touched[j >> 12] & bit))
+                    atomicOr(&touched[j >> 12], bit);
+            };
+            auto apply = [&](int u0, const int* jj, const double* vv) __attribute__((always_inline)) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int u = u0 + d;   // uniform
+                    if (u < cnt) {
+                        const double a = sp_readlane(aa, u);
+                        if (jj[d] >= 0) add(jj[d], a * vv[d]);
+                        const int n = __builtin_amdgcn_readlane(yn, u);
+                        if (n > 64) {   // the rest of a long row of Y (distinct columns: lane order is free)
+                            const int b = __builtin_amdgcn_readlane(yb, u);
+                            for (int t = b + 64 + lane; t < b + n; t += 64) add(yci[t], a * yva[t]);
+                        }
+                    }
+                }
+            };
+            load(0, jA, vA);
+            for (int u0 = 0; u0 < cnt; u0 += 2 * D) {
+                load(u0 + D, jB, vB);
+                apply(u0, jA, vA);
+                load(u0 + 2 * D, jA, vA);
+                apply(u0 + D, jB, vB);
+            }
+        }
+        // write out, count and re-zero the touched blocks
+        if (nw == 1) {
+            unsigned lo = (unsigned)mybits, hi = (unsigned)(mybits >> 32);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                lo |= __shfl_xor(lo, d);
+                hi |= __shfl_xor(hi, d);
+            }
+            if (lane == 0) touched[0] = ((unsigned long long)hi << 32) | lo;
+        }
+        __syncthreads();
+        int nz = 0;
+        double* drow = dense + (size_t)i * nc;
+        for (int w = 0; w < nw; ++w) {
+            unsigned long long m = touched[w];
+            while (m) {
+                const int b = (w << 6) + __builtin_ctzll(m);
+                m &= m - 1;
+                const int j = (b << 6) + lane;
+                if (j < nc) {
+                    const double v = acc[j];
+                    drow[j] = v;
+                    nz += (v != 0.0);
+                    acc[j] = 0.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d);
+        __syncthreads();
+        if (lane < nw) {
+            rowbits[(size_t)i * nw + lane] = touched[lane];
+            touched[lane] = 0ull;
+        }
+        if (lane == 0) rowcnt[i] = nz;
+        __syncthreads();
+    }
+}
+
 static inline size_t round_up(size_t v, size_t q) { return (v + q - 1) / q * q; }
 
 // Which product kernel is expected to finish first.  The row kernel is a dependent chain per
@@ -630,9 +755,15 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
             const size_t lds = std::max<size_t>((size_t)nc * 8, 16);
             IPD_OPTIN_LDS(ctx, k_spgemm_rows, 128 * 1024);
             const int threads = (Y.nr > 0 && (double)Y.nnz / Y.nr >= 96.0) ? 256 : 64;
-            hipLaunchKernelGGL(k_spgemm_rows, dim3(std::min(nr, 16384)), dim3(threads), lds,
-                               ctx->stream, nr, nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense,
-                               rowcnt, rowbits);
+            const char* nwv = getenv("IPD_NO_SPGEMM_WAVE");
+            if (threads == 64 && !(nwv && nwv[0] == '1')) {
+                IPD_OPTIN_LDS(ctx, k_spgemm_rows_w<8>, 128 * 1024);
+                hipLaunchKernelGGL(k_spgemm_rows_w<8>, dim3(std::min(nr, 16384)), dim3(64), lds, ctx->stream, nr,
+                                   nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense, rowcnt, rowbits);
+            } else
+                hipLaunchKernelGGL(k_spgemm_rows, dim3(std::min(nr, 16384)), dim3(threads), lds,
+                                   ctx->stream, nr, nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense,
+                                   rowcnt, rowbits);
             IPD_KERNEL_CHECK();
         }
     }
