@@ -7,12 +7,14 @@ OUT=gpurun_out
   echo "# (IPD_BENCH_NODBG=1) is the figure to quote, the per-stage figures (with stamps) give proportions; then the same launch"
   echo "# with parts switched off (IPD_DEBUG_SKIP: 1 polynomial passes, 2 coarsest PCG, 4 row walks of the thread-per-row"
   echo "# sweeps, 8 those sweeps altogether, 15 all of it) and with the round's changes switched off one by one."
-  for k in 30 20; do
+  for k in 30 20 9; do
     echo "== APD iteration $((k+1))"
     IPD_DEBUG_SWEEP=1 python tools/ubench_subcycle.py 1024 $k 2>&1 | tail -3
     for m in 0 1 2 4 8 15; do
       echo "   skip $m: $(IPD_BENCH_NODBG=1 IPD_DEBUG_SKIP=$m python tools/ubench_subcycle.py 1024 $k 2>&1 | tail -1 | cut -c1-44)"
     done
+    echo "   IPD_NO_BPOLY=1:           $(IPD_BENCH_NODBG=1 IPD_NO_BPOLY=1 python tools/ubench_subcycle.py 1024 $k 2>&1 | tail -1 | cut -c1-44)"
+    echo "   IPD_NO_BPOLY=1 IPD_NO_LPOLY=1 (first half of round 3): $(IPD_BENCH_NODBG=1 IPD_NO_BPOLY=1 IPD_NO_LPOLY=1 IPD_NO_BLKDENSE=1 python tools/ubench_subcycle.py 1024 $k 2>&1 | tail -1 | cut -c1-44)"
     echo "   IPD_NO_POLY=1:            $(IPD_BENCH_NODBG=1 IPD_NO_POLY=1 python tools/ubench_subcycle.py 1024 $k 2>&1 | tail -1 | cut -c1-44)"
     echo "   IPD_NO_LMAP=1:            $(IPD_BENCH_NODBG=1 IPD_NO_LMAP=1 python tools/ubench_subcycle.py 1024 $k 2>&1 | tail -1 | cut -c1-44)"
     echo "   IPD_NO_POLY=1 IPD_NO_LMAP=1 (round 2's sweeps): $(IPD_BENCH_NODBG=1 IPD_NO_POLY=1 IPD_NO_LMAP=1 python tools/ubench_subcycle.py 1024 $k 2>&1 | tail -1 | cut -c1-44)"
