@@ -397,6 +397,16 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
         // Four levels with a level 3 too big for any LDS image and a coarsest level of at most 64 rows
         // (dense masks early in a run, the bench's tree / hub masks): level 3 resident, level 4 solved
         // by every workgroup as the local tail -- no tail workgroup.
+        // (a V cycle visits the tail once: there the local tail stays ahead of a tail workgroup rooted at a
+        // level 3 in block-wide polynomial form -- tree mask 0.096 against 0.102 ms; a W cycle is the other
+        // way round, 0.198 against 0.191)
+        if (remote && !three && h->J == 4 && h->opts.cycle == 'v' && !(n3 && n3[0] == '1') &&
+            h->L[4].A.nr <= RES_TAIL_MAX) {
+            const int S3 = st->run[3].dev.S > 0 ? st->run[3].dev.S : (st->run[3].maxoff + 3) / 4 * 4;
+            if (S3 > 0 && S3 <= 512 && Nt <= BT && N2 <= RES_NMAX / 2 && std::max(d1.S, d2.S) <= 512 &&
+                Nt + std::max(cdiv(std::max(nf, nc), RES_WAVES), cdiv(N2, RES_WAVES)) <= 2 * BT)
+                remote = false;
+        }
         if (!remote && !(nr && nr[0] == '1') && !(n3 && n3[0] == '1') && h->J == 4 && cyc &&
             h->L[4].A.nr <= RES_TAIL_MAX) {
             const int S3 = st->run[3].dev.S > 0 ? st->run[3].dev.S : (st->run[3].maxoff + 3) / 4 * 4;
@@ -974,7 +984,7 @@ void amg_prepare_levels(ipd_amg* h) {
                     !(std::getenv("IPD_NO_BLK") && std::getenv("IPD_NO_BLK")[0] == '1');
     // (polynomial form: a level whose stacked operator [e'; r_c] has more than 32 rows -- one lane per row in
     // a single wave -- runs block-wide instead, out of LDS all the same: is_lpoly below)
-    const bool use_lpoly = !(std::getenv("IPD_NO_LPOLY") && std::getenv("IPD_NO_LPOLY")[0] == '1') &&
+    bool use_lpoly = !(std::getenv("IPD_NO_LPOLY") && std::getenv("IPD_NO_LPOLY")[0] == '1') &&
                            !(std::getenv("IPD_NO_BLK") && std::getenv("IPD_NO_BLK")[0] == '1');
     auto find_tiny_lo = [&](int rows_max) {
         int lo = h->J + 1;
@@ -1083,9 +1093,20 @@ void amg_prepare_levels(ipd_amg* h) {
         const int lo_poly = tiny_lo;
         use_poly = false;
         tiny_lo = find_tiny_lo(32);
-        if (with_poly <= plan_lds(16, &u)) {
+        const int without = plan_lds(16, &u);
+        if (with_poly <= without) {
             use_poly = true;
             tiny_lo = lo_poly;
+        } else if (use_lpoly) {
+            // the block-wide form out of LDS pads its operators to 64 rows: where that is what does not
+            // fit, the one-wave form (48 rows) may still
+            use_lpoly = false;
+            use_poly = true;
+            tiny_lo = find_tiny_lo(48);
+            if (plan_lds(16, &u) > without) {
+                use_poly = false;
+                tiny_lo = find_tiny_lo(32);
+            }
         }
     }
     auto tiny_from = [&](int k_lds) {   // tiny levels: <= 32 rows, cached, Jacobi (k >= 2)

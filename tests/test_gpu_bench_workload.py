@@ -286,7 +286,8 @@ def test_tree_mask_three_resident_levels_with_a_local_tail(ipd, cycle, bpoly):
     mode, grid, _ = solve_mode(h)
     lev, root = c_int32(), c_int32()
     _lib.check(_lib.lib.ipd_amg_resident_levels(h.handle, byref(lev), byref(root)))
-    assert (mode, grid, lev.value) == ((2, 129, 2) if bpoly else (2, 128, 3)), (mode, grid, lev.value)
+    # (a V cycle keeps the local tail either way: plan_resident)
+    assert (mode, grid, lev.value) == ((2, 129, 2) if (bpoly and cycle == "w") else (2, 128, 3)), (mode, grid, lev.value)
     x, it, rel, relk, rhok = h.solve(f, guess)
     assert solve_mode(h)[2] == 0
     xc, itc, relc, relkc, rhokc = hc.solve(f, guess)

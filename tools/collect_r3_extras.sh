@@ -3,7 +3,7 @@
 OUT=gpurun_out
 {
   echo "# tools/ubench_subcycle.py: one launch of the single-workgroup sub-cycle kernel (one W leg rooted at k_sub) on Newton"
-  echo "# systems captured from the m=n=1024 Class 1 driver run at APD iteration 31 / 21; 'us per launch' without stamps"
+  echo "# systems captured from the m=n=1024 Class 1 driver run at APD iterations 31 / 21 / 10; 'us per launch' without stamps"
   echo "# (IPD_BENCH_NODBG=1) is the figure to quote, the per-stage figures (with stamps) give proportions; then the same launch"
   echo "# with parts switched off (IPD_DEBUG_SKIP: 1 polynomial passes, 2 coarsest PCG, 4 row walks of the thread-per-row"
   echo "# sweeps, 8 those sweeps altogether, 15 all of it) and with the round's changes switched off one by one."
