@@ -2708,9 +2708,9 @@ struct BPolyEntry {
     double* cs;   // column sums of A
     double* M;    // out: [Mr | Me | Mc], LD rows, 8-padded column counts (zeroed by the host)
     double* W;    // out: LD
-    // out, instead of M: row-major [N + Nc][1024] with Mr in columns 0..N-1 and Me in 512..512+N-1, no
-    // Mc (the resident kernels' third level: a thread holds entries t and 512 + t of its workgroup's
-    // rows, ipd_resident.h POLY3); W then has N + Nc entries
+    // out, instead of M: row-major [N + Nc][RES_P3_LD] with Mr in columns 0..N-1, Me in 512..512+N-1
+    // and Mc in 1024..1024+Nc-1 (the resident kernels' third level: a thread holds entries t, 512 + t
+    // and 1024 + t of its workgroup's rows, ipd_resident.h POLY3); W then has N + Nc entries
     double* rows;
 };
 typedef double bp_d4 __attribute__((ext_vector_type(4)));
@@ -2853,7 +2853,7 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int nZ,
     const double* Y = e.Y;
     auto put = [&](int row, bool me, int j, double v) {
         if (e.rows)
-            e.rows[(size_t)row * 1024 + (me ? 512 : 0) + j] = v;
+            e.rows[(size_t)row * 1152 + (me ? 512 : 0) + j] = v;
         else
             e.M[row + (size_t)((me ? N8 : 0) + j) * LD] = v;
     };
@@ -2879,7 +2879,6 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int nZ,
     }
     blk -= nZ;
     if (blk < nC) {   // Mc = M1 P: Np x Ncp
-        if (e.rows) return;
         const int ni = Np / 16, tile = blk;
         const int I0 = 16 * (tile % ni), J0 = 16 * (tile / ni);
         const bp_d4 c = bp_tile(Y + (size_t)Np * Np, 1, Np, e.P, 1, Np, Np, I0, J0);
@@ -2887,7 +2886,12 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int nZ,
         const int j = J0 + (l & 15);
         for (int g = 0; g < 4; ++g) {
             const int i = I0 + (l >> 4) + 4 * g;
-            if (i < N && j < Nc) e.M[i + (size_t)(2 * N8 + j) * LD] = c[g];
+            if (i < N && j < Nc) {
+                if (e.rows)
+                    e.rows[(size_t)i * 1152 + 1024 + j] = c[g];
+                else
+                    e.M[i + (size_t)(2 * N8 + j) * LD] = c[g];
+            }
         }
         return;
     }

@@ -292,10 +292,10 @@ static BPolyDev pack_bpoly(ipd_ctx* ctx, ipd_amg* h, CycleState* st, int k, int 
     e.u = e.dv + Np;
     e.cs = e.u + Np;
     const size_t ncols = 2 * N8 + Nc8;
-    const size_t out = rows ? (N + Nc) * 1024 + (N + Nc) : (size_t)LD * (ncols + 1);
+    const size_t out = rows ? (N + Nc) * (size_t)RES_P3_LD + (N + Nc) : (size_t)LD * (ncols + 1);
     b.LD = LD;
     b.M = ar.alloc<double>(out);
-    b.W = rows ? b.M + (N + Nc) * 1024 : b.M + (size_t)LD * ncols;
+    b.W = rows ? b.M + (N + Nc) * (size_t)RES_P3_LD : b.M + (size_t)LD * ncols;
     IPD_HIP(hipMemsetAsync(b.M, 0, out * sizeof(double), ctx->stream));
     e.M = b.M;
     e.W = b.W;
@@ -432,7 +432,7 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     if (three && Nt + G > 2 * BT) return;        // level-3 hand-offs: N3 + G granules, two per thread
     // level 3 in polynomial form (ResDesc::p3rows): remote tail, one restriction row per workgroup at most,
     // at most four rows of level 3 per workgroup
-    const bool poly3 = three && remote && h->opts.smoth >= 1 && h->L[4].A.nr <= G && Nt <= 4 * G && Nt <= BT &&
+    const bool poly3 = three && remote && h->opts.smoth >= 1 && h->L[4].A.nr <= G && h->L[4].A.nr <= 128 && Nt <= 4 * G && Nt <= BT &&
                        !(std::getenv("IPD_NO_RES_POLY3") && std::getenv("IPD_NO_RES_POLY3")[0] == '1') &&
                        !(std::getenv("IPD_NO_POLY") && std::getenv("IPD_NO_POLY")[0] == '1');
     if (poly3) ke3 = 1;
@@ -1517,6 +1517,7 @@ void amg_prepare_levels(ipd_amg* h) {
     // thirteen) the same holds wherever that form applies, semi-cached root or not: 0.33-0.36 -> see DESIGN.
     const bool poly3_likely =
         h->J >= 5 && h->opts.smoth >= 1 && h->L[1].nf > 0 &&
+        h->L[4].A.nr <= 128 &&
         h->L[4].A.nr <= std::max(cdiv(std::max(h->L[1].nf, h->L[1].A.nr - h->L[1].nf), RES_WAVES), cdiv(h->L[2].A.nr, RES_WAVES)) &&
         !(std::getenv("IPD_NO_RES_POLY3") && std::getenv("IPD_NO_RES_POLY3")[0] == '1') &&
         !(std::getenv("IPD_NO_POLY") && std::getenv("IPD_NO_POLY")[0] == '1');

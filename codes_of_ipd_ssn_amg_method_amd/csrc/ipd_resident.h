@@ -43,6 +43,7 @@ static constexpr int RES_NMAX = 4 * BT;        // rows per level (fixed LDS slot
 static constexpr int RES_GRAN_MAX = RES_NMAX;  // granules per hand-off buffer
 static constexpr size_t RES_LDS_BYTES = sizeof(double) * ((size_t)9 * RES_NMAX + RES_NMAX / 2 + 3 * RES_TAIL_MAX + 16 * RES_WAVES + 12);
 static constexpr unsigned RES_SPIN_MAX = 1u << 18;
+static constexpr int RES_P3_LD = 1152;         // row stride of ResDesc::p3rows: 512 + 512 + 128
 
 struct ResLevelDesc {
     int N, nf, S;
@@ -70,9 +71,11 @@ struct ResDesc {
     int tail_root;    // remote tail: 3 or 4
     // Level 3 in polynomial form (template argument KE3 == 1, remote tail only; pack_bpoly with rows):
     // row i < N3 of p3rows is [M2a | M1](i,:) and row N3 + c is the restriction row c stacked on it,
-    // entries 0..N3-1 applied to r_3 and 512..512+N3-1 to e_3; p3w their factors of 1'r_3.  A visit of
-    // level 3 is then THREE hand-offs (e' and the restricted residual; the tail's answer; e'') instead of
-    // thirteen (ten sweeps, the residual, the restriction, the prolongation).
+    // entries 0..N3-1 applied to r_3, 512..512+N3-1 to e_3 and (rows < N3) 1024..1024+N4-1 = (M1 P4)(i,:)
+    // to the tail's e_4 (row stride RES_P3_LD); p3w their factors of 1'r_3.  A visit of level 3 is then
+    // THREE hand-offs (e' and the restricted residual; the tail's answer e_4 -- the tail workgroup does not
+    // prolongate in this mode --; e'') instead of thirteen (ten sweeps, the residual, the restriction, the
+    // prolongation).
     const double* p3rows;
     const double* p3w;
     // Remote tail (hierarchies with more than three levels): workgroup gridDim.x - 1 holds the LDS
@@ -365,6 +368,10 @@ __device__ __forceinline__ void res_tail_workgroup(const ResDesc& D, char* dyn_r
         }
         const double* e3 = sol_e(c, k0);
         const int base = (int)(tseq & 1) * (RES_GRAN_MAX * 16);
+        if (D.p3rows) {   // polynomial level 3: its workgroups apply M1 P4 themselves, the answer is e_4
+            if (tid < N3)
+                __builtin_amdgcn_raw_buffer_store_b128(res_pack(e3[tid], tseq), rout, base + tid * 16, 0, 16 /* sc1 */);
+        } else
         for (int j = tid; j < N2; j += BT) {   // e_2 += P e_3 is finished by the receivers     MG_Vcycle.m:31
             double sd = 0.0;
             for (int t = Pout.rp[j]; t < Pout.rp[j + 1]; ++t) sd += Pout.va[t] * e3[Pout.ci[t]];
@@ -446,18 +453,21 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     if (THREE && !POLY3) res_load_slice<K3>(D.L3, r3, v3, lane, c3, a3);
     // polynomial form: entries tid and 512 + tid of the workgroup's rows lo3..hi3-1 (at most four) and of
     // restriction row b (the remote tail's root level has at most G rows: one per workgroup)
-    double m3r[5], m3e[5];
+    double m3r[5], m3e[5], m3c[4];
 #pragma unroll
     for (int q = 0; q < 5; ++q) m3r[q] = m3e[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m3c[q] = 0.0;
     if (POLY3) {
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
             const int row = q < 4 ? lo3 + q : N3 + b;
             const bool ok = (q < 4 ? row < hi3 : b < Nt) && tid < N3;
             if (ok) {
-                m3r[q] = D.p3rows[(size_t)row * 1024 + tid];
-                m3e[q] = D.p3rows[(size_t)row * 1024 + 512 + tid];
+                m3r[q] = D.p3rows[(size_t)row * RES_P3_LD + tid];
+                m3e[q] = D.p3rows[(size_t)row * RES_P3_LD + 512 + tid];
             }
+            if (q < 4 && row < hi3 && tid < Nt) m3c[q] = D.p3rows[(size_t)row * RES_P3_LD + 1024 + tid];
         }
         if (tid < 5) {
             const int row = tid < 4 ? lo3 + tid : N3 + b;
@@ -965,12 +975,15 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // one visit of level 3 and, through the remote tail rooted at level 4, of everything below it
     // polynomial form: the sums of this workgroup's rows against [r_3; e_3] (+ their factor of 1'r_3)
     // -> sm[oR3 + 40 + q]; the caller's next barrier publishes them
-    auto poly3_rows = [&](int nrows) __attribute__((always_inline)) {
+    auto poly3_rows = [&](int nrows, bool post) __attribute__((always_inline)) {
         const double xr = tid < N3 ? sm[oR3L + tid] : 0.0, xe = tid < N3 ? sm[oE3L + tid] : 0.0;
+        const double xc = (post && tid < Nt) ? sm[oRR3L + tid] : 0.0;
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
             if (q < nrows) {
-                const double pq = wave_sum(__builtin_fma(m3e[q], xe, m3r[q] * xr));
+                double t = __builtin_fma(m3e[q], xe, m3r[q] * xr);
+                if (q < 4) t = __builtin_fma(m3c[q], xc, t);
+                const double pq = wave_sum(t);
                 if (lane == 0) sm[oR3 + 8 * q + w] = pq;
             }
         }
@@ -987,28 +1000,24 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         if (POLY3) {
             ++tseq;
             // e' = M2a r + M1 e and the restricted residual of e' in one pass                 MG_Vcycle.m:20-29
-            poly3_rows(5);
+            poly3_rows(5, false);
             if (tid == 0 && b < Nt)
                 __builtin_amdgcn_raw_buffer_store_b128(res_pack(sm[oR3 + 44], tseq), rtin,
                                                        (int)(tseq & 1) * (RES_GRAN_MAX * 16) + b * 16, 0,
                                                        16 /* sc1 */);
             if (tid < 4) sm[oPUB + tid] = sm[oR3 + 40 + tid];
             RES_HANDOFF3({ sm[oE3L + j] = v; }, 0, dum0);
-            double hv[4];
+            double hv[1];
             int st = 0;
-            if (!dead) st = res_wait_slow<4>(rtout, tseq, N3, D.tmo, nullptr, hv);
+            if (!dead) st = res_wait_slow<1>(rtout, tseq, Nt, D.tmo, nullptr, hv);   // e_4 (Nt <= G <= BT values)
             if (st) {
                 *fail = 1;
                 if (lane == 0) __hip_atomic_store(D.tmo, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = tid + u * BT;
-                if (j < N3 && !dead && !st) sm[oE3L + j] = sm[oE3L + j] + hv[u];     // e' + P4 e_4    :31
-            }
+            if (tid < Nt) sm[oRR3L + tid] = (!dead && !st) ? hv[0] : 0.0;
             __syncthreads();
             if (*fail) dead = true;
-            poly3_rows(4);                                                            // e'' = M2a r + M1 (e' + P4 e_4)
+            poly3_rows(4, true);                                         // e'' = M2a r + M1 e' + (M1 P4) e_4   :31-41
             if (tid < 4) sm[oPUB + tid] = sm[oR3 + 40 + tid];
             RES_HANDOFF3({ sm[oE3L + j] = v; }, 0, dum0);
             (void)keep;
