@@ -44,6 +44,12 @@ struct CycleState {
     SolveDesc* d_sub = nullptr;
     bool sub_semi_root = false;    // d_sub's root level is semi-cached (rows from L2)
     std::vector<int> level_forms;  // per level, over all images packed: see ipd_amg_level_forms
+    struct PolyOp {                // block-wide polynomial operators packed for the images (ipd_amg_poly_operator)
+        const double* M = nullptr;
+        const double* W = nullptr;
+        int LD = 0, N = 0, Nc = 0;
+    };
+    std::vector<PolyOp> poly_ops;
     SolveDesc* d_sub4 = nullptr;   // image rooted at level 4 for the resident kernel's `three` mode
     size_t sub4_lds = 0;           // (packed beside d_sub when that one is rooted at level 3)
     SolveDesc* d_sub3 = nullptr;   // image rooted at level 3 for the resident kernel alone (k_sub == 0)
@@ -1031,7 +1037,16 @@ void amg_prepare_levels(ipd_amg* h) {
     auto ensure_bpoly = [&](int k, int nu, int isnsp) -> const BPolyDev& {
         (void)nu;
         BPolyDev& b = bpoly_dev[(size_t)k];
-        if (!b.M) b = pack_bpoly(ctx, h, st.get(), k, isnsp, bpoly_ld(k), false);
+        if (!b.M) {
+            b = pack_bpoly(ctx, h, st.get(), k, isnsp, bpoly_ld(k), false);
+            st->poly_ops.resize((size_t)h->J + 1);
+            CycleState::PolyOp& po = st->poly_ops[(size_t)k];
+            po.M = b.M;
+            po.W = b.W;
+            po.LD = b.LD;
+            po.N = h->L[k].A.nr;
+            po.Nc = h->L[k + 1].A.nr;
+        }
         return b;
     };
     auto is_bdense = [&](int k) {
@@ -2563,6 +2578,27 @@ extern "C" int ipd_amg_level_forms(const ipd_amg* h, int32_t* forms, int32_t cou
         const CycleState* st = h->cyc.get();
         for (int k = 0; k < count; ++k)
             forms[k] = (st && (size_t)k < st->level_forms.size()) ? st->level_forms[(size_t)k] : 0;
+    });
+}
+
+// Test hook: the block-wide polynomial operator of level k as packed for the images, column-major with
+// *ld rows: columns [Mr (N8) | Me (N8) | Mc (Nc8)] then the column W (N8 = N rounded up to 8); needs
+// ld * (2 N8 + Nc8 + 1) doubles.  IPD_E_ARG when level k has no such operator.
+extern "C" int ipd_amg_poly_operator(const ipd_amg* h, int32_t k, double* out, int64_t cap, int32_t* ld,
+                                     int32_t* n, int32_t* nc) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && out && ld && n && nc, IPD_E_ARG, "NULL argument");
+        const CycleState* st = h->cyc.get();
+        IPD_REQUIRE(st && k >= 1 && (size_t)k < st->poly_ops.size() && st->poly_ops[(size_t)k].M, IPD_E_ARG,
+                    "level has no block-wide polynomial operator");
+        const CycleState::PolyOp& po = st->poly_ops[(size_t)k];
+        const int64_t N8 = (po.N + 7) / 8 * 8, Nc8 = (po.Nc + 7) / 8 * 8;
+        const int64_t need = (int64_t)po.LD * (2 * N8 + Nc8 + 1);
+        IPD_REQUIRE(cap >= need, IPD_E_ARG, "buffer too small");
+        h->ctx->fetch(po.M, out, (size_t)need);   // W lies right behind M (pack_bpoly)
+        *ld = po.LD;
+        *n = po.N;
+        *nc = po.Nc;
     });
 }
 

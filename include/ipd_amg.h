@@ -421,6 +421,13 @@ int ipd_amg_resident_levels(const ipd_amg* h, int32_t* levels, int32_t* tail_roo
  * residual and transfers of a visit as two dense passes), 16 block-wide polynomial form (49..144 rows,
  * operators streamed from L2); 0: in no image (launches or the resident workgroups' registers).      */
 int ipd_amg_level_forms(const ipd_amg* h, int32_t* forms, int32_t count);
+/* Test hook: the block-wide polynomial operator of level k (forms bit 16) as packed for the images:
+ * column-major with *ld rows, columns [Mr (N8) | Me (N8) | Mc (Nc8)] and then the column W, N8 / Nc8 =
+ * *n / *nc rounded up to 8; `out` needs ld * (2 N8 + Nc8 + 1) doubles (cap = its size).  Rows < n:
+ * e' = Mr r + Me e (+ Mc e_c in the second pass) + W 1'r; rows n .. n + nc - 1: the restricted residual
+ * (AMG/MG_Vcycle.m:14-41 as two dense maps).  IPD_E_ARG without such an operator. */
+int ipd_amg_poly_operator(const ipd_amg* h, int32_t k, double* out, int64_t cap, int32_t* ld, int32_t* n,
+                          int32_t* nc);
 /* Mode 2 only: `cycles` loop bodies in one launch with in-kernel stamps of workgroup 0:
  * stamps[0] shader clocks spent waiting in hand-off sweeps, [1] shader clocks of the launch,
  * [2] hand-offs, [3] 100 MHz ticks of the launch, [4] clocks in the barrier ahead of the

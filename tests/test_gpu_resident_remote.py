@@ -243,3 +243,47 @@ def test_amg4pot_as_first_resident_use_in_a_fresh_process():
         "print('ok', it, res)\n") % root
     res = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+def test_block_wide_polynomial_operators_against_numpy(ipd, newton_system):
+    """The operators k_bpoly_* pack on the f64 matrix cores (S^nu by nu - 1 products, the stacked
+    restriction rows by one more) against the numpy restatement of the same algebra, which
+    tests/test_poly_form_algebra.py ties to the oracle's smoothing loops (AMG/MG_Vcycle.m:14-41)."""
+    from ctypes import POINTER, c_double, c_int64
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    from tests.test_poly_form_algebra import stacked_operators
+    Ae, f, n, _ = newton_system
+    opts = options("w", n)
+    h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand(5489))
+    forms = h.level_forms()
+    levels = [k for k in range(1, h.J) if forms[k - 1] & 16]
+    if not levels:
+        pytest.skip("no level of %s in block-wide polynomial form (forms %s)" % (h.level_sizes(), forms))
+    for k in levels:
+        A = h.A(k).toarray()
+        P = h.P(k + 1).toarray()
+        N, Nc = P.shape
+        N8, Nc8 = -(-N // 8) * 8, -(-Nc // 8) * 8
+        cap = 256 * (2 * N8 + Nc8 + 1)
+        buf = np.zeros(cap)
+        ld, nn, nc = c_int32(), c_int32(), c_int32()
+        _lib.check(_lib.lib.ipd_amg_poly_operator(h.handle, c_int32(k), buf.ctypes.data_as(POINTER(c_double)),
+                                                  c_int64(cap), byref(ld), byref(nn), byref(nc)))
+        assert (nn.value, nc.value) == (N, Nc) and ld.value in (128, 256) and N + Nc <= ld.value
+        LD = ld.value
+        M = buf[:LD * (2 * N8 + Nc8 + 1)].reshape(2 * N8 + Nc8 + 1, LD).T     # column-major -> [row, col]
+        ref = stacked_operators(A, P, 0.5 / np.diag(A), opts["isnsp"], opts["smoth"])
+        blocks = {
+            "M2a": (M[:N, :N], ref["M2a"]), "M1": (M[:N, N8:N8 + N], ref["M1"]),
+            "Mc": (M[:N, 2 * N8:2 * N8 + Nc], ref["Mc"]), "w": (M[:N, 2 * N8 + Nc8], ref["w"]),
+            "Mr_low": (M[N:N + Nc, :N], ref["Mr_low"]), "Me_low": (M[N:N + Nc, N8:N8 + N], ref["Me_low"]),
+            "W_low": (M[N:N + Nc, 2 * N8 + Nc8], ref["W_low"]),
+        }
+        for name, (got, want) in blocks.items():
+            # (the rank-one factors w = (I + ... + S^(nu-1)) u and -T1 w carry u ~ 1/xx ~ 1e5 and cancel: the
+            # two summation orders differ by 6e-11 relative on the most ill-conditioned system, k = 31)
+            tol = 1e-9 if name in ("w", "W_low") else 1e-11
+            assert np.abs(got - want).max() <= tol * (1.0 + np.abs(want).max()), (k, name)
+        # the padding the passes rely on is zero
+        assert not M[N + Nc:, :].any() and not M[:, N:N8].any() and not M[:, N8 + N:2 * N8].any()
+    h.close()
