@@ -728,12 +728,11 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
     if (spgemm_prefers_tiles(X, Y, &tile_bytes)) {
         const size_t nrp = round_up((size_t)nr, GT), nkp = round_up((size_t)X.nc, GT),
                      ncp = round_up((size_t)nc, GT);
-        double* xd = tmp.alloc<double>(nrp * nkp);
-        double* yd = tmp.alloc<double>(nkp * ncp);
+        double* xd = tmp.alloc<double>(nrp * nkp + nkp * ncp);   // both operands: one memset
+        double* yd = xd + nrp * nkp;
         dense = tmp.alloc<double>(nrp * ncp);
         ld = (int)ncp;
-        IPD_HIP(hipMemsetAsync(xd, 0, nrp * nkp * 8, ctx->stream));
-        IPD_HIP(hipMemsetAsync(yd, 0, nkp * ncp * 8, ctx->stream));
+        IPD_HIP(hipMemsetAsync(xd, 0, (nrp * nkp + nkp * ncp) * 8, ctx->stream));
         hipLaunchKernelGGL(k_csr_expand, dim3(std::min(cdiv(X.nr, 4), 4096)), dim3(256), 0,
                            ctx->stream, X.nr, (int)nkp, X.rp, X.ci, X.va, xd);
         hipLaunchKernelGGL(k_csr_expand, dim3(std::min(cdiv(Y.nr, 4), 4096)), dim3(256), 0,
