@@ -243,7 +243,9 @@ void csr_download_as_csc(ipd_ctx* ctx, const Csr& m, bool already_transposed, ip
 void csr_transpose(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* At);  // deterministic
 void csr_spmv(ipd_ctx* ctx, const Csr& A, const double* x, double* y);
 void exclusive_scan_i32(ipd_ctx* ctx, const int* in, int* out, int n);  // out has n+1 entries
-int exclusive_scan_total(ipd_ctx* ctx, const int* in, int* out, int n);  // same, returns out[n]
+int exclusive_scan_total(ipd_ctx* ctx, const int* in, int* out, int n);
+void exclusive_scan_total2(ipd_ctx* ctx, const int* in1, int* out1, const int* in2, int* out2, int n,
+                           int* total1, int* total2);  // same, returns out[n]
 void fill_i32(ipd_ctx* ctx, int* p, int v, size_t n);
 void fill_f64(ipd_ctx* ctx, double* p, double v, size_t n);
 void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n);

@@ -1383,8 +1383,7 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
             X.nr = X.nc = N;
             W1.rp = tmp.alloc<int>((size_t)N + 1);
             X.rp = tmp.alloc<int>((size_t)N + 1);
-            W1.nnz = exclusive_scan_total(ctx, cnt1, W1.rp, N);
-            X.nnz = exclusive_scan_total(ctx, cntx, X.rp, N);
+            exclusive_scan_total2(ctx, cnt1, W1.rp, cntx, X.rp, N, &W1.nnz, &X.nnz);   // one launch, one round trip
             W1.ci = tmp.alloc<int>((size_t)std::max(W1.nnz, 1));
             W1.va = tmp.alloc<double>((size_t)std::max(W1.nnz, 1));
             X.ci = tmp.alloc<int>((size_t)std::max(X.nnz, 1));

@@ -37,9 +37,7 @@ void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n) { fill_t(ctx, p, v, 
 
 // Exclusive scan of n ints by ONE workgroup (n is a row/column count, at most a
 // few thousand on this path); out[n] receives the total.  in == out is allowed.
-__global__ __launch_bounds__(1024) void k_exscan(const int* __restrict__ in, int* out, int n,
-                                                 volatile unsigned* box, unsigned ticket) {
-    __shared__ int wsum[16];
+__device__ __forceinline__ int exscan_block(const int* __restrict__ in, int* out, int n, int* wsum) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int carry = 0;
     for (int base = 0; base < n; base += 1024) {
@@ -64,13 +62,31 @@ __global__ __launch_bounds__(1024) void k_exscan(const int* __restrict__ in, int
         carry += total;
         __syncthreads();
     }
-    if (tid == 0) {
-        out[n] = carry;
-        if (box) {   // post the total to the host mailbox (ipd_ctx::mailbox_wait)
-            box[16] = (unsigned)carry;
-            __threadfence_system();
-            box[0] = ticket;
-        }
+    if (tid == 0) out[n] = carry;
+    return carry;
+}
+__global__ __launch_bounds__(1024) void k_exscan(const int* __restrict__ in, int* out, int n,
+                                                 volatile unsigned* box, unsigned ticket) {
+    __shared__ int wsum[16];
+    const int carry = exscan_block(in, out, n, wsum);
+    if (threadIdx.x == 0 && box) {   // post the total to the host mailbox (ipd_ctx::mailbox_wait)
+        box[16] = (unsigned)carry;
+        __threadfence_system();
+        box[0] = ticket;
+    }
+}
+// two arrays of the same length, one launch, both totals in one mailbox message
+__global__ __launch_bounds__(1024) void k_exscan2(const int* __restrict__ in1, int* out1,
+                                                  const int* __restrict__ in2, int* out2, int n,
+                                                  volatile unsigned* box, unsigned ticket) {
+    __shared__ int wsum[16];
+    const int c1 = exscan_block(in1, out1, n, wsum);
+    const int c2 = exscan_block(in2, out2, n, wsum);
+    if (threadIdx.x == 0 && box) {
+        box[16] = (unsigned)c1;
+        box[17] = (unsigned)c2;
+        __threadfence_system();
+        box[0] = ticket;
     }
 }
 
@@ -93,6 +109,23 @@ int exclusive_scan_total(ipd_ctx* ctx, const int* in, int* out, int n) {
     int total = 0;
     ctx->mailbox_wait(ticket, &total, sizeof(int));
     return total;
+}
+
+void exclusive_scan_total2(ipd_ctx* ctx, const int* in1, int* out1, const int* in2, int* out2, int n,
+                           int* total1, int* total2) {
+    unsigned ticket = 0;
+    if (!ctx->mailbox_begin(&ticket)) {
+        *total1 = exclusive_scan_total(ctx, in1, out1, n);
+        *total2 = exclusive_scan_total(ctx, in2, out2, n);
+        return;
+    }
+    hipLaunchKernelGGL(k_exscan2, dim3(1), dim3(1024), 0, ctx->stream, in1, out1, in2, out2, n, ctx->mailbox,
+                       ticket);
+    IPD_KERNEL_CHECK();
+    int t[2] = {0, 0};
+    ctx->mailbox_wait(ticket, t, sizeof(t));
+    *total1 = t[0];
+    *total2 = t[1];
 }
 
 // ---------------------------------------------------------------------------
