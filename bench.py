@@ -152,6 +152,8 @@ def pmc_summary_for(args):
     want = {"n1": args.n1, "mask": args.mask, "rho": float(args.rho), "cycle": args.cycle}
     if args.mask != "bernoulli":
         want.pop("rho")
+    if args.mask == "newton":
+        want["newton_k"] = int(args.newton_k)
     for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary*.json")), reverse=True):
         try:
             pm = json.load(open(pf))

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 --pmc counter_collection.csv files into per-kernel means.
 
 usage: summarize_pmc.py OUT.json NAME=counter_collection.csv [NAME=...] [RESIDENT_CYCLES=w,k]
-                        [WORKLOAD=n1:1024,mask:bernoulli,rho:1,cycle:v]
+                        [WORKLOAD=n1:1024,mask:bernoulli,rho:1,cycle:v[,newton_k:9]]
 WORKLOAD: the bench.py arguments of the profiled command, stored under "_workload"; bench.py quotes
 a summary's traffic only on a line of the same workload.
 RESIDENT_CYCLES: the profiled command launched k_resident twice, with w (warm-up) and k (timed)
@@ -33,6 +33,8 @@ def main():
             kv = dict(t.split(":", 1) for t in path.split(","))
             workload = {"n1": int(kv.get("n1", 1024)), "mask": kv.get("mask", "bernoulli"),
                         "rho": float(kv.get("rho", 1.0)), "cycle": kv.get("cycle", "v")}
+            if "newton_k" in kv:
+                workload["newton_k"] = int(kv["newton_k"])
             continue
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(path)):
