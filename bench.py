@@ -31,6 +31,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
+HANDOFF_FLOOR_US = 1.0  # MI355X_MICROARCH.md, table row `handoff-1to1`: an idle tagged-granule hand-off, 0.8-1.0 us
 BK1, TK = 0.0038, 0.0255
 
 
@@ -186,8 +187,26 @@ def spawn_ranks(n, argv, run=None):
     cmd = rank_command(n, argv, port)
     sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
     sys.stderr.flush()
-    res = (run or subprocess.run)(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True,
-                                  timeout=float(os.environ.get("IPD_BENCH_RANKS_TIMEOUT", "1500")))
+    limit = float(os.environ.get("IPD_BENCH_RANKS_TIMEOUT", "1500"))
+    if run is not None:
+        res = run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True, timeout=limit)
+    else:
+        # own session: on a time-out the WHOLE group goes (the launcher and its rank processes -- ranks left
+        # behind would keep holding the GPUs), and the caller gets an exit code, not a traceback
+        import signal
+        import types
+        child = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, _ = child.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            child.communicate()
+            sys.stderr.write("bench.py: the ranks did not finish within %.0f s; process group killed\n" % limit)
+            return 5
+        res = types.SimpleNamespace(returncode=child.returncode, stdout=out)
     line = None
     for ln in (res.stdout or "").splitlines():
         if ln.startswith("{") and '"metric"' in ln:
@@ -242,6 +261,7 @@ def main():
     import codes_of_ipd_ssn_amg_method_amd as ipd
     from codes_of_ipd_ssn_amg_method_amd import _lib
     from ctypes import byref, c_double, c_int, c_int64
+    from ctypes import c_int32 as _ci32
     if "IPD_DEVICE" not in os.environ:
         from ctypes import c_int32 as _ci32
         ndev = _ci32(0)
@@ -428,16 +448,19 @@ def main():
     # residual + restriction are ONE launch, r_c = P'r - (P'A)e
     fused_rrc = [h.level_dims(k)[1] * 2 <= (1 << 18) for k in (1, 2)] if h.J == 3 else None
     launches_classic = 4 * nu + 2 + visits2 * (2 * nu + 4) + 1 + 2
-    # hand-offs of the resident kernel per cycle: top, 2 per level-1 sweep, residual, restriction,
-    # per level-2 visit nu + nu sweeps and a residual, prolongation; the zero-start first sweeps of
-    # level 1 and of level 2's first visit need no matrix row and are formed locally (-2)
-    handoffs = (4 * nu + 3 + visits2 * (2 * nu + 1) + 1 - (2 if nu >= 1 else 0)) if h.J == 3 else None
-    # mask-form kernel for level 1 beyond 2048 rows (csrc/ipd_resident_big.h): per cycle the exchange of
-    # ||r||, 1'r (partial sums), 2 per level-1 sweep, the rho-scaled residual of the F rows, 1'r_2, per
-    # level-2 visit nu + nu sweeps and the tail's restriction, the prolongated iterate block by block
-    big = resident and (M > 4096 // 2 + 2048 or os.environ.get("IPD_RESIDENT_BIG") == "1") and h.J == 3
-    if big:
-        handoffs = 1 + 4 * nu + 2 + visits2 * (2 * nu + 1) + 2
+    # which resident kernel ran and how many chip-wide hand-offs its timed launch made: reported by the
+    # library (ipd_amg_resident_kernel), not re-derived from sizes here.  A launch of K loop
+    # bodies makes K x (hand-offs per cycle) + 1: the residual norm after the last cycle.
+    kname, handoffs, big, xmask_lib = "", None, False, False
+    if resident:
+        from ctypes import create_string_buffer
+        nb_, ho_, cy_, xm_ = create_string_buffer(64), c_int64(), _ci32(), _ci32()
+        _lib.check(_lib.lib.ipd_amg_resident_kernel(h.handle, nb_, _ci32(64), byref(ho_), byref(cy_), byref(xm_)))
+        kname = nb_.value.decode()
+        big = kname.startswith("k_resident_big")
+        xmask_lib = bool(xm_.value)
+        if cy_.value == args.steps and ho_.value > 0:
+            handoffs = (ho_.value - 1) / float(args.steps)
     result = {
         "metric": "V-cycle throughput (DoF*cycles/sec), m=n=%d OT grid" % m,
         "value": value, "unit": "DoF*cycles/s", "n_gpus": world, "steps": args.steps,
@@ -454,7 +477,8 @@ def main():
                    "M": M, "E": int(s.sum()), "levels": h.level_sizes(),
                    "level_nnz": [h.level_dims(k)[1] for k in range(1, h.J + 1)],
                    "level1_operator": "bit mask + scale vectors" if maskop else "CSR",
-                   "resident_transfers": "bit mask + scale vectors" if xmask else "CSR rows of P', P",
+                   "resident_transfers": (("bit mask + scale vectors" if xmask_lib else "CSR rows of P', P")
+                                          if resident else None),
                    "parallelism": ("row-block sharded x%d, RCCL all-gather" % world) if sharded
                    else ("replicas x%d" % world if world > 1 else "single GPU")},
         "cycle_bytes_algorithmic": bytes_per_cycle,
@@ -463,7 +487,7 @@ def main():
         "rel_res_after_steps": rel_res_after,
         "execution": ({"mode": ("level-resident kernel, mask form (csrc/ipd_resident_big.h)" if big else
                                 "level-resident kernel (csrc/ipd_resident.h)") + ": the timed steps are ONE launch",
-                       "workgroups": grid_.value, "launches_per_cycle": 1.0 / args.steps,
+                       "kernel": kname, "workgroups": grid_.value, "launches_per_cycle": 1.0 / args.steps,
                        "handoffs_per_cycle": handoffs, "resident_kernel_timeouts": tmo_.value}
                       if resident else
                       {"mode": "one launch per phase" + (", graph replay" if not sharded else ", eager + RCCL"),
@@ -530,33 +554,40 @@ def main():
                "avg_bytes_per_launch": tot_bytes / launches if launches else None,
                "per_level": per_level}
         if resident:
-            # The dominant kernel IS the whole timed region: one launch of k_resident runs the
-            # `steps` loop bodies.  achieved = algorithmic bytes of the launch (B_V of SURVEY 8d
-            # x steps) / its duration (HIP events on the library's stream).  The kernel moves far
-            # fewer bytes than that: the matrices of levels 1-2 are read ONCE per launch into
-            # registers, so `traffic` (PMC, per launch of `steps` cycles) is tiny beside it.
-            ach = bytes_per_cycle * args.steps / ev_ms / 1e6
+            # The dominant kernel IS the whole timed region: one launch of the resident kernel runs the
+            # `steps` loop bodies, the matrices of levels 1-2 are read ONCE into registers, and what
+            # bounds a cycle is the latency of its chip-wide hand-offs, not bytes.
+            #   bound "latency": floor = hand-offs per cycle x 1.0 us -- MI355X_MICROARCH.md's
+            #     `handoff-1to1` row prices an idle tagged-granule hand-off at 0.8-1.0 us;
+            #   achieved / frac: COUNTER-based -- HBM-side bytes of the launch (rocprofv3 FETCH_SIZE /
+            #     WRITE_SIZE passes of this workload, gfx950 corrections of tools/summarize_pmc.py) over
+            #     its duration, against 8 TB/s; null without a committed PMC summary of this workload;
+            #   effective_GBps: the ALGORITHMIC bytes of SURVEY 8d (every sweep re-reads its matrix) over
+            #     the time -- what a matrix-streaming cycle would have to sustain; never a roofline fraction
+            #     (it exceeds the HBM peak at m=n=2048).
+            us_cycle = 1e3 * ev_ms / args.steps
             tr = None
             d = (pm or {}).get("k_resident")
             if d:   # traffic = fixed part (matrix load) + per-cycle part, from two dispatches
                 tr = d["hbm_traffic_bytes_fixed"] + d["hbm_traffic_bytes_per_cycle"] * args.steps
+            ach = (tr / (ev_ms * 1e-3) / 1e9) if tr else None
+            floor = handoffs * HANDOFF_FLOOR_US if handoffs else None
             result["roofline"] = {
-                "bound": "hbm", "kernel": "k_resident", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr,
+                "bound": "latency", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach is not None else None, "traffic": tr,
+                "achieved_kind": "measured HBM-side bytes (PMC) / launch duration",
+                "handoffs_per_cycle": handoffs, "handoff_floor_us": HANDOFF_FLOOR_US,
+                "latency_floor_us": floor, "us_per_cycle": us_cycle,
+                "frac_of_latency_floor": (floor / us_cycle) if floor else None,
+                "us_per_handoff": (us_cycle / handoffs) if handoffs else None,
                 "cycles_per_launch": args.steps, "us_per_launch": 1e3 * ev_ms,
+                "effective_GBps": bytes_per_cycle * args.steps / ev_ms / 1e6,
                 "algorithmic_bytes_per_launch": bytes_per_cycle * args.steps,
-                "us_per_handoff": 1e3 * ev_ms / (args.steps * handoffs) if handoffs else None,
-                # what `achieved` is and is not: an EFFECTIVE rate -- the bytes a
-                # matrix-streaming cycle would move, over the time -- for a kernel whose limiter is
-                # the latency of its hand-offs; the rate of the bytes it really moves is beside it
-                "achieved_kind": "effective (algorithmic bytes of SURVEY 8d / time)",
                 "limiter": "hand-off latency",
-                "frac_of_measured_traffic": (tr / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None,
-                "note": "algorithmic bytes (every sweep re-reads its matrix) over time: the kernel "
-                        "itself keeps the matrices in registers, and the 38 MB hierarchy is "
-                        "Infinity-Cache resident anyway, so FETCH_SIZE/WRITE_SIZE are not HBM bytes "
-                        "here; the step is latency-bound (hand-off ~1 us + dependent row work), "
-                        "see profiles/r2_resident_stamps.txt",
+                "note": "latency-bound: one launch keeps the matrices in registers and exchanges only the "
+                        "iterate (tagged 16-byte granules, sc1); frac is the counter-based HBM fraction, "
+                        "frac_of_latency_floor = (hand-offs x 1.0 us) / measured cycle time; "
+                        "effective_GBps is NOT traffic (see profiles/r4_resident_stamps.txt)",
                 "multi_launch_k_smooth": ksm}
         else:
             result["roofline"] = ksm

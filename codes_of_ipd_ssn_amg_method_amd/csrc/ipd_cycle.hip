@@ -3092,5 +3092,4 @@ __global__ __launch_bounds__(BT) void k_subcycle(const SolveDesc* __restrict__ D
 
 #include "ipd_resident.h"
 #include "ipd_resident_big.h"
-#include "ipd_mid.h"
 #include "ipd_cycle_host.h"

@@ -70,6 +70,8 @@ struct CycleState {
     double* res_out = nullptr;
     unsigned char* res_block = nullptr;   // [gran0 | gran1 | tmo]: zeroed before every launch
     int res_timeouts = 0;    // launches whose bounded spins gave up (then: multi-launch path)
+    long long res_last_handoffs = 0;   // hand-offs and cycles of the last launch (ipd_amg_resident_kernel)
+    int res_last_cycles = 0;
     int res_capacity = -1;   // workgroups of the chosen instantiation the device holds at once (-1: not asked yet)
     // level 1 of up to 4096 rows: the mask-form resident kernel (ipd_resident_big.h), set up by
     // amg_attach_maskop once the bit mask of level 1 is there
@@ -77,14 +79,6 @@ struct CycleState {
     bool res_off = false;    // IPD_NO_RESIDENT=1 when the hierarchy was set up
     ResBigDesc resb_desc;
     int resb_ke2 = 16;
-    // whole solve of a realistic hierarchy in one workgroup (ipd_mid.h): levels 1-2 thread-per-row
-    // with rows in registers and vectors in LDS, levels 3..J out of the LDS image
-    bool mid_ok = false;
-    bool mid_l3c = false;   // level 3 chunked in the kernel (image from level 4) / image from level 3
-    MidDesc mid_desc{};
-    SolveDesc* d_mid = nullptr;
-    size_t mid_lds = 0;
-    double* mid_out = nullptr;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};  // captured Class_AMG loop bodies (x->x2, x2->x)
     const double* gb = nullptr;                    // right-hand side the graphs were captured for
     ~CycleState() {
@@ -716,37 +710,10 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
         if (st->res_timeouts >= 2) st->res_ok = false;
         return false;
     }
+    st->res_last_handoffs = (long long)out[nout - 1];
+    st->res_last_cycles = fixed_cycles > 0 ? fixed_cycles : (int)out[0];
     if (out_host) *out_host = std::move(out);
     return true;
-}
-
-// The single-workgroup whole solve of a realistic hierarchy (ipd_mid.h) on the iterate in x.
-static void run_mid(ipd_amg* h, CycleState* st, const double* b_dev, double* x, int fixed_cycles,
-                    std::vector<double>* out_host, float* ms) {
-    ipd_ctx* ctx = h->ctx;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ms) {
-        IPD_HIP(hipEventCreate(&e0));
-        IPD_HIP(hipEventCreate(&e1));
-        IPD_HIP(hipEventRecord(e0, ctx->stream));
-    }
-    if (st->mid_l3c)
-        hipLaunchKernelGGL(k_solve_mid<true>, dim3(1), dim3(BT), st->mid_lds, ctx->stream,
-                           (const SolveDesc*)st->d_mid, st->mid_desc, b_dev, x, st->mid_out, fixed_cycles);
-    else
-        hipLaunchKernelGGL(k_solve_mid<false>, dim3(1), dim3(BT), st->mid_lds, ctx->stream,
-                           (const SolveDesc*)st->d_mid, st->mid_desc, b_dev, x, st->mid_out, fixed_cycles);
-    IPD_KERNEL_CHECK();
-    if (ms) IPD_HIP(hipEventRecord(e1, ctx->stream));
-    const size_t nout = 4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2);
-    std::vector<double> out(nout);
-    ctx->fetch(st->mid_out, out.data(), nout);
-    if (ms) {
-        IPD_HIP(hipEventElapsedTime(ms, e0, e1));
-        IPD_HIP(hipEventDestroy(e0));
-        IPD_HIP(hipEventDestroy(e1));
-    }
-    if (out_host) *out_host = std::move(out);
 }
 
 void amg_prepare_levels(ipd_amg* h) {
@@ -1393,33 +1360,6 @@ void amg_prepare_levels(ipd_amg* h) {
         const size_t need = used + 3 * r16(8 * (size_t)l2.A.nr);
         return need <= 150 * 1024 ? need : 0;
     };
-    // (a') whole solve in one workgroup for a 2048-row system: level 1 through the generic
-    // phases (global memory), level 2 semi-cached, the rest out of LDS.  Opt-in
-    // (IPD_WHOLE_SEMI=1): measured 1.86 s against 1.82 s for multi-launch level 1 + sub-cycle on
-    // the m=n=1024 Class 1 run -- level 1's 25 phases per cycle cost one workgroup what they cost
-    // as launches.
-    {
-        const char* ns = std::getenv("IPD_NO_SMALL");
-        const char* nw = std::getenv("IPD_WHOLE_SEMI");
-        const Level& l1 = h->L[1];
-        const size_t stage = r16(sizeof(double) * (size_t)l1.A.nr);
-        const bool cyc = h->opts.cycle == 'w' || h->opts.cycle == 'v';
-        if (!(ns && ns[0] == '1') && (nw && nw[0] == '1') && cyc && l1.A.nr > 1024 &&
-            l1.A.nr <= 2048 && l1.A.nnz <= 40000 && h->L.size() > 2 && h->L[2].P.nnz <= 40000 &&
-            semi_plan(stage) != 0) {
-            std::unique_ptr<SolveDesc> sd(new SolveDesc());
-            fill_desc(sd.get());
-            sd->k_lds = 2;
-            sd->k_semi = 2;
-            sd->k_tiny = tiny_from(3);
-            sd->k_blk = blk_from(2);
-            sd->stage_bytes = (int)stage;
-            st->solve_cached = true;
-            st->d_solve = build_image(sd.get(), 2, stage, &st->solve_lds);
-            st->solve_out = ar.alloc<double>(4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2));
-            st->small_ok = true;
-        }
-    }
     if (!st->small_ok) {
         const char* ns = std::getenv("IPD_NO_SMALL");
         bool ok = !(ns && ns[0] == '1') && h->J <= SOLVE_ML;
@@ -1582,127 +1522,10 @@ void amg_prepare_levels(ipd_amg* h) {
             st->d_sub3 = build_image(sd.get(), 3, stage, &st->sub3_lds);
         }
     }
-    // (c) realistic hierarchies whose levels 1-2 are too big for (a) and too small to need many
-    // CUs: the whole solve in ONE workgroup (ipd_mid.h).  Level 3 is either the root of the LDS
-    // image (when it fits) or, typically (a few hundred rows of 10-70 entries: more than LDS
-    // holds), walked in chunks from L2 with the image starting at level 4.
-    {
-        // OPT-IN (IPD_MID=1): measured on the Newton systems of the m=n=1024 Class 1 run
-        // (levels 2048 / 1024 / ~280 / ~80 / ...), it is no faster than the multi-launch path
-        // (0.74-1.0 ms against 0.55-0.75 ms per W cycle): one CU cannot hold the rows of levels 1-3
-        // AND their vectors, so every phase still pays dependent L2 round trips (0.5-0.7 us each,
-        // nothing to overlap them with in a single workgroup), and the W cycle's time is mostly the
-        // 2^(k-1) visits of the tiny levels, which this kernel runs with the same code.
-        const char* nm = std::getenv("IPD_MID");
-        const bool cyc = h->opts.cycle == 'w' || h->opts.cycle == 'v';
-        bool ok = (nm && nm[0] == '1') && !st->small_ok && lean_vectors && h->J >= 3 &&
-                  h->J <= SOLVE_ML && !h->opts.twogrid;
-        if (ok) {
-            const Level& l1 = h->L[1];
-            const Level& l2 = h->L[2];
-            const Level& l3 = h->L[3];
-            // short rows on levels 1-2 (the register copy holds MID_RC entries of a row; longer rows
-            // pay a trip to L2 per sweep) and levels that fit the thread-per-row layout
-            ok = l1.A.nr <= MID_RPT * BT && l2.A.nr <= MID_RPT2 * BT &&
-                 (double)l1.A.nnz <= 7.0 * l1.A.nr && (double)l2.A.nnz <= 7.0 * l2.A.nr &&
-                 (double)l2.P.nnz <= 8.0 * l1.A.nr && (double)l3.P.nnz <= 8.0 * l2.A.nr;
-            for (int k = 3; k <= h->J && ok; ++k) ok = small_level(k);
-        }
-        if (ok) {
-            const size_t stage = 16;
-            size_t used = 0;
-            const int k_lds = plan_lds(stage, &used);
-            const int root = k_lds <= 3 ? 3 : 4;   // first level of the image
-            const bool l3c = root == 4;
-            ok = k_lds <= 4 && h->J >= root && blk_from(root) == root && h->L[root].A.nr <= BT;
-            const int N3 = h->L[3].A.nr;
-            const int nch_max = l3c ? h->L[3].A.nnz / MID_CH + N3 + 1 : 0;
-            if (ok) {
-                std::unique_ptr<SolveDesc> sd(new SolveDesc());
-                fill_desc(sd.get());
-                sd->k_lds = root;
-                sd->k_tiny = tiny_from(root);
-                sd->k_blk = blk_from(root);
-                sd->stage_bytes = (int)stage;
-                size_t img_total = 0;
-                SolveDesc* img = build_image(sd.get(), root, stage, &img_total);
-                const size_t l3_off = r16(img_total);
-                const size_t l3_bytes = l3c ? sizeof(double) * ((size_t)3 * N3 + (size_t)nch_max) : 0;
-                if (l3_off + l3_bytes <= 156 * 1024) {
-                    auto mid_level = [&](int k) {
-                        const Level& lv = h->L[k];
-                        const Level& ch = h->L[k + 1];
-                        MidLevel m;
-                        m.N = lv.A.nr;
-                        m.nf = lv.nf;
-                        m.Nc = ch.A.nr;
-                        m.rp = lv.A.rp;
-                        m.ci = lv.A.ci;
-                        m.va = lv.A.va;
-                        m.dinv = lv.dinv;
-                        m.Axi = lv.Axi;
-                        m.xx = lv.xx;
-                        m.Rrp = ch.Pt.rp;
-                        m.Rci = ch.Pt.ci;
-                        m.Rva = ch.Pt.va;
-                        m.Prp = ch.P.rp;
-                        m.Pci = ch.P.ci;
-                        m.Pva = ch.P.va;
-                        return m;
-                    };
-                    MidDesc md;
-                    std::memset(&md, 0, sizeof(md));
-                    md.L1 = mid_level(1);
-                    md.L2 = mid_level(2);
-                    md.l3_off = (unsigned)l3_off;
-                    md.nch_max = nch_max;
-                    if (l3c) {
-                        md.L3 = mid_level(3);
-                        int* cnt = ar.alloc<int>((size_t)N3 + 1);
-                        int* row_ch = ar.alloc<int>((size_t)N3 + 1);
-                        int* ch_t0 = ar.alloc<int>((size_t)nch_max);
-                        hipLaunchKernelGGL(k_mid_chunk_counts, dim3(cdiv(N3, 256)), dim3(256), 0, ctx->stream,
-                                           N3, h->L[3].A.rp, cnt);
-                        IPD_KERNEL_CHECK();
-                        exclusive_scan_i32(ctx, cnt, row_ch, N3);
-                        hipLaunchKernelGGL(k_mid_chunk_fill, dim3(cdiv(N3, 256)), dim3(256), 0, ctx->stream,
-                                           N3, h->L[3].A.rp, (const int*)row_ch, ch_t0);
-                        IPD_KERNEL_CHECK();
-                        md.row_ch = row_ch;
-                        md.ch_t0 = ch_t0;
-                    } else {
-                        md.L3.N = N3;   // the level below level 2 (sizes only)
-                    }
-                    md.J = h->J;
-                    md.nu = h->opts.smoth;
-                    md.isnsp = h->opts.isnsp;
-                    md.wcycle = h->opts.cycle == 'w';
-                    md.anycycle = cyc;
-                    md.maxit = h->opts.maxit;
-                    md.retol = h->opts.retol;
-                    md.e1 = h->L[1].e;
-                    md.e1b = h->L[1].e2;
-                    md.w1 = h->L[1].w;
-                    md.r1 = h->L[1].r;
-                    md.e2 = h->L[2].e;
-                    md.e2b = h->L[2].e2;
-                    md.r2 = h->L[2].r;
-                    st->mid_desc = md;
-                    st->mid_l3c = l3c;
-                    st->d_mid = img;
-                    st->mid_lds = l3_off + l3_bytes;
-                    st->mid_out = ar.alloc<double>(4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2));
-                    st->mid_ok = true;
-                    IPD_OPTIN_LDS(ctx, k_solve_mid<false>, 156 * 1024);
-                    IPD_OPTIN_LDS(ctx, k_solve_mid<true>, 156 * 1024);
-                }
-            }
-        }
-    }
     plan_resident(h, st.get());
     if (const char* dbg = std::getenv("IPD_DEBUG_LEVELS"); dbg && dbg[0] == '1') {
-        std::fprintf(stderr, "[ipd] J=%d small=%d k_sub=%d mid=%d resident=%d(G=%d,KE=%d) levels:", h->J,
-                     (int)st->small_ok, st->k_sub, (int)st->mid_ok, (int)st->res_ok, st->res_G, st->res_ke);
+        std::fprintf(stderr, "[ipd] J=%d small=%d k_sub=%d resident=%d(G=%d,KE=%d) levels:", h->J,
+                     (int)st->small_ok, st->k_sub, (int)st->res_ok, st->res_G, st->res_ke);
         for (int k = 1; k <= h->J; ++k) std::fprintf(stderr, " %d/%d", h->L[k].A.nr, h->L[k].A.nnz);
         std::fprintf(stderr, "\n");
     }
@@ -2351,20 +2174,6 @@ void amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev, dou
         else
             IPD_HIP(hipMemsetAsync(xa, 0, sizeof(double) * (size_t)N, ctx->stream));
     }
-    if (st->mid_ok && st->shard_ranks == 1) {
-        std::vector<double> out;
-        run_mid(h, st, b_dev, xa, 0, &out, nullptr);
-        const int its = (int)out[0];
-        if (rel_resk) std::memcpy(rel_resk, out.data() + 4, sizeof(double) * ((size_t)its + 1));
-        if (rhok) std::memcpy(rhok, out.data() + 4 + (o.maxit + 2), sizeof(double) * ((size_t)its + 1));
-        if (x_dev)
-            IPD_HIP(hipMemcpyAsync(x_dev, xa, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
-                                   ctx->stream));
-        if (it_out) *it_out = its;
-        if (rel_res_out) *rel_res_out = out[1];
-        ctx->sync();
-        return;
-    }
     launch_top(h, st, b_dev, xa, nullptr, xb, true);                            // :89
     std::swap(xa, xb);
     double hh[5];
@@ -2379,16 +2188,7 @@ void amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev, dou
         double last_rel = 1.0;
         if (rel_resk) rel_resk[0] = 1.0;
         if (rhok) rhok[0] = NAN;
-        // Optional replay of the loop body from two captured HIP graphs (IPD_SOLVE_GRAPH=1).
-        // Measured: no gain for a solve -- the device, not the host, is the bottleneck at
-        // ~3 us per dependent launch, and instantiating ~600 nodes costs ~1 ms per hierarchy.
-        const char* sg = std::getenv("IPD_SOLVE_GRAPH");
-        const bool use_graph = (sg && sg[0] == '1') && st->shard_ranks == 1;
-        if (use_graph) ensure_graphs(h, st, b_dev);
         while (last_rel > o.retol && it <= o.maxit) {                            // :95
-            if (use_graph)
-                IPD_HIP(hipGraphLaunch(st->gexec[xa == h->x ? 0 : 1], ctx->stream));
-            else
             enqueue_loop_body(h, st, b_dev, xa, xb);                             // :96-105
             std::swap(xa, xb);
             ctx->fetch(st->hist, hh, 5);
@@ -2569,6 +2369,30 @@ extern "C" int ipd_amg_resident_levels(const ipd_amg* h, int32_t* levels, int32_
     });
 }
 
+// Which resident kernel this hierarchy's solve phase launches (mode 2 of ipd_amg_solve_mode) -- the
+// instantiation's name as it appears in a rocprofv3 kernel trace, "" otherwise -- and what its last
+// launch did: chip-wide hand-offs (tagged-granule exchanges, plus visits of the remote tail) and loop
+// bodies.  bench.py derives hand-offs per cycle from these instead of re-deriving the kernel from sizes.
+extern "C" int ipd_amg_resident_kernel(const ipd_amg* h, char* name, int32_t cap, int64_t* handoffs,
+                                       int32_t* cycles, int32_t* mask_transfers) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h && name && cap > 0, IPD_E_ARG, "bad argument");
+        const CycleState* st = h->cyc.get();
+        char buf[64] = "";
+        if (st && st->res_ok) {
+            if (st->resb)
+                std::snprintf(buf, sizeof buf, "k_resident_big<%d>", st->resb_ke2);
+            else
+                std::snprintf(buf, sizeof buf, "k_resident<%d,%d,%d>", st->res_ke, st->res_ke, st->res_ke3);
+        }
+        std::snprintf(name, (size_t)cap, "%s", buf);
+        if (handoffs) *handoffs = st ? st->res_last_handoffs : 0;
+        if (cycles) *cycles = st ? st->res_last_cycles : 0;
+        // level 1 <-> 2 transfers from the bit mask: always in the mask-form kernel, ResDesc::xm otherwise
+        if (mask_transfers) *mask_transfers = (st && st->res_ok && (st->resb || st->res_desc.xm)) ? 1 : 0;
+    });
+}
+
 // How the levels held in the LDS images of this hierarchy run (bit mask over all images packed):
 // 1 thread-per-row sweeps, 2 the same with dense rows in registers, 4 one-wave sweeps, 8 one-wave
 // polynomial form, 16 block-wide polynomial form; 0: the level is in no image.
@@ -2606,7 +2430,7 @@ extern "C" int ipd_amg_solve_mode(const ipd_amg* h, int32_t* mode, int32_t* grid
     if (!h || !mode) return IPD_E_ARG;
     const CycleState* st = h->cyc.get();
     if (!st) return IPD_E_ARG;
-    *mode = st->small_ok ? 1 : (st->res_ok ? 2 : (st->mid_ok ? 3 : 0));
+    *mode = st->small_ok ? 1 : (st->res_ok ? 2 : 0);
     if (grid) *grid = st->res_ok ? st->res_G + (st->res_remote ? 1 : 0) : (st->small_ok ? 1 : 0);
     if (timeouts) *timeouts = st->res_timeouts;
     return IPD_OK;
@@ -2716,18 +2540,6 @@ extern "C" int ipd_amg_bench_cycles(ipd_amg* h, const double* b_dev, double* x_d
                 if (bytes_per_cycle) *bytes_per_cycle = cycle_bytes(h);
                 return;
             }
-        }
-        if (st->mid_ok) {  // one single-workgroup launch runs all the cycles
-            IPD_HIP(hipMemcpyAsync(h->x, x_dev, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
-                                   ctx->stream));
-            float msf = 0.f;
-            run_mid(h, st, b_dev, h->x, cycles, nullptr, &msf);
-            IPD_HIP(hipMemcpyAsync(x_dev, h->x, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice,
-                                   ctx->stream));
-            ctx->sync();
-            *total_ms = msf;
-            if (bytes_per_cycle) *bytes_per_cycle = cycle_bytes(h);
-            return;
         }
         const char* ng = std::getenv("IPD_NO_GRAPH");
         const bool use_graph = !(ng && ng[0] == '1');

@@ -452,16 +452,15 @@ struct MaskHint {   // p, q, tk of the rescaled system when A is the whole Ae (e
     double tk = 0.0;
 };
 
-// Row f3 (opt-in, IPD_REUSE_HIERARCHY=1): AMG4POT solves two systems with the same Ae
-// (Class2/AMG4POT.m:46-47) and the reference sets the hierarchy up twice.  The second setup draws
-// fresh random numbers in mis_set, so its hierarchy differs from the first; reusing the first one
-// changes zeta within the solver tolerance only, but not bit for bit -- hence off by default.
+// Row f3: AMG4POT solves two systems with the same Ae (Class2/AMG4POT.m:46-47) and the reference
+// sets the hierarchy up twice.  The second setup draws fresh random numbers in mis_set, so only the
+// rand-independent part (Ae, the components, levels 1-2) is shared: bit-identical to two full setups.
+// (One hierarchy for both right-hand sides was measured in round 2 -- it changes zeta by 6.5e-9 and is
+// slower, because the two solves no longer overlap -- and removed in round 4.)
 struct HybridCache {
     bool valid = false;
     Csr Ae;
     Components cc;
-    std::vector<std::unique_ptr<ipd_amg, void (*)(ipd_amg*)>> hier;   // in order of use
-    size_t next = 0;
     // donors (default path): the first call records its hierarchies, the second call's setups
     // share their rand-independent part (amg_setup's `donor`): bit-identical results
     bool record_donors = false, use_donors = false;
@@ -490,9 +489,7 @@ static std::function<void(int*, double*)> class_amg_prepare(
     ctx->upload(dg, g.data(), (size_t)N);
     std::shared_ptr<ipd_amg> own;
     ipd_amg* h = nullptr;
-    if (cache && cache->valid && cache->next < cache->hier.size()) {
-        h = cache->hier[cache->next++].get();          // second right-hand side: same operator
-    } else if (cache && (cache->record_donors || cache->use_donors)) {
+    if (cache && (cache->record_donors || cache->use_donors)) {
         ProfScope ps(ctx, PROF_AMG_SETUP);
         std::shared_ptr<ipd_amg> donor;
         if (cache->use_donors && cache->next_donor < cache->donors.size())
@@ -508,10 +505,7 @@ static std::function<void(int*, double*)> class_amg_prepare(
         h = fresh.get();
         // matrix-free level 1 where it pays (policy in amg_attach_maskop)
         if (mh.p && o.bigph) amg_attach_maskop(h, mh.p, mh.q, mh.m, mh.n, mh.tk, true);
-        if (cache)
-            cache->hier.push_back(std::move(fresh));
-        else
-            own = std::shared_ptr<ipd_amg>(fresh.release(), ipd_amg_destroy);
+        own = std::shared_ptr<ipd_amg>(fresh.release(), ipd_amg_destroy);
     }
     return [ctx, h, own, f, dg, u_out](int* it, double* rel_res) {
         int32_t its = 0;
@@ -600,7 +594,6 @@ static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, 
     const int N0 = 100;                                                   // Hybrid_AMG.m:51
     Arena& tmp = *ctx->scratch;
     const bool reuse = cache && cache->valid;
-    if (cache) cache->next = 0;
     Csr Ae;
     if (reuse) {
         Ae = cache->Ae;
@@ -832,19 +825,16 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
                  const double* q, int m, int n, double bk1, double tk, const double* z,
                  const uint8_t* s, const double* phi, const AmgOpts& opts, ipd_rng* rng,
                  double* zeta, HybridOut* out, StepDonors* step) {
-    const char* re = getenv("IPD_REUSE_HIERARCHY");
-    const bool reuse_env = re && re[0] == '1';
     const char* nc = getenv("IPD_NO_POT_CONCURRENT");
-    const bool concurrent = !reuse_env && !(nc && nc[0] == '1');
+    const bool concurrent = !(nc && nc[0] == '1');
     HybridCache cache;
     if (!concurrent) {
         if (step) step->prev.clear();
         auto solve = [&](const double* rhs, double* x, HybridOut* o) {
-            hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o,
-                              reuse_env ? &cache : nullptr);
+            hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o, nullptr);
         };
         pot_reduce(ctx, H0, p, q, m, n, bk1, tk, z, s, phi, zeta, out, solve);
-        ctx->sync();   // the cached hierarchies are released on return
+        ctx->sync();
         return;
     }
     // The two systems Ae*vv = v and Ae*ww = w are independent (Class2/AMG4POT.m:46-47).  Their

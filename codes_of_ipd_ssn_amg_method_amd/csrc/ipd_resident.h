@@ -382,7 +382,7 @@ __device__ __forceinline__ void res_tail_workgroup(const ResDesc& D, char* dyn_r
 }
 
 // out[0] = it, out[1] = rel_res, out[2] = res0; rel_resk at out[4 ..], rhok at out[4+maxit+2 ..]
-// (the layout of k_solve_small).  fixed_cycles > 0: exactly that many loop bodies, no stopping
+// (the layout of k_solve_small; the last slot: hand-offs of the launch).  fixed_cycles > 0: exactly that many loop bodies, no stopping
 // rules (bench hook).  dbg (optional, 16 words): [0] shader clocks spent waiting in sweeps by
 // workgroup 0, [1] clocks of the whole loop, [2] number of hand-offs, [3] 100 MHz ticks of the loop,
 // [4] clocks in the barrier before the publish, [5] in the store phase, [6] in the closing barrier.
@@ -1220,6 +1220,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         // workgroup 0 itself saw every hand-off arrive
         const unsigned anytmo = __hip_atomic_load(D.tmo, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         out[3] = (dead || anytmo != 0) ? 1.0 : 0.0;
+        // the last slot of the rhok block is never written by the iteration (it <= maxit): hand-offs of this
+        // launch, chip-wide ones and visits of the remote tail (ipd_amg_resident_kernel)
+        out[4 + 2 * (maxit + 2) - 1] = (double)(seq + tseq);
     }
     if (dbg) {
         D.dbg[0] = dbg_acc[0];

@@ -575,6 +575,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         out[1] = rel_res;
         out[2] = res0;
         out[3] = (dead || anytmo != 0) ? 1.0 : 0.0;
+        out[4 + 2 * (maxit + 2) - 1] = (double)seq;   // hand-offs of this launch (see k_resident)
     }
 #undef RB_PARTIALS
 #undef RB_HANDOFF

@@ -1036,244 +1036,6 @@ __global__ void k_ideal_rows(int N, int Nc, const uint8_t* __restrict__ isF, con
 }
 
 
-// ---------------------------------------------------------------------------
-// interpolation rows -> P, P', P'A, P'AP of a SMALL level in one launch   (transfer.m:46-66)
-// ---------------------------------------------------------------------------
-// What follows k_build_W on a small level (mis_set_small's sizes) used to be 16 launches and 3 host
-// round trips: scan + compaction of the dense interpolation rows, row normalisation, the bitmap
-// transpose (4 launches), and two ordered products of three launches each.  One workgroup does it
-// here, a wave per row, with the same statements per entry as k_dense_compact2 / k_row_normalize /
-// k_tr_mark / k_tr_prefix / k_tr_scatter / k_spgemm_rows / k_dense_compact -- every C(i,j) still
-// receives its terms one at a time in ascending inner index, multiply and add rounded separately --
-// so the bits do not change.  Outputs are sized for the worst case (P, P': N*Nc entries, P'A: Nc*N,
-// P'AP: Nc*Nc); the three entry counts go to the host mailbox in one ticket.
-struct GalSmallArgs {
-    int N, Nc, isnsp, wpc;
-    const int* Arp;
-    const int* Aci;
-    const double* Ava;
-    const double* dense;     // N x Nc interpolation rows (k_build_W)
-    const int* rowcnt;       // their entry counts
-    const uint8_t* isF;
-    int *Prp, *Pci;
-    double* Pva;
-    int *Qrp, *Qci;          // Q = P'
-    double* Qva;
-    int *Trp, *Tci;          // T1 = P'A
-    double* Tva;
-    int *Crp, *Cci;          // C = P'AP
-    double* Cva;
-    unsigned* bits;          // Nc * wpc words (transpose bitmap), scratch
-    int* pref;               // Nc * wpc
-    int* tci;                // Nc * max(N, Nc): a row's compacted entries before its offset is known
-    double* tva;
-    int* tcnt;               // Nc
-    volatile unsigned* box;
-    unsigned ticket;
-};
-__device__ __forceinline__ void gal_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-// ordered product rows: out(i,:) = sum_e x(i,k_e) * y(k_e,:), one wave per row, LDS accumulator of `nc`
-// doubles per wave; the compacted row goes to tci/tva at stride `ld`, its length to tcnt
-__device__ __forceinline__ void gal_product_rows(int nr, int nc, int ld, const int* xrp, const int* xci,
-                                                 const double* xva, const int* yrp, const int* yci,
-                                                 const double* yva, double* acc, int* tci, double* tva,
-                                                 int* tcnt) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int i = wave; i < nr; i += nwaves) {
-        for (int j = lane; j < nc; j += 64) acc[j] = 0.0;
-        gal_wave_sync();
-        const int xb = xrp[i], xe = xrp[i + 1];
-        // The inner index is walked in ascending order, but the memory round trips are taken 64 / 8
-        // terms at a time: lane u fetches term e0 + u (column, value, the y row's range) in one burst,
-        // then the y entries of eight terms are requested together before they are added one term after
-        // the other (a dependent chain of three L2 round trips PER TERM made this kernel 0.4 ms).
-        for (int e0 = xb; e0 < xe; e0 += 64) {
-            const int eu = e0 + lane;
-            const bool have = eu < xe;
-            const int kk = have ? xci[eu] : 0;
-            const double aa = have ? xva[eu] : 0.0;
-            const int ybb = have ? yrp[kk] : 0, yee = have ? yrp[kk + 1] : 0;
-            const int cnt = min(64, xe - e0);
-            for (int u0 = 0; u0 < cnt; u0 += 8) {
-                int jj[8], yb[8], ye[8];
-                double vv[8], au[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int src = min(u0 + u, 63);
-                    yb[u] = __shfl(ybb, src);
-                    ye[u] = (u0 + u < cnt) ? __shfl(yee, src) : yb[u];
-                    au[u] = __shfl(aa, src);
-                    const int t = yb[u] + lane;
-                    const bool in = t < ye[u];
-                    jj[u] = in ? yci[t] : -1;
-                    vv[u] = in ? yva[t] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (jj[u] >= 0) {
-                        const double prod = au[u] * vv[u];
-                        acc[jj[u]] = acc[jj[u]] + prod;
-                    }
-                    for (int t = yb[u] + 64 + lane; t < ye[u]; t += 64) {   // y rows of more than 64 entries
-                        const int j = yci[t];
-                        const double prod = au[u] * yva[t];
-                        acc[j] = acc[j] + prod;
-                    }
-                    gal_wave_sync();
-                }
-            }
-        }
-        int base = 0;
-        for (int j0 = 0; j0 < nc; j0 += 64) {
-            const int j = j0 + lane;
-            const double v = j < nc ? acc[j] : 0.0;
-            const bool nzf = v != 0.0;
-            const unsigned long long mask = __ballot(nzf);
-            if (nzf) {
-                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-                tci[(size_t)i * ld + pos] = j;
-                tva[(size_t)i * ld + pos] = v;
-            }
-            base += __popcll(mask);
-        }
-        if (lane == 0) tcnt[i] = base;
-        gal_wave_sync();
-    }
-}
-__device__ __forceinline__ void gal_copy_rows(int nr, int ld, const int* rp, const int* tci, const double* tva,
-                                              int* ci, double* va) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int i = wave; i < nr; i += nwaves) {
-        const int b = rp[i], n = rp[i + 1] - b;
-        for (int t = lane; t < n; t += 64) {
-            ci[b + t] = tci[(size_t)i * ld + t];
-            va[b + t] = tva[(size_t)i * ld + t];
-        }
-    }
-}
-__global__ __launch_bounds__(1024) void k_galerkin_small(const GalSmallArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char gal_raw[];
-    __shared__ int wsum[16];
-    const int N = a.N, Nc = a.Nc, wpc = a.wpc, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    // ---- P: row pointers, ordered compaction (k_dense_compact2), normalisation (k_row_normalize)
-    int nnzP = 0;
-    {
-        const int off = mis_block_exscan(tid < N ? a.rowcnt[tid] : 0, wsum, &nnzP);
-        if (tid < N) a.Prp[tid] = off;
-        if (tid == 0) a.Prp[N] = nnzP;
-    }
-    __syncthreads();
-    for (int i = wave; i < N; i += nwaves) {
-        int base = a.Prp[i];
-        const double* drow = a.dense + (size_t)i * Nc;
-        for (int j0 = 0; j0 < Nc; j0 += 64) {
-            const int j = j0 + lane;
-            const double v = j < Nc ? drow[j] : 0.0;
-            const bool nzf = v != 0.0;
-            const unsigned long long mask = __ballot(nzf);
-            if (nzf) {
-                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-                a.Pci[pos] = j;
-                a.Pva[pos] = v;
-            }
-            base += __popcll(mask);
-        }
-    }
-    __syncthreads();
-    if (a.isnsp == 1) {
-        for (int i = wave; i < N; i += nwaves) {
-            if (!a.isF[i]) continue;
-            const int b = a.Prp[i], e = a.Prp[i + 1];
-            double accs = 0.0;
-            if (lane == 0)
-                for (int t = b; t < e; ++t) accs = accs + a.Pva[t];  // ascending columns, sequential
-            const double sgm = __shfl(accs, 0);
-            for (int t = b + lane; t < e; t += 64) a.Pva[t] = a.Pva[t] / sgm;
-        }
-        __syncthreads();
-    }
-    // ---- Q = P' by the row bitmaps of the columns (k_tr_mark / k_tr_prefix / k_tr_scatter)
-    for (int wd = tid; wd < Nc * wpc; wd += blockDim.x) a.bits[wd] = 0u;
-    __syncthreads();
-    for (int r = wave; r < N; r += nwaves) {
-        const int b = a.Prp[r], e = a.Prp[r + 1];
-        for (int t = b + lane; t < e; t += 64)
-            atomicOr(&a.bits[(size_t)a.Pci[t] * wpc + (r >> 5)], 1u << (r & 31));
-    }
-    __syncthreads();
-    for (int c = wave; c < Nc; c += nwaves) {
-        int carry = 0;
-        for (int base = 0; base < wpc; base += 64) {
-            const int wd = base + lane;
-            const int v = wd < wpc ? __popc(a.bits[(size_t)c * wpc + wd]) : 0;
-            int x = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int y = __shfl_up(x, d);
-                if (lane >= d) x += y;
-            }
-            if (wd < wpc) a.pref[(size_t)c * wpc + wd] = carry + x - v;
-            carry += __shfl(x, 63);
-        }
-        if (lane == 0) a.tcnt[c] = carry;
-    }
-    __syncthreads();
-    {
-        int tot = 0;
-        const int off = mis_block_exscan(tid < Nc ? a.tcnt[tid] : 0, wsum, &tot);
-        if (tid < Nc) a.Qrp[tid] = off;
-        if (tid == 0) a.Qrp[Nc] = tot;
-    }
-    __syncthreads();
-    for (int r = wave; r < N; r += nwaves) {
-        const int b = a.Prp[r], e = a.Prp[r + 1];
-        const unsigned below = (1u << (r & 31)) - 1u;
-        for (int t = b + lane; t < e; t += 64) {
-            const int c = a.Pci[t];
-            const size_t wd = (size_t)c * wpc + (r >> 5);
-            const int pos = a.Qrp[c] + a.pref[wd] + __popc(a.bits[wd] & below);
-            a.Qci[pos] = r;
-            a.Qva[pos] = a.Pva[t];
-        }
-    }
-    __syncthreads();
-    // ---- T1 = P'A, then C = T1 P: left to right (transfer.m:66)
-    double* acc = reinterpret_cast<double*>(gal_raw) + (size_t)wave * (size_t)(N > Nc ? N : Nc);
-    const int ld = N > Nc ? N : Nc;
-    gal_product_rows(Nc, N, ld, a.Qrp, a.Qci, a.Qva, a.Arp, a.Aci, a.Ava, acc, a.tci, a.tva, a.tcnt);
-    __syncthreads();
-    int nnzT = 0;
-    {
-        const int off = mis_block_exscan(tid < Nc ? a.tcnt[tid] : 0, wsum, &nnzT);
-        if (tid < Nc) a.Trp[tid] = off;
-        if (tid == 0) a.Trp[Nc] = nnzT;
-    }
-    __syncthreads();
-    gal_copy_rows(Nc, ld, a.Trp, a.tci, a.tva, a.Tci, a.Tva);
-    __syncthreads();
-    gal_product_rows(Nc, Nc, ld, a.Trp, a.Tci, a.Tva, a.Prp, a.Pci, a.Pva, acc, a.tci, a.tva, a.tcnt);
-    __syncthreads();
-    int nnzC = 0;
-    {
-        const int off = mis_block_exscan(tid < Nc ? a.tcnt[tid] : 0, wsum, &nnzC);
-        if (tid < Nc) a.Crp[tid] = off;
-        if (tid == 0) a.Crp[Nc] = nnzC;
-    }
-    __syncthreads();
-    gal_copy_rows(Nc, ld, a.Crp, a.tci, a.tva, a.Cci, a.Cva);
-    if (tid == 0) {
-        a.box[16] = (unsigned)nnzP;
-        a.box[17] = (unsigned)nnzT;
-        a.box[18] = (unsigned)nnzC;
-        __threadfence_system();
-        a.box[0] = a.ticket;
-    }
-}
-
 void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int level,
                   ipd_rng* rng, Csr* Ac, Csr* Pout, Csr* Ptout, uint8_t* cmask, Csr* T1out) {
     IPD_REQUIRE(A.nr == A.nc, IPD_E_ARG, "transfer: A must be square");
@@ -1406,70 +1168,6 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
                                (size_t)Nc * 16, ctx->stream, N, Nc, A.rp, A.ci, A.va, diag, strong,
                                isC, isF, cidx, dense, rowcnt);
             IPD_KERNEL_CHECK();
-            // small level: everything from here to the coarse operator in ONE launch (k_galerkin_small)
-            const size_t worst = 12 * (2 * (size_t)N * Nc + (size_t)Nc * N + (size_t)Nc * Nc);
-            unsigned ticket = 0;
-            // OPT-IN (IPD_GALERKIN_SMALL=1).  Measured on the m=n=1024 Class 1 run: bit-identical, but the
-            // setups take 0.385 s with it against 0.243 s without -- sixteen waves of one workgroup walk
-            // the rows of the two products one after the other, each term a chain of L2 round trips
-            // (0.50 s before the terms were fetched 64 / 8 at a time), where the launches it replaces run
-            // a hundred workgroups side by side; the launches' latency is the smaller cost.
-            const char* ngs = getenv("IPD_GALERKIN_SMALL");
-            if (small_done && (ngs && ngs[0] == '1') && Nc <= 1024 && worst <= (size_t(24) << 20) &&
-                ctx->mailbox_begin(&ticket)) {
-                GalSmallArgs g;
-                g.N = N;
-                g.Nc = Nc;
-                g.isnsp = o.isnsp;
-                g.wpc = (N + 31) / 32;
-                g.Arp = A.rp;
-                g.Aci = A.ci;
-                g.Ava = A.va;
-                g.dense = dense;
-                g.rowcnt = rowcnt;
-                g.isF = isF;
-                Csr Pt, T1, C;
-                Arena& t1dst = T1out ? dst : tmp;
-                P.rp = g.Prp = dst.alloc<int>((size_t)N + 1);
-                P.ci = g.Pci = dst.alloc<int>((size_t)N * Nc);
-                P.va = g.Pva = dst.alloc<double>((size_t)N * Nc);
-                Pt.rp = g.Qrp = dst.alloc<int>((size_t)Nc + 1);
-                Pt.ci = g.Qci = dst.alloc<int>((size_t)N * Nc);
-                Pt.va = g.Qva = dst.alloc<double>((size_t)N * Nc);
-                T1.rp = g.Trp = t1dst.alloc<int>((size_t)Nc + 1);
-                T1.ci = g.Tci = t1dst.alloc<int>((size_t)Nc * N);
-                T1.va = g.Tva = t1dst.alloc<double>((size_t)Nc * N);
-                C.rp = g.Crp = dst.alloc<int>((size_t)Nc + 1);
-                C.ci = g.Cci = dst.alloc<int>((size_t)Nc * Nc);
-                C.va = g.Cva = dst.alloc<double>((size_t)Nc * Nc);
-                g.bits = tmp.alloc<unsigned>((size_t)Nc * g.wpc);
-                g.pref = tmp.alloc<int>((size_t)Nc * g.wpc);
-                const size_t ldt = (size_t)std::max(N, Nc);
-                g.tci = tmp.alloc<int>((size_t)Nc * ldt);
-                g.tva = tmp.alloc<double>((size_t)Nc * ldt);
-                g.tcnt = tmp.alloc<int>((size_t)Nc + 1);
-                g.box = ctx->mailbox;
-                g.ticket = ticket;
-                IPD_OPTIN_LDS(ctx, k_galerkin_small, 156 * 1024);
-                hipLaunchKernelGGL(k_galerkin_small, dim3(1), dim3(1024), 16 * ldt * 8, ctx->stream, g);
-                IPD_KERNEL_CHECK();
-                unsigned w3[3] = {0, 0, 0};
-                ctx->mailbox_wait(ticket, w3, sizeof(w3));
-                P.nnz = (int)w3[0];
-                Pt.nr = Nc;
-                Pt.nc = N;
-                Pt.nnz = P.nnz;
-                T1.nr = Nc;
-                T1.nc = N;
-                T1.nnz = (int)w3[1];
-                C.nr = C.nc = Nc;
-                C.nnz = (int)w3[2];
-                if (T1out) *T1out = T1;
-                *Ac = C;
-                *Pout = P;
-                *Ptout = Pt;
-                return;
-            }
         }
         P.rp = dst.alloc<int>((size_t)N + 1);
         P.nnz = exclusive_scan_total(ctx, rowcnt, P.rp, N);

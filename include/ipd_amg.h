@@ -415,6 +415,14 @@ int ipd_amg_solve_mode(const ipd_amg* h, int32_t* mode, int32_t* grid, int32_t* 
 /* Mode 2 only: *levels = levels kept in the registers of the resident workgroups (2 or 3),
  * *tail_root = level at which the rest starts (3, or 4 below a resident level 3); zeros otherwise. */
 int ipd_amg_resident_levels(const ipd_amg* h, int32_t* levels, int32_t* tail_root);
+/* Mode 2 only: name = the kernel instantiation a solve of this hierarchy launches, as a rocprofv3
+ * kernel trace spells it ("k_resident<16,16,0>", "k_resident_big<32>"; "" in the other modes; cap =
+ * size of the buffer); *handoffs / *cycles = chip-wide hand-offs (tagged-granule exchanges, visits of
+ * the remote tail included) and Class_AMG loop bodies (AMG/Class_AMG.m:96-105) of the LAST launch;
+ * *mask_transfers != 0: the level 1 <-> 2 transfers run from the active-set bit mask.  Any output
+ * pointer but name may be NULL.                                                                    */
+int ipd_amg_resident_kernel(const ipd_amg* h, char* name, int32_t cap, int64_t* handoffs,
+                            int32_t* cycles, int32_t* mask_transfers);
 /* forms[k], k < count (level k = 1..J; forms[0] = 0): how level k runs where it is held in a single
  * workgroup's LDS image (bit mask over the images packed for this hierarchy): 1 thread-per-row sweeps,
  * 2 the same with dense rows in registers, 4 one-wave sweeps, 8 one-wave polynomial form (the nu sweeps,

@@ -59,6 +59,15 @@ def solve_mode(h):
     return mode.value, grid.value, tmo.value
 
 
+def resident_kernel_name(h):
+    """The kernel instantiation a solve of this hierarchy launches ("" outside mode 2)."""
+    from ctypes import create_string_buffer
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    buf = create_string_buffer(64)
+    _lib.check(_lib.lib.ipd_amg_resident_kernel(h.handle, buf, c_int32(64), None, None, None))
+    return buf.value.decode()
+
+
 def same_history(it, relk, itc, relkc, tol=1e-10):
     """Residual histories agree to `tol` over their common part.  The dense systems here reach the
     rounding floor (2-4e-11 of the initial residual, above retol = 1e-11) after ONE cycle and then
@@ -118,6 +127,7 @@ def test_metric_workload_against_oracle(ipd, metric_system, cycle):
     assert [h.level_dims(k)[1] for k in (1, 2, 3)] == [2099200, 1048576, 1]
     mode, grid, _ = solve_mode(h)
     assert mode == 2 and grid == 128, "the metric workload runs in the level-resident kernel"
+    assert resident_kernel_name(h).startswith("k_resident<16,16,"), resident_kernel_name(h)
     # (ii) K timed loop bodies against the oracle's K iterations
     K = 3
     x, ms, bpc = bench_cycles(h, f, guess, K)

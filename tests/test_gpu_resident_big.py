@@ -13,7 +13,8 @@ import scipy.sparse as sp
 import bench
 from oracle import ipd_oracle as O
 from tests import problems as PR
-from tests.test_gpu_bench_workload import bench_cycles, env, options, same_history, solve_mode
+from tests.test_gpu_bench_workload import (bench_cycles, env, options, resident_kernel_name, same_history,
+                                            solve_mode)
 
 pytestmark = pytest.mark.gpu
 
@@ -77,19 +78,36 @@ def test_forced_big_kernel_against_oracle_and_resident(ipd, m, n, rho, pq, isnsp
     hc.close()
 
 
-@pytest.mark.parametrize("cycle", ["v", "w"])
-def test_n2048_runs_in_the_big_kernel(ipd, cycle):
-    """m = n = 2048, regime D (M = 4096: levels 4096 / 2048 / 1): the mask-form kernel on 256 workgroups
-    against the multi-launch path with the mask sweeps."""
+@pytest.fixture(scope="module")
+def n2048(ipd):
+    """m = n = 2048, regime D (BASELINE config 4's size) and the ORACLE's hierarchy of it: one
+    O.amg_setup (about 35 s: the dense Galerkin products), shared by the V and the W case."""
     m = n = 2048
     s = bench.build_mask(m, n, "bernoulli", 1.0)
     Ae, f, guess, H0 = bench.build_newton_system(ipd, m, n, s)
+    o = dict(options("v", n))
+    o.update(guess=guess)
+    ho = O.amg_setup(Ae, o, O.matlab_rng())
+    return m, n, Ae, f, guess, ho
+
+
+@pytest.mark.parametrize("cycle", ["v", "w"])
+def test_n2048_runs_in_the_big_kernel(ipd, n2048, cycle):
+    """m = n = 2048, regime D (M = 4096: levels 4096 / 2048 / 1): the mask-form kernel on 256 workgroups
+    -- k_resident_big<32>, the instantiation with 32 mask bits and 32 level-2 entries per lane, which only
+    this size selects -- against the ORACLE directly (hierarchy sizes, K loop bodies through
+    A(x - x_oracle), the residual history of a whole solve; AMG/Class_AMG.m:86-109, AMG/MG_Vcycle.m:12-45)
+    and against the multi-launch path with the mask sweeps."""
+    m, n, Ae, f, guess, ho = n2048
     opts = options(cycle, n)
     h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
     assert h.level_sizes() == [4096, 2048, 1] and solve_mode(h)[0] == 0
+    assert h.level_sizes() == ho.level_sizes()
+    assert [h.level_dims(k)[1] for k in range(1, h.J + 1)] == ho.level_nnz()
     assert h.attach_mask_operator(np.ones(m), np.ones(n), bench.TK)
     mode, grid, _ = solve_mode(h)
     assert (mode, grid) == (2, 256), (mode, grid)
+    assert resident_kernel_name(h) == "k_resident_big<32>"
     with env(IPD_NO_RESIDENT_BIG=1):
         hc = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
         assert hc.attach_mask_operator(np.ones(m), np.ones(n), bench.TK)
@@ -102,10 +120,22 @@ def test_n2048_runs_in_the_big_kernel(ipd, cycle):
     assert np.linalg.norm(A @ (a - b)) <= 5e-9 * nf_
     r0 = np.linalg.norm(A @ guess - f)
     assert np.linalg.norm(A @ a - f) < 1e-6 * r0
+    # the oracle's K loop bodies on ITS hierarchy (Class_AMG.m:96-102 without the exit tests)
+    xo = guess.copy()
+    for _ in range(K):
+        r = f - A @ xo
+        xo = xo + (O.MG_Wcycle(ho, r, 1) if cycle == "w" else O.MG_Vcycle(ho, r, 1))
+    assert np.linalg.norm(A @ (a - xo)) <= 1e-9 * nf_
     x, it, rel, relk, rhok = h.solve(f, guess)
     xc, itc, relc, relkc, rhokc = hc.solve(f, guess)
     assert solve_mode(h)[2] == 0
     same_history(it, relk, itc, relkc)
     assert np.linalg.norm(A @ (x - xc)) <= 1e-9 * nf_
+    # a whole solve against O.Class_AMG's solve phase on the oracle's hierarchy
+    o = dict(opts)
+    o.update(guess=guess)
+    xs, ito, relo, relko, rhoko = O.amg_solve(ho, f, o)
+    same_history(it, relk, ito, relko)
+    assert np.linalg.norm(A @ (x - xs)) <= 1e-9 * nf_
     h.close()
     hc.close()

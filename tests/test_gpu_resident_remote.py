@@ -129,12 +129,14 @@ def _against_oracle(ipd, Ae, f, n, cycle, x0, expect_mode=None, kv=None):
     # Tolerance: 1e-10 on rel_res (north_star), unless the ORACLE's own history moves more than that
     # under a perturbation of the right-hand side by one unit in the last place -- these systems have
     # condition numbers of 1e8 and more (bk1 ~ 2e-5 against entries of 1/tk ~ 1e3), and on the latest
-    # one (k = 31) rounding alone moves rel_res(2) = 8e-4 by ~1e-10; the bound is then 8 x that.
+    # one (k = 31) rounding alone moves rel_res(2) = 8e-4 by ~1e-10; the bound is then 2 x that, never
+    # more than 1e-9 (round 3 allowed 8 x, uncapped: 9 x looser than any deviation on record,
+    # profiles/r3_history_sensitivity.txt -- VERDICT r3 #1).
     sgn = np.where(np.random.RandomState(11).random_sample(f.size) < 0.5, -1.0, 1.0)
     _, itp, _, relkp, _ = O.Class_AMG(Ae, f * (1.0 + 2.2e-16 * sgn), o, O.matlab_rng(5489))
     kk = min(ito, itp) + 1
     sens = float(np.max(np.abs(np.asarray(relko[:kk]) - np.asarray(relkp[:kk]))))
-    same_history(it, np.asarray(relk), ito, np.asarray(relko), tol=max(1e-10, 8.0 * sens))
+    same_history(it, np.asarray(relk), ito, np.asarray(relko), tol=min(max(1e-10, 2.0 * sens), 1e-9))
     assert np.linalg.norm(Ae @ (x - xo)) <= 1e-9 * np.linalg.norm(f)
     _against_oracle.forms = h.level_forms()
     h.close()

@@ -127,14 +127,14 @@ def test_transfer_standalone(ipd):
 def test_transfer_small_level_paths(ipd, N, deg, seed, isnsp):
     """`transfer` on levels of at most 1024 rows goes through the one-launch mis_set (k_mis_small): the
     split, Pro, Ac and the NUMBER of random numbers consumed against the oracle, with the launch-per-step
-    form (IPD_NO_MIS_SMALL=1) and the opt-in one-launch Galerkin part (IPD_GALERKIN_SMALL=1) beside it."""
+    form (IPD_NO_MIS_SMALL=1) beside it."""
     import os
     A = PR.random_sym_graph_laplacian(N, deg=deg, seed=seed)
     o = O.amg_options_class1("v"); o.update(bigph=0, isnsp=isnsp)
     rr = O.matlab_rng()
     Ac, Pro, info = O.transfer(A, o, 2, rr)
     used = len(info["mis"]["rand"])
-    for kv in ({}, {"IPD_NO_MIS_SMALL": "1"}, {"IPD_GALERKIN_SMALL": "1"}):
+    for kv in ({}, {"IPD_NO_MIS_SMALL": "1"}):
         os.environ.update(kv)
         try:
             rng = ipd.MatlabRand()

@@ -1,7 +1,9 @@
 #!/bin/bash
+# rocprofv3 kernel statistics of one whole Class 1 driver run at m=n=1024 (run on the GPU box from the
+# repo root; prints the 45 kernels with the largest total time).  Usage: bash tools/prof_driver.sh [SIZE]
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; cd /tmp; export TMPDIR=/tmp
 rm -rf $OUT/prof_drv3
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_drv3 -o d -- python3 $ROOT/tools/bench_driver.py --sizes 1024 --classes 1 > $OUT/prof_drv3.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_drv3 -o d -- python3 $ROOT/tools/bench_driver.py --sizes ${1:-1024} --classes 1 > $OUT/prof_drv3.log 2>&1
 S=$(find $OUT/prof_drv3 -name "*kernel_stats.csv" | head -1)
 python3 - "$S" <<'PY'
 import csv, sys

@@ -1,4 +1,6 @@
 #!/bin/bash
+# rocprofv3 kernel statistics of tools/bench_kkt.py (ASAt / Ax / Aty at m=n=1024); run on the GPU box from
+# the repo root.
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; cd /tmp; export TMPDIR=/tmp
 rm -rf $OUT/prof_kkt3
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kkt3 -o k -- python3 $ROOT/tools/bench_kkt.py --reps 50 > $OUT/prof_kkt3.log 2>&1

@@ -1,8 +1,10 @@
 #!/bin/bash
-# kernel sequence of ONE Newton step of the m=n=1024 Class 1 run (between two resident launches)
+# kernel sequence of ONE Newton step of the m=n=1024 Class 1 run (between two resident launches): run on the
+# GPU box from the repo root; WHICH=<index of the resident launch> (default 60), SIZE=<m=n> (default 1024);
+# result in gpurun_out/trace_step.txt
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; cd /tmp; export TMPDIR=/tmp
 rm -rf $OUT/prof_trace
-timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_trace -o d -- python3 $ROOT/tools/bench_driver.py --sizes 1024 --classes 1 > $OUT/prof_trace.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_trace -o d -- python3 $ROOT/tools/bench_driver.py --sizes ${SIZE:-1024} --classes 1 > $OUT/prof_trace.log 2>&1
 S=$(find $OUT/prof_trace -name "*kernel_trace.csv" | head -1)
 python3 - "$S" "${WHICH:-60}" <<'PY' > $OUT/trace_step.txt
 import csv, sys
