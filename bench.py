@@ -301,6 +301,10 @@ def main():
         _lib.check(_lib.lib.ipd_amg_attach_mask_operator(h.handle, dp.ptr, dq.ptr, c_int64(m),
                                                          c_int64(n), c_double(TK), byref(got)))
         maskop = bool(got.value)
+    if args.mask == "newton" and M == 2 * args.n1 and M > 2048 and not args.no_maskop:
+        # a realistic system beyond k_resident's 2048 rows: the mask-form kernel's deep mode needs the bit mask
+        # (what Hybrid_AMG does itself for a whole, connected Ae: csrc/ipd_cycle_host.h amg_attach_maskop)
+        maskop_deep = h.attach_mask_operator(np.ones(m), np.ones(n), tk_)
     xmask = False
     if args.mask != "newton" and not args.no_maskop:
         # level-resident kernel: level 1 <-> 2 transfers from the bit mask (what Hybrid_AMG does itself)
@@ -461,6 +465,9 @@ def main():
         xmask_lib = bool(xm_.value)
         if cy_.value == args.steps and ho_.value > 0:
             handoffs = (ho_.value - 1) / float(args.steps)
+        else:
+            sys.stderr.write("bench.py: the library reports %d hand-offs over %d cycles for its last resident "
+                             "launch (timed: %d cycles)\n" % (ho_.value, cy_.value, args.steps))
     result = {
         "metric": "V-cycle throughput (DoF*cycles/sec), m=n=%d OT grid" % m,
         "value": value, "unit": "DoF*cycles/s", "n_gpus": world, "steps": args.steps,
@@ -539,13 +546,13 @@ def main():
         # about this line, and `traffic` is then null
         pm = pmc_summary_for(args)
         traffic = None
-        for kname, d in (pm or {}).items():
+        for pk_, d in (pm or {}).items():
             if not isinstance(d, dict) or "hbm_traffic_bytes_per_launch" not in d:
                 continue
-            if "k_smooth_mask" in kname:
+            if "k_smooth_mask" in pk_:
                 if "level1_mask_operator" in result:
                     result["level1_mask_operator"]["traffic"] = d["hbm_traffic_bytes_per_launch"]
-            elif "k_smooth" in kname:
+            elif "k_smooth" in pk_:
                 traffic = d["hbm_traffic_bytes_per_launch"]
         ksm = {"bound": "hbm", "kernel": "k_smooth", "achieved": achieved,
                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

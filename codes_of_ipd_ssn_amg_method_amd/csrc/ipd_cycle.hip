@@ -2712,6 +2712,8 @@ struct BPolyEntry {
     // and Mc in 1024..1024+Nc-1 (the resident kernels' third level: a thread holds entries t, 512 + t
     // and 1024 + t of its workgroup's rows, ipd_resident.h POLY3); W then has N + Nc entries
     double* rows;
+    int rows_seg;   // segment length of that layout: 512 (k_resident, Mc at most 128 columns) or RB_P3_SEG
+    int rows_ld;    // its row stride
 };
 typedef double bp_d4 __attribute__((ext_vector_type(4)));
 // (the k index of MFMA u in a group of four is k0 + 4 (l >> 4) + u, not k0 + 4 u + (l >> 4): a lane's four
@@ -2853,7 +2855,7 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int nZ,
     const double* Y = e.Y;
     auto put = [&](int row, bool me, int j, double v) {
         if (e.rows)
-            e.rows[(size_t)row * 1152 + (me ? 512 : 0) + j] = v;
+            e.rows[(size_t)row * e.rows_ld + (me ? e.rows_seg : 0) + j] = v;
         else
             e.M[row + (size_t)((me ? N8 : 0) + j) * LD] = v;
     };
@@ -2888,7 +2890,7 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int nZ,
             const int i = I0 + (l >> 4) + 4 * g;
             if (i < N && j < Nc) {
                 if (e.rows)
-                    e.rows[(size_t)i * 1152 + 1024 + j] = c[g];
+                    e.rows[(size_t)i * e.rows_ld + 2 * e.rows_seg + j] = c[g];
                 else
                     e.M[i + (size_t)(2 * N8 + j) * LD] = c[g];
             }

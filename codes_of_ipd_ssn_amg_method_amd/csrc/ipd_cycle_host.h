@@ -79,6 +79,7 @@ struct CycleState {
     bool res_off = false;    // IPD_NO_RESIDENT=1 when the hierarchy was set up
     ResBigDesc resb_desc;
     int resb_ke2 = 16;
+    bool resb_deep = false;  // realistic hierarchy: level 3 in polynomial form, remote tail at level 4 (RPW = 2)
     hipGraphExec_t gexec[2] = {nullptr, nullptr};  // captured Class_AMG loop bodies (x->x2, x2->x)
     const double* gb = nullptr;                    // right-hand side the graphs were captured for
     ~CycleState() {
@@ -252,7 +253,8 @@ struct BPolyDev {
     double* W = nullptr;
     int LD = 0;
 };
-static BPolyDev pack_bpoly(ipd_ctx* ctx, ipd_amg* h, CycleState* st, int k, int isnsp, int LD, bool rows) {
+static BPolyDev pack_bpoly(ipd_ctx* ctx, ipd_amg* h, CycleState* st, int k, int isnsp, int LD, bool rows,
+                           int rows_seg = 512, int rows_ld = RES_P3_LD) {
     Arena& ar = *h->arena;
     BPolyDev b;
     const Level& lv = h->L[k];
@@ -292,14 +294,16 @@ static BPolyDev pack_bpoly(ipd_ctx* ctx, ipd_amg* h, CycleState* st, int k, int 
     e.u = e.dv + Np;
     e.cs = e.u + Np;
     const size_t ncols = 2 * N8 + Nc8;
-    const size_t out = rows ? (N + Nc) * (size_t)RES_P3_LD + (N + Nc) : (size_t)LD * (ncols + 1);
+    const size_t out = rows ? (N + Nc) * (size_t)rows_ld + (N + Nc) : (size_t)LD * (ncols + 1);
     b.LD = LD;
     b.M = ar.alloc<double>(out);
-    b.W = rows ? b.M + (N + Nc) * (size_t)RES_P3_LD : b.M + (size_t)LD * ncols;
+    b.W = rows ? b.M + (N + Nc) * (size_t)rows_ld : b.M + (size_t)LD * ncols;
     IPD_HIP(hipMemsetAsync(b.M, 0, out * sizeof(double), ctx->stream));
     e.M = b.M;
     e.W = b.W;
     e.rows = rows ? b.M : nullptr;
+    e.rows_seg = rows_seg;
+    e.rows_ld = rows_ld;
     hipLaunchKernelGGL(k_bpoly_scatter, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream, e);
     IPD_KERNEL_CHECK();
     hipLaunchKernelGGL(k_bpoly_colsum, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream, e);
@@ -632,25 +636,30 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
     if (st->resb) {
         ResBigDesc B = st->resb_desc;
         B.dbg_skip_seq = D.dbg_skip_seq;
-#define IPD_RESB_LAUNCH(KE2)                                                                        \
+#define IPD_RESB_LAUNCH(KE2, RPW, DEEP)                                                             \
     do {                                                                                            \
-        IPD_OPTIN_LDS(ctx, (k_resident_big<KE2>), 156 * 1024);                                      \
+        IPD_OPTIN_LDS(ctx, (k_resident_big<KE2, RPW, DEEP>), 156 * 1024);                           \
         if (st->res_capacity < 0) {                                                                 \
             int nb_ = 0;                                                                            \
-            IPD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, (k_resident_big<KE2>), BT, st->res_lds)); \
+            IPD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, (k_resident_big<KE2, RPW, DEEP>), BT, st->res_lds)); \
             st->res_capacity = nb_ * st->num_cu;                                                    \
         }                                                                                           \
         if (grid > st->res_capacity) {                                                              \
             fits = false;                                                                           \
             break;                                                                                  \
         }                                                                                           \
-        hipLaunchKernelGGL((k_resident_big<KE2>), dim3(grid), dim3(BT), st->res_lds, ctx->stream, B, b_dev, x, \
-                           st->res_out, fixed_cycles);                                              \
+        hipLaunchKernelGGL((k_resident_big<KE2, RPW, DEEP>), dim3(grid), dim3(BT), st->res_lds, ctx->stream, B, \
+                           b_dev, x, st->res_out, fixed_cycles);                                    \
     } while (0)
-        if (st->resb_ke2 == 16)
-            IPD_RESB_LAUNCH(16);
+        if (st->resb_deep) {
+            if (st->resb_ke2 == 4)
+                IPD_RESB_LAUNCH(4, 2, true);
+            else
+                IPD_RESB_LAUNCH(8, 2, true);
+        } else if (st->resb_ke2 == 16)
+            IPD_RESB_LAUNCH(16, 1, false);
         else
-            IPD_RESB_LAUNCH(32);
+            IPD_RESB_LAUNCH(32, 1, false);
 #undef IPD_RESB_LAUNCH
     } else
 #define IPD_RES_LAUNCH(KE, KE3)                                                                     \
@@ -668,6 +677,10 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
         hipLaunchKernelGGL((k_resident<KE, KE, KE3>), dim3(grid), dim3(BT), st->res_lds, ctx->stream, \
                            D, b_dev, x, st->res_out, fixed_cycles);                                 \
     } while (0)
+#ifdef IPD_DEV_ONLY_BIG   // (development: compile the mask-form kernels alone, see tools/kernel_regs.py)
+    (void)D;
+    fits = false;
+#else
     if (st->res_ke3 == 0) {
         if (st->res_ke == 4)
             IPD_RES_LAUNCH(4, 0);
@@ -691,6 +704,7 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
         else
             IPD_RES_LAUNCH(8, 8);
     }
+#endif
 #undef IPD_RES_LAUNCH
     if (!fits) {
         st->res_ok = false;
@@ -998,7 +1012,11 @@ void amg_prepare_levels(ipd_amg* h) {
     auto is_bpoly = [&](int k) {
         if (!use_poly || !use_bpoly || k < 2 || k >= h->J || k >= tiny_lo) return false;
         const long long N = h->L[k].A.nr, Nc = h->L[k + 1].A.nr;
-        return N > 32 && N <= 144 && N + Nc <= 256 && !is_lpoly(k);
+        // (up to 224 rows below a level 1 of more than 2048 rows: there level 4 has 150-200 rows, often dense --
+        // 23 k entries do not fit an LDS image, the operators of this form stay in L2 -- and the mask-form
+        // resident kernel needs its tail rooted at level 4, ipd_resident_big.h DEEP)
+        const long long nmax = h->L[1].A.nr > RES_NMAX ? 224 : 144;
+        return N > 32 && N <= nmax && N + Nc <= 256 && 2 * ((N + 7) / 8 * 8) + (Nc + 7) / 8 * 8 <= 512 && !is_lpoly(k);
     };
     std::vector<BPolyDev> bpoly_dev((size_t)h->J + 2);
     auto ensure_bpoly = [&](int k, int nu, int isnsp) -> const BPolyDev& {
@@ -1044,6 +1062,10 @@ void amg_prepare_levels(ipd_amg* h) {
                 // partial sums of a pass
                 bytes = 3 * r16(8 * r8(N)) + 48 + 8 * (8 * (size_t)bpoly_ld(k) + 8);
             } else {
+                // (the thread-per-row sub-cycle deals BT threads to the rows: a level of more than BT rows cannot
+                // be held that way -- it fits the budget once its child's operators stay in L2, block-wide
+                // polynomial form of a 150-224-row level 4 below a 576-row level 3)
+                if (k >= 2 && N > (size_t)BT) break;
                 bytes = r16(4 * (N + 1)) +
                         (is_bdense(k) ? r16(8 * N * (size_t)bdense_ld((int)N))
                                       : r16(4 * (size_t)lv.A.nnz) + r16(8 * (size_t)lv.A.nnz)) +
@@ -1744,20 +1766,47 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
                               !(std::getenv("IPD_RES_NO_XMASK") && std::getenv("IPD_RES_NO_XMASK")[0] == '1');
     bool sweeps_too = !transfers_only;
     const bool big_forced = std::getenv("IPD_RESIDENT_BIG") && std::getenv("IPD_RESIDENT_BIG")[0] == '1';
-    if (transfers_only && !for_resident && !big_forced) return false;
+    // Realistic hierarchy with a level 1 beyond k_resident's 2048 rows (the Newton systems of the m = n = 2048
+    // runs): candidate for the mask-form kernel's DEEP mode (ipd_resident_big.h) -- it needs the bit mask
+    // whatever the population of the rows
+    const SolveDesc* deep_img = nullptr;
+    size_t deep_img_lds = 0;
+    bool deep_cand = false;
+    {
+        const char* nrs = std::getenv("IPD_NO_RESIDENT");
+        const char* nbg = std::getenv("IPD_NO_RESIDENT_BIG");
+        const char* ndp = std::getenv("IPD_NO_RESIDENT_DEEP");
+        const bool cyc = h->opts.cycle == 'w' || h->opts.cycle == 'v';
+        if (st->k_sub == 4 && st->d_sub) {
+            deep_img = st->d_sub;
+            deep_img_lds = st->sub_lds;
+        } else if (st->k_sub == 3 && st->d_sub4) {
+            deep_img = st->d_sub4;
+            deep_img_lds = st->sub4_lds;
+        }
+        deep_cand = !(nrs && nrs[0] == '1') && !(nbg && nbg[0] == '1') && !(ndp && ndp[0] == '1') && !st->res_off &&
+                    !st->res_ok && !st->resb && !st->small_ok && !h->opts.twogrid && cyc && h->opts.smoth >= 1 &&
+                    h->J >= 5 && (n + m > RES_NMAX || big_forced) && n <= RB_HALF && m <= RB_HALF && lv.nf == n &&
+                    lv.N == m + n && h->L[2].A.nr == m && h->L[3].A.nr <= RB_N3MAX && h->L[4].A.nr <= RB_N4MAX &&
+                    deep_img != nullptr && std::max(RB_LDS_BYTES, deep_img_lds) <= (size_t)156 * 1024;
+    }
+    if (transfers_only && !for_resident && !big_forced && !deep_cand) return false;
     if (policy) {
         const char* off = std::getenv("IPD_NO_MASKOP");
         if (off && off[0] == '1') return false;
         const char* on = std::getenv("IPD_MASKOP");
         if (!(on && on[0] == '1') && (double)lv.A.nnz < 4.0e6) {
-            if (!for_resident) return false;
+            if (!for_resident && !deep_cand) return false;
             sweeps_too = false;   // below the size where the mask SWEEPS of the launch path pay
         }
     }
     if (h->J < 2 || lv.nf != n || lv.N != m + n || tk == 0.0) return false;
     // a row of the mask costs nw word walks whatever its population: with fewer than ~16 entries
     // per row the padded CSR sweep always beats it
-    if ((double)lv.A.nnz < 16.0 * lv.N) return false;
+    if ((double)lv.A.nnz < 16.0 * lv.N) {
+        if (!deep_cand) return false;
+        sweeps_too = false;
+    }
     if (std::max(m, n) > 4096) return false;   // a row's mask words must fit one wave (64 words)
     Arena& ar = *h->arena;
     MaskOp mo;
@@ -1897,6 +1946,115 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
                 st->res_ke3 = 0;
                 st->res_G = G;
                 st->res_lds = RB_LDS_BYTES;
+                st->res_capacity = -1;
+                st->res_desc.dbg_skip_seq = 0;
+                if (const char* e = std::getenv("IPD_RES_DEBUG_SKIP_PUBLISH")) st->res_desc.dbg_skip_seq = (unsigned)std::max(0, std::atoi(e));
+                if (!st->res_out) st->res_out = ar.alloc<double>(4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2));
+                st->res_ok = true;
+            }
+        }
+    }
+    // DEEP mode of the mask-form kernel: realistic hierarchies (five levels and more) whose level 1 exceeds
+    // k_resident's 2048 rows.  Level 2 as short register slices, level 3 in polynomial form (pack_bpoly in the
+    // RB_P3_SEG row layout), the LDS image rooted at level 4 for the tail workgroup; G <= 255 workgroups
+    // (the tail needs a compute unit of its own), two rows of each block per wave.
+    if (deep_cand && !st->resb) {
+        const int N3 = h->L[3].A.nr, N4 = h->L[4].A.nr;
+        int G = std::max(std::max(cdiv(std::max(n, m), 2 * RES_WAVES), cdiv(N3, 4)), std::max(N4, 128));
+        if (const char* e = std::getenv("IPD_RESIDENT_G")) G = std::max(G, std::atoi(e));
+        LevelDev d2 = st->run[2].dev;
+        if (d2.S <= 0 && st->run[2].maxoff > 0) d2.S = -((st->run[2].maxoff + 3) / 4 * 4);   // private copy wanted
+        const int S2 = std::abs(d2.S);
+        if (G + 1 <= st->num_cu && G <= std::min(n, m) && S2 > 0 && S2 <= 64 * 8) {
+            if (d2.S < 0) {
+                d2.S = S2;
+                const Csr& A2 = h->L[2].A;
+                unsigned short* pci = ar.alloc<unsigned short>((size_t)A2.nr * d2.S);
+                double* pva = ar.alloc<double>((size_t)A2.nr * d2.S);
+                double* dg = ar.alloc<double>((size_t)A2.nr);
+                hipLaunchKernelGGL(k_pad_build, dim3(std::max(1, std::min(cdiv(A2.nr, 4), 4096))), dim3(256), 0,
+                                   ctx->stream, A2.nr, d2.S, A2.rp, A2.ci, A2.va, pci, pva, dg);
+                IPD_KERNEL_CHECK();
+                d2.pci = pci;
+                d2.pva = pva;
+                d2.diag = dg;
+            }
+            double* rho = ar.alloc<double>((size_t)n);
+            IPD_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+            hipLaunchKernelGGL(k_res_xmask_rho, dim3(cdiv(n, 4)), dim3(256), 0, ctx->stream, n, m, h->opts.isnsp,
+                               (const unsigned long long*)fb, mo.nwf, (const double*)alpha, (const double*)beta,
+                               (const double*)diag, h->L[2].P.rp, h->L[2].P.ci, h->L[2].P.va, rho, bad);
+            IPD_KERNEL_CHECK();
+            if (ctx->fetch1(bad) == 0) {
+                const BPolyDev pb = pack_bpoly(ctx, h, st, 3, h->opts.isnsp, 0, true, RB_P3_SEG, RB_P3_LD);
+                st->level_forms.resize((size_t)h->J + 1, 0);
+                st->level_forms[3] |= 64;
+                ResBigDesc B{};
+                B.nf = n;
+                B.nc = m;
+                B.N2 = m;
+                B.S2 = d2.S;
+                B.pci2 = d2.pci;
+                B.pva2 = d2.pva;
+                B.diag2 = d2.diag;
+                B.dinv2 = d2.dinv;
+                B.Axi2 = d2.Axi;
+                B.xx2 = d2.xx;
+                B.diag1 = diag;
+                B.dinv1 = st->run[1].dev.dinv;
+                B.Axi1 = st->run[1].dev.Axi;
+                B.xx1 = st->run[1].dev.xx;
+                B.fbits = fb;
+                B.cbits = cb;
+                B.nwf = mo.nwf;
+                B.nwc = mo.nwc;
+                B.alpha = alpha;
+                B.beta = beta;
+                B.rho = rho;
+                B.P3.rp = h->L[3].P.rp;   // (unused in DEEP mode)
+                B.P3.ci = h->L[3].P.ci;
+                B.P3.va = h->L[3].P.va;
+                B.A3.rp = h->L[3].A.rp;
+                B.A3.ci = h->L[3].A.ci;
+                B.A3.va = h->L[3].A.va;
+                B.N3 = N3;
+                B.N4 = N4;
+                B.Pt3.rp = h->L[3].Pt.rp;
+                B.Pt3.ci = h->L[3].Pt.ci;
+                B.Pt3.va = h->L[3].Pt.va;
+                B.P3d.rp = h->L[3].P.rp;
+                B.P3d.ci = h->L[3].P.ci;
+                B.P3d.va = h->L[3].P.va;
+                B.p3rows = pb.M;
+                B.p3w = pb.W;
+                B.nu = h->opts.smoth;
+                B.isnsp = h->opts.isnsp;
+                B.wcycle = h->opts.cycle == 'w';
+                B.anycycle = 1;
+                B.maxit = h->opts.maxit;
+                B.retol = h->opts.retol;
+                B.pcg_maxit = h->opts.pcg_maxit;
+                B.pollsleep = 1;
+                B.presleep = 13;
+                if (const char* e = std::getenv("IPD_RES_PRESLEEP")) B.presleep = std::max(0, std::min(64, std::atoi(e)));
+                const size_t gbytes = (size_t)RB_GRAN * 16, tbytes = (size_t)RES_GRAN_MAX * 16;
+                st->res_block_bytes = 2 * gbytes + 16 + 4 * tbytes + 16;
+                st->res_block = reinterpret_cast<unsigned char*>(ar.alloc_bytes(st->res_block_bytes));
+                B.gran = st->res_block;
+                B.tmo = reinterpret_cast<unsigned*>(st->res_block + 2 * gbytes);
+                B.dbg_skip_seq = 0;
+                B.sub = deep_img;
+                B.tin = st->res_block + 2 * gbytes + 16;
+                B.tout = st->res_block + 2 * gbytes + 16 + 2 * tbytes;
+                B.tctl = reinterpret_cast<unsigned*>(st->res_block + 2 * gbytes + 16 + 4 * tbytes);
+                st->resb_desc = B;
+                st->resb_ke2 = d2.S <= 64 * 4 ? 4 : 8;
+                st->resb = true;
+                st->resb_deep = true;
+                st->res_remote = true;
+                st->res_ke3 = 1;
+                st->res_G = G;
+                st->res_lds = std::max(RB_LDS_BYTES, deep_img_lds);
                 st->res_capacity = -1;
                 st->res_desc.dbg_skip_seq = 0;
                 if (const char* e = std::getenv("IPD_RES_DEBUG_SKIP_PUBLISH")) st->res_desc.dbg_skip_seq = (unsigned)std::max(0, std::atoi(e));
@@ -2381,7 +2539,8 @@ extern "C" int ipd_amg_resident_kernel(const ipd_amg* h, char* name, int32_t cap
         char buf[64] = "";
         if (st && st->res_ok) {
             if (st->resb)
-                std::snprintf(buf, sizeof buf, "k_resident_big<%d>", st->resb_ke2);
+                std::snprintf(buf, sizeof buf, "k_resident_big<%d,%d,%s>", st->resb_ke2, st->resb_deep ? 2 : 1,
+                              st->resb_deep ? "true" : "false");
             else
                 std::snprintf(buf, sizeof buf, "k_resident<%d,%d,%d>", st->res_ke, st->res_ke, st->res_ke3);
         }

@@ -662,13 +662,14 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // sum of the LDS vector at `off` over the set bits of `bits` (entry lane + 64 q <-> bit q), n entries
     auto masked_sum = [&](unsigned bits, int off, int n) __attribute__((always_inline)) {
         double s0 = 0.0, s1 = 0.0;
+        // (entry lane + 64 q at a constant distance from entry `lane`: one address register and immediate offsets;
+        // entries beyond n lie inside the vector's LDS slot -- n <= RES_NMAX / 2 -- and their mask bits are zero)
+        (void)n;
+        const double* base = sm + off + lane;
         for (int q0 = 0; q0 < 16; q0 += 8) {   // eight gathers in flight (sixteen cost registers the row slices need)
             double x[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int j = lane + 64 * (q0 + q);
-                x[q] = sm[off + (j < n ? j : 0)];
-            }
+            for (int q = 0; q < 8; ++q) x[q] = base[64 * (q0 + q)];
             const unsigned bq = bits >> q0;
 #pragma unroll
             for (int q = 0; q < 8; q += 2) {

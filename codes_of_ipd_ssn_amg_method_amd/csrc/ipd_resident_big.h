@@ -16,14 +16,34 @@
 //     a sum is needed -- the workgroups exchange their partial sums (G or 2G granules instead of N).
 // Protocol (tagged 16-byte granules, two buffers by step parity, bounded spins, give-up word), the
 // one-row tail's PCG and the stationary iteration with its stopping rules are k_resident's.
+//
+// Round 4 -- REALISTIC hierarchies at M = 4096 (template argument DEEP; the Newton systems of the m = n =
+// 2048 driver run: levels about 4096 / 2048 / 640 / 190 / 55 / 15, 12 k / 8 k / 3 k entries).  Level 1 and
+// the level 1 <-> 2 transfers stay the bit mask (a row is one register whatever its population -- the
+// hub rows of a dense early mask and the three-entry rows of a late one cost the same 32 LDS gathers),
+// level 2 is short CSR slices in registers (KE2 = 4 or 8), level 3 (up to 1024 rows) runs in polynomial
+// form exactly as k_resident's POLY3 level (rows [M2a | M1] and the stacked restriction row in registers,
+// two entries per thread and segment: three hand-offs per visit), and everything from level 4 down is
+// the remote tail workgroup (res_tail_workgroup: k_subcycle's LDS image rooted at level 4).  The tail
+// workgroup needs a compute unit of its own, so the rows are dealt to G <= 255 workgroups: a wave then
+// owns RPW = 2 rows of each block (rows w and w + 8 of the workgroup's run).
 // Reference: AMG/Class_AMG.m:86-109, AMG/MG_Vcycle.m:12-45, AMG/MG_Wcycle.m:13-46, PCG.m:68-87.
 #pragma once
 
 static constexpr int RB_NMAX = 8 * BT;                 // rows of level 1
 static constexpr int RB_HALF = 4 * BT;                 // rows of a block of level 1 / of level 2
 static constexpr int RB_GRAN = RB_NMAX;                // granules per hand-off buffer
-static constexpr size_t RB_LDS_BYTES =
-    sizeof(double) * ((size_t)2 * RB_NMAX + 3 * RB_HALF + 2 * RES_WAVES + 2 * RES_WAVES + 16 * RES_WAVES + 16);
+static constexpr int RB_RPW_MAX = 2;                   // rows of a block per wave
+static constexpr int RB_N3MAX = 2 * BT;                // rows of the polynomial level 3 (DEEP)
+static constexpr int RB_N4MAX = BT / 2;                // rows of the remote tail's root level (DEEP)
+static constexpr int RB_P3_SEG = RB_N3MAX;             // p3rows layout: [Mr (RB_P3_SEG) | Me (RB_P3_SEG) | Mc (RB_N4MAX)]
+static constexpr int RB_P3_LD = 2 * RB_P3_SEG + RB_N4MAX;
+// LDS (doubles): E2, TU, P3C / RR2, E1S, XS, reductions, publish slots, own-row constants, fail word;
+// DEEP: R3, E3 (RB_N3MAX each), E4 (RB_N4MAX), 64 partial sums of the polynomial passes
+static constexpr size_t RB_LDS_DOUBLES = (size_t)2 * RB_NMAX + 3 * RB_HALF + 2 * RES_WAVES +
+                                         2 * 8 * RB_RPW_MAX + 20 * 8 * RB_RPW_MAX + 8 +
+                                         2 * RB_N3MAX + RB_N4MAX + 64;
+static constexpr size_t RB_LDS_BYTES = sizeof(double) * RB_LDS_DOUBLES;
 
 struct ResBigDesc {
     int nf, nc, N2, S2;
@@ -45,6 +65,16 @@ struct ResBigDesc {
     unsigned* tmo;
     int presleep, pollsleep;
     unsigned dbg_skip_seq;
+    // DEEP: level 3 in polynomial form + remote tail rooted at level 4 (see the header comment)
+    int N3, N4;
+    ResCsr Pt3, P3d;          // level 2 <-> 3: rows of P3' (N3 x N2) and of P3 (N2 x N3)
+    const double* p3rows;     // [N3 + N4][RB_P3_LD]: pack_bpoly's row layout with RB_P3_SEG segments
+    const double* p3w;        // N3 + N4: the rows' factors of 1'r_3
+    // ... and what its tail workgroup needs (res_tail_workgroup's fields of ResDesc)
+    const SolveDesc* sub;     // LDS image of levels 4..J
+    unsigned char* tin;       // 2 x RES_GRAN_MAX granules by visit parity: r_4 for the tail
+    unsigned char* tout;      // ... its answer e_4
+    unsigned* tctl;           // [0] != 0: the solve is over, the tail workgroup leaves
 };
 
 __device__ __forceinline__ void rb_publish(__amdgpu_buffer_rsrc_t rs, unsigned seq, int gidx, double v) {
@@ -87,30 +117,65 @@ __device__ __forceinline__ bool rb_sweep(__amdgpu_buffer_rsrc_t rs, unsigned seq
 }
 
 // out[]: the layout of k_resident / k_solve_small.
-template <int KE2>
+template <int KE2, int RPW, bool DEEP>
 __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, const double* __restrict__ bvec,
                                                         double* xg, double* out, int fixed_cycles) {
+    static_assert(RPW >= 1 && RPW <= RB_RPW_MAX, "rows per wave");
+    constexpr int PUBW = RES_WAVES * RPW;   // rows of a block per workgroup
     extern __shared__ __attribute__((aligned(16))) char rb_smem[];
     double* sm = reinterpret_cast<double*>(rb_smem);
     const char* smb = rb_smem;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int b = blockIdx.x, G = gridDim.x;
+    const int b = blockIdx.x, G = gridDim.x - (DEEP ? 1 : 0);
+    if (DEEP && b == G) {   // the tail workgroup: levels 4..J out of its LDS image
+        __shared__ PhaseLds tail_lds;
+        __shared__ double tail_red[16];
+        __shared__ double tail_part[48 + SOLVE_ML + 1];
+        __shared__ int tail_stat[RES_WAVES];
+        ResDesc T{};
+        T.sub = D.sub;
+        T.tail_root = 4;
+        T.Nt = D.N4;
+        T.remote = 1;
+        T.three = 1;
+        T.wcycle = D.wcycle;
+        T.p3rows = D.p3rows;   // (non-NULL: the tail answers with e_4, the resident workgroups apply M1 P4)
+        T.tin = D.tin;
+        T.tout = D.tout;
+        T.tctl = D.tctl;
+        T.tmo = D.tmo;
+        T.L2.N = D.N2;
+        T.L3.N = D.N3;
+        res_tail_workgroup(T, rb_smem, &tail_lds, tail_red, tail_part, tail_stat);
+        return;
+    }
     const int nf = D.nf, nc = D.nc, N1 = nf + nc, N2 = D.N2;
+    const int N3 = DEEP ? D.N3 : 0, N4 = DEEP ? D.N4 : 0;
     // LDS map (doubles); E2 is a gather target of the register rows: below 64 KB
     constexpr int oE2 = 0, oTU = RB_HALF, oP3C = 2 * RB_HALF, oE1S = 3 * RB_HALF, oXS = oE1S + RB_NMAX;
-    constexpr int oRED = oXS + RB_NMAX, oPUB = oRED + 2 * RES_WAVES, oOWN = oPUB + 2 * RES_WAVES;
-    int* fail = reinterpret_cast<int*>(sm + oOWN + 16 * RES_WAVES);
+    constexpr int oRR2 = oP3C;   // DEEP: rr_2 for everybody (there is no one-row tail column then)
+    constexpr int oRED = oXS + RB_NMAX, oPUB = oRED + 2 * RES_WAVES, oOWN = oPUB + 2 * 8 * RB_RPW_MAX;
+    constexpr int oFAIL = oOWN + 20 * 8 * RB_RPW_MAX;
+    constexpr int oR3L = oFAIL + 8, oE3L = oR3L + RB_N3MAX, oE4 = oE3L + RB_N3MAX, oPS = oE4 + RB_N4MAX;
+    int* fail = reinterpret_cast<int*>(sm + oFAIL);
     double* red = sm + oRED;
 
-    // ---- rows of this wave ------------------------------------------------------------------
+    // ---- rows of this wave: rows w + 8 p (p < RPW) of the workgroup's run of each block -------------
     const int loF = (int)(((long long)b * nf) / G), hiF = (int)(((long long)(b + 1) * nf) / G);
     const int loC = (int)(((long long)b * nc) / G), hiC = (int)(((long long)(b + 1) * nc) / G);   // C index (0-based)
-    const int rowF = loF + w, rowCi = loC + w;
-    const bool vF = rowF < hiF, vC = rowCi < hiC;   // level-2 row of the wave = its C node
-    const int rF = vF ? rowF : 0, rCi = vC ? rowCi : 0;
-    // level-2 row slice -> registers; mask bits of the F row (over C nodes) and of the C row (over F rows)
-    unsigned c2[KE2 / 2];
-    double a2[KE2];
+    bool vF[RPW], vC[RPW];   // level-2 row of the wave = its C node
+    int rF[RPW], rCi[RPW];
+#pragma unroll
+    for (int p = 0; p < RPW; ++p) {
+        const int rowF = loF + w + RES_WAVES * p, rowCi = loC + w + RES_WAVES * p;
+        vF[p] = rowF < hiF;
+        vC[p] = rowCi < hiC;
+        rF[p] = vF[p] ? rowF : 0;
+        rCi[p] = vC[p] ? rowCi : 0;
+    }
+    // level-2 row slices -> registers; mask bits of the F rows (over C nodes) and of the C rows (over F rows)
+    unsigned c2[RPW][KE2 / 2];
+    double a2[RPW][KE2];
     {
         ResLevelDesc L2;
         L2.N = N2;
@@ -122,53 +187,69 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         L2.dinv = D.dinv2;
         L2.Axi = D.Axi2;
         L2.xx = D.xx2;
-        res_load_slice<KE2>(L2, rCi, vC, lane, c2, a2);
+#pragma unroll
+        for (int p = 0; p < RPW; ++p) res_load_slice<KE2>(L2, rCi[p], vC[p], lane, c2[p], a2[p]);
     }
-    unsigned bitsF = 0, bitsC = 0;   // bit q <-> entry lane + 64 q
-    for (int q0 = 0; q0 < 32; q0 += 8) {   // eight words of each row per burst
-        unsigned long long wf[8], wc[8];
+    unsigned bitsF[RPW], bitsC[RPW];   // bit q <-> entry lane + 64 q
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            wf[q] = D.fbits[(size_t)rF * D.nwf + (q0 + q < D.nwf ? q0 + q : 0)];
-            wc[q] = D.cbits[(size_t)rCi * D.nwc + (q0 + q < D.nwc ? q0 + q : 0)];
-        }
+    for (int p = 0; p < RPW; ++p) {
+        bitsF[p] = bitsC[p] = 0;
+        for (int q0 = 0; q0 < 32; q0 += 8) {   // eight words of each row per burst
+            unsigned long long wf[8], wc[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            bitsF |= (vF && q0 + q < D.nwf) ? (unsigned)((wf[q] >> lane) & 1ull) << (q0 + q) : 0u;
-            bitsC |= (vC && q0 + q < D.nwc) ? (unsigned)((wc[q] >> lane) & 1ull) << (q0 + q) : 0u;
+            for (int q = 0; q < 8; ++q) {
+                wf[q] = D.fbits[(size_t)rF[p] * D.nwf + (q0 + q < D.nwf ? q0 + q : 0)];
+                wc[q] = D.cbits[(size_t)rCi[p] * D.nwc + (q0 + q < D.nwc ? q0 + q : 0)];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                bitsF[p] |= (vF[p] && q0 + q < D.nwf) ? (unsigned)((wf[q] >> lane) & 1ull) << (q0 + q) : 0u;
+                bitsC[p] |= (vC[p] && q0 + q < D.nwc) ? (unsigned)((wc[q] >> lane) & 1ull) << (q0 + q) : 0u;
+            }
         }
     }
     // constants of the own rows (LDS: a register pair each would stay live for the whole solve)
     if (lane == 0) {
-        sm[oOWN + 0 * RES_WAVES + w] = D.diag1[rF];
-        sm[oOWN + 1 * RES_WAVES + w] = D.dinv1[rF];
-        sm[oOWN + 2 * RES_WAVES + w] = bvec[rF];
-        sm[oOWN + 3 * RES_WAVES + w] = D.Axi1[rF];
-        sm[oOWN + 4 * RES_WAVES + w] = D.alpha[rF];
-        sm[oOWN + 5 * RES_WAVES + w] = D.rho[rF];
-        sm[oOWN + 6 * RES_WAVES + w] = D.diag1[nf + rCi];
-        sm[oOWN + 7 * RES_WAVES + w] = D.dinv1[nf + rCi];
-        sm[oOWN + 8 * RES_WAVES + w] = bvec[nf + rCi];
-        sm[oOWN + 9 * RES_WAVES + w] = D.Axi1[nf + rCi];
-        sm[oOWN + 10 * RES_WAVES + w] = D.beta[rCi];
-        sm[oOWN + 11 * RES_WAVES + w] = D.diag2[rCi];
-        sm[oOWN + 12 * RES_WAVES + w] = D.dinv2[rCi];
-        sm[oOWN + 13 * RES_WAVES + w] = D.Axi2[rCi];
+#pragma unroll
+        for (int p = 0; p < RPW; ++p) {
+            const int o = oOWN + w + RES_WAVES * p;
+            sm[o + 0 * PUBW] = D.diag1[rF[p]];
+            sm[o + 1 * PUBW] = D.dinv1[rF[p]];
+            sm[o + 2 * PUBW] = bvec[rF[p]];
+            sm[o + 3 * PUBW] = D.Axi1[rF[p]];
+            sm[o + 4 * PUBW] = D.alpha[rF[p]];
+            sm[o + 5 * PUBW] = D.rho[rF[p]];
+            sm[o + 6 * PUBW] = D.diag1[nf + rCi[p]];
+            sm[o + 7 * PUBW] = D.dinv1[nf + rCi[p]];
+            sm[o + 8 * PUBW] = bvec[nf + rCi[p]];
+            sm[o + 9 * PUBW] = D.Axi1[nf + rCi[p]];
+            sm[o + 10 * PUBW] = D.beta[rCi[p]];
+            sm[o + 11 * PUBW] = D.diag2[rCi[p]];
+            sm[o + 12 * PUBW] = D.dinv2[rCi[p]];
+            sm[o + 13 * PUBW] = D.Axi2[rCi[p]];
+        }
     }
-#define RB_dgF sm[oOWN + 0 * RES_WAVES + w]
-#define RB_dvF sm[oOWN + 1 * RES_WAVES + w]
-#define RB_bF sm[oOWN + 2 * RES_WAVES + w]
-#define RB_axF sm[oOWN + 3 * RES_WAVES + w]
-#define RB_alF sm[oOWN + 4 * RES_WAVES + w]
-#define RB_rhF sm[oOWN + 5 * RES_WAVES + w]
-#define RB_dgC sm[oOWN + 6 * RES_WAVES + w]
-#define RB_dvC sm[oOWN + 7 * RES_WAVES + w]
-#define RB_bC sm[oOWN + 8 * RES_WAVES + w]
-#define RB_axC sm[oOWN + 9 * RES_WAVES + w]
-#define RB_btC sm[oOWN + 10 * RES_WAVES + w]
-#define RB_dg2 sm[oOWN + 11 * RES_WAVES + w]
-#define RB_dv2 sm[oOWN + 12 * RES_WAVES + w]
-#define RB_ax2 sm[oOWN + 13 * RES_WAVES + w]
+#define RB_OWN(k, p) sm[oOWN + (k) * PUBW + w + RES_WAVES * (p)]
+#define RB_dgF(p) RB_OWN(0, p)
+#define RB_dvF(p) RB_OWN(1, p)
+#define RB_bF(p) RB_OWN(2, p)
+#define RB_axF(p) RB_OWN(3, p)
+#define RB_alF(p) RB_OWN(4, p)
+#define RB_rhF(p) RB_OWN(5, p)
+#define RB_dgC(p) RB_OWN(6, p)
+#define RB_dvC(p) RB_OWN(7, p)
+#define RB_bC(p) RB_OWN(8, p)
+#define RB_axC(p) RB_OWN(9, p)
+#define RB_btC(p) RB_OWN(10, p)
+#define RB_dg2(p) RB_OWN(11, p)
+#define RB_dv2(p) RB_OWN(12, p)
+#define RB_ax2(p) RB_OWN(13, p)
+// ... and their right-hand sides / the iterate x: uniform per wave, read once or twice per half sweep
+#define RB_xF(p) RB_OWN(14, p)
+#define RB_xC(p) RB_OWN(15, p)
+#define RB_rF(p) RB_OWN(16, p)
+#define RB_rC(p) RB_OWN(17, p)
+#define RB_r2(p) RB_OWN(18, p)
     const bool nsp = D.isnsp != 0;
     const double xx1 = nsp ? D.xx1[0] : 1.0, xx2 = nsp ? D.xx2[0] : 1.0;
     // per-thread constants of the granules this thread receives -- granule j = tid + u BT (u < 4) of a
@@ -193,15 +274,17 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
             pF += aF4[u];
             pC += aC4[u];
         }
-        for (int j = tid; j < N2; j += BT) {
-            double v = 0.0;
-            for (int t = D.P3.rp[j]; t < D.P3.rp[j + 1]; ++t)
-                if (D.P3.ci[t] == 0) v = D.P3.va[t];
-            sm[oP3C + j] = v;
-            pk += D.Axi2[j] * v;
+        if (!DEEP) {
+            for (int j = tid; j < N2; j += BT) {
+                double v = 0.0;
+                for (int t = D.P3.rp[j]; t < D.P3.rp[j + 1]; ++t)
+                    if (D.P3.ci[t] == 0) v = D.P3.va[t];
+                sm[oP3C + j] = v;
+                pk += D.Axi2[j] * v;
+            }
+            for (int t = D.A3.rp[0]; t < D.A3.rp[1]; ++t)
+                if (D.A3.ci[t] == 0) h33 = D.A3.va[t];
         }
-        for (int t = D.A3.rp[0]; t < D.A3.rp[1]; ++t)
-            if (D.A3.ci[t] == 0) h33 = D.A3.va[t];
         pF = wave_sum(pF);
         pC = wave_sum(pC);
         pk = wave_sum(pk);
@@ -218,6 +301,32 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         kappa = res_red8(red);
         __syncthreads();
     }
+    // ---- DEEP: level 3 in polynomial form.  Rows lo3..hi3-1 of [M2a | M1] (at most four) and restriction
+    // row b (N4 <= G: one per workgroup), entries tid and BT + tid of a segment per thread; the rows of P3'
+    // that produce this workgroup's r_3 entries (wave q < n3own) and the rows of P3 of the own level-2 rows
+    const int lo3 = DEEP ? (int)(((long long)b * N3) / G) : 0, hi3 = DEEP ? (int)(((long long)(b + 1) * N3) / G) : 0;
+    const int n3own = hi3 - lo3;
+    int pt3e0 = 0, pt3e1 = 0, p3e0[RPW], p3e1[RPW];
+#pragma unroll
+    for (int p = 0; p < RPW; ++p) p3e0[p] = p3e1[p] = 0;
+    if (DEEP) {
+        if (tid < 5) {
+            const int row = tid < 4 ? lo3 + tid : N3 + b;
+            sm[oPS + 48 + tid] = (tid < 4 ? row < hi3 : b < N4) ? D.p3w[row] : 0.0;
+        }
+        if (w < n3own) {
+            pt3e0 = D.Pt3.rp[lo3 + w];
+            pt3e1 = D.Pt3.rp[lo3 + w + 1];
+        }
+#pragma unroll
+        for (int p = 0; p < RPW; ++p)
+            if (vC[p]) {
+                p3e0[p] = D.P3d.rp[rCi[p]];
+                p3e1[p] = D.P3d.rp[rCi[p] + 1];
+            }
+        for (int j = tid; j < RB_N3MAX; j += BT) sm[oR3L + j] = sm[oE3L + j] = 0.0;
+        for (int j = tid; j < RB_N4MAX; j += BT) sm[oE4 + j] = 0.0;
+    }
     // x: scaled gather copy for everybody, the own rows' values as wave scalars
     for (int j = tid; j < N1; j += BT) {
         const double sc = j < nf ? D.alpha[j] : D.beta[j - nf];
@@ -225,26 +334,46 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         sm[oE1S + j] = 0.0;
     }
     for (int j = tid; j < N2; j += BT) sm[oE2 + j] = 0.0;
-    double xF = vF ? xg[rF] : 0.0, xC = vC ? xg[nf + rCi] : 0.0;
-    double rFv = 0.0, rCv = 0.0, eF = 0.0, eC = 0.0, r2v = 0.0, e2v = 0.0;
+    double eF[RPW], eC[RPW], e2v[RPW];
+#pragma unroll
+    for (int p = 0; p < RPW; ++p) {
+        if (lane == 0) {
+            RB_xF(p) = vF[p] ? xg[rF[p]] : 0.0;
+            RB_xC(p) = vC[p] ? xg[nf + rCi[p]] : 0.0;
+            RB_rF(p) = RB_rC(p) = RB_r2(p) = 0.0;
+        }
+        eF[p] = eC[p] = e2v[p] = 0.0;
+    }
     if (tid == 0) *fail = 0;
     __syncthreads();
 
+    // Addresses are re-derived from FRESH copies of the thread's indices at every use site (RB_FRESH shadows
+    // tid / w / lane by copies laundered through an empty volatile asm): left alone, LLVM reassociates every
+    // `index + constant` of the own-row slots, the hand-off stores and the polynomial rows into a loop-invariant
+    // part and hoists it out of the cycle loop -- a hundred address registers (the LDS map ends beyond the 64 KB
+    // an immediate offset reaches, so each address is a register of its own) that push the data the loop
+    // needs into scratch.
+#define RB_FRESH                                                                                   \
+    const int tid0_ = tid, w0_ = w, lane0_ = lane;                                                 \
+    int tid = tid0_, w = w0_, lane = lane0_;                                                       \
+    asm volatile("" : "+v"(tid), "+v"(w), "+v"(lane))
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(D.gran, 0, 2 * RB_GRAN * 16, 0x00020000);
     unsigned seq = 0;
     bool dead = false;
 
     // sum of the LDS vector at `off` over the set bits of `bits` (entry lane + 64 q <-> bit q)
     auto masked_sum = [&](unsigned bits, int off, int n) __attribute__((always_inline)) {
+        RB_FRESH;
         double s0 = 0.0, s1 = 0.0;
         const int nq = (n + 63) >> 6;
+        // entry lane + 64 q sits at a constant distance from entry `lane`: one address register and immediate
+        // offsets (an index clamped to n cost a register per gather, all of them hoisted out of the cycle loop
+        // and spilled).  Entries beyond n lie inside the vector's LDS slot and their mask bits are zero.
+        const double* base = sm + off + lane;
         for (int q0 = 0; q0 < nq; q0 += 8) {   // eight gathers in flight (all 32 at once spilled registers)
             double x[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int j = lane + 64 * (q0 + q);
-                x[q] = sm[off + (j < n ? j : 0)];
-            }
+            for (int q = 0; q < 8; ++q) x[q] = base[64 * (q0 + q)];
             const unsigned bq = bits >> q0;
 #pragma unroll
             for (int q = 0; q < 8; q += 2) {
@@ -255,17 +384,18 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         return wave_sum(s0 + s1);
     };
 
-    // hand-off: barrier, wave 0 publishes sm[oPUB ..] (block A: granules gA.., cA rows; block B), sweep of
-    // n granules, STORE(j, v) per granule of the thread, block sums of p0 / p1 on request
+    // hand-off: barrier, wave 0 publishes sm[oPUB ..] (block A: granules gA.., cA rows; block B: the values
+    // at oPUB + PUBW ..), sweep of n granules, STORE(j, v) per granule of the thread, block sums of p0 / p1
 #define RB_HANDOFF(NJ, n, gA, cA, gB, cB, STORE, want_sums, t0, t1)                                  \
     do {                                                                                           \
         double hv_[NJ];                                                                            \
+        RB_FRESH;                                                                                  \
         ++seq;                                                                                     \
         __syncthreads();                                                                           \
         if (w == 0) {                                                                              \
-            const int l8_ = lane & (RES_WAVES - 1);                                                \
-            const bool second_ = lane >= RES_WAVES;                                                \
-            if (lane < 2 * RES_WAVES && l8_ < (second_ ? (cB) : (cA)) &&                           \
+            const int l8_ = lane & (PUBW - 1);                                                     \
+            const bool second_ = lane >= PUBW;                                                     \
+            if (lane < 2 * PUBW && l8_ < (second_ ? (cB) : (cA)) &&                                \
                 !(seq == D.dbg_skip_seq && b == G - 1))                                            \
                 rb_publish(rs, seq, (second_ ? (gB) : (gA)) + l8_, sm[oPUB + lane]);               \
         }                                                                                          \
@@ -286,20 +416,21 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
             p0 = wave_sum(p0);                                                                     \
             if ((want_sums) > 1) p1 = wave_sum(p1);                                                \
             if (lane == 0) {                                                                       \
-                red[w] = p0;                                                                       \
-                if ((want_sums) > 1) red[RES_WAVES + w] = p1;                                      \
+                sm[oRED + w] = p0;                                                                       \
+                if ((want_sums) > 1) sm[oRED + RES_WAVES + w] = p1;                                      \
             }                                                                                      \
         }                                                                                          \
         __syncthreads();                                                                           \
         if (want_sums) {                                                                           \
-            t0 = res_red8(red);                                                                    \
-            if ((want_sums) > 1) t1 = res_red8(red + RES_WAVES);                                   \
+            t0 = res_red8(sm + oRED);                                                                    \
+            if ((want_sums) > 1) t1 = res_red8(sm + oRED + RES_WAVES);                                   \
         }                                                                                          \
         if (*fail) dead = true;                                                                    \
     } while (0)
     // exchange of K <= 2 partial sums per workgroup: t0 / t1 = their totals (same order everywhere)
 #define RB_PARTIALS(K, v0, v1, t0, t1)                                                             \
     do {                                                                                           \
+        RB_FRESH;                                                                                  \
         if (w == 0 && lane == 0) {                                                                 \
             sm[oPUB + 0] = (v0);                                                                   \
             sm[oPUB + 1] = (v1);                                                                   \
@@ -314,24 +445,36 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
 
     // block sum of a per-wave value held by lane 0 of the waves with a row (others contribute 0)
     auto own_pair_sum = [&](double vA, double vB, double& tA, double& tB) __attribute__((always_inline)) {
+        RB_FRESH;
         if (lane == 0) {
-            red[w] = vA;
-            red[RES_WAVES + w] = vB;
+            sm[oRED + w] = vA;
+            sm[oRED + RES_WAVES + w] = vB;
         }
         __syncthreads();
-        tA = res_red8(red);
-        tB = res_red8(red + RES_WAVES);
+        tA = res_red8(sm + oRED);
+        tB = res_red8(sm + oRED + RES_WAVES);
         __syncthreads();
     };
 
     // r = b - A x on the own rows, ||r|| and 1'r by partial sums; E1 := 0            Class_AMG.m:89,96,103
     auto top = [&]() __attribute__((always_inline)) {
-        const double sF = masked_sum(bitsF, oXS + nf, nc), sC = masked_sum(bitsC, oXS, nf);
-        rFv = vF ? RB_bF - (RB_dgF * xF - RB_alF * sF) : 0.0;
-        rCv = vC ? RB_bC - (RB_dgC * xC - RB_btC * sC) : 0.0;
-        eF = eC = 0.0;
+        RB_FRESH;
+        double a2_ = 0.0, a1_ = 0.0;
+#pragma unroll
+        for (int p = 0; p < RPW; ++p) {
+            const double sF = masked_sum(bitsF[p], oXS + nf, nc), sC = masked_sum(bitsC[p], oXS, nf);
+            const double rFv = vF[p] ? RB_bF(p) - (RB_dgF(p) * RB_xF(p) - RB_alF(p) * sF) : 0.0;
+            const double rCv = vC[p] ? RB_bC(p) - (RB_dgC(p) * RB_xC(p) - RB_btC(p) * sC) : 0.0;
+            if (lane == 0) {
+                RB_rF(p) = rFv;
+                RB_rC(p) = rCv;
+            }
+            eF[p] = eC[p] = 0.0;
+            a2_ += rFv * rFv + rCv * rCv;
+            a1_ += rFv + rCv;
+        }
         double q2 = 0.0, q1 = 0.0;
-        own_pair_sum((vF ? rFv * rFv : 0.0) + (vC ? rCv * rCv : 0.0), (vF ? rFv : 0.0) + (vC ? rCv : 0.0), q2, q1);
+        own_pair_sum(a2_, a1_, q2, q1);
         double nrm2 = 0.0;
         RB_PARTIALS(2, q2, q1, nrm2, sumr1);
         c1 = nsp ? sumr1 / xx1 : 0.0;
@@ -343,18 +486,32 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
     // one half of a bigraph Gauss-Seidel sweep on level 1                  MG_Vcycle.m:15-21,34-38
     double afirst = 0.0;   // (A1)'w over the half handed off first
     auto half1 = [&](bool frows, bool first, bool ezero) __attribute__((always_inline)) {
-        const bool valid = frows ? vF : vC;
-        double s = 0.0;
-        if (!(ezero && first)) s = frows ? masked_sum(bitsF, oE1S + nf, nc) : masked_sum(bitsC, oE1S, nf);
-        const double eo = ezero ? 0.0 : (frows ? eF : eC);
-        const double ae = (frows ? RB_dgF : RB_dgC) * eo - (frows ? RB_alF : RB_btC) * s;        // (A e)_row
-        const double g_i = (frows ? rFv : rCv) - ae - (frows ? RB_axF : RB_axC) * c1;
-        const double wv = eo + (frows ? RB_dvF : RB_dvC) * g_i;
+        RB_FRESH;
+        const double cc = c1;
+#pragma unroll
+        for (int p = 0; p < RPW; ++p) {
+            const bool valid = frows ? vF[p] : vC[p];
+            double s = 0.0;
+            if (!(ezero && first)) s = frows ? masked_sum(bitsF[p], oE1S + nf, nc) : masked_sum(bitsC[p], oE1S, nf);
+            const double eo = ezero ? 0.0 : (frows ? eF[p] : eC[p]);
+            const double ae = (frows ? RB_dgF(p) : RB_dgC(p)) * eo - (frows ? RB_alF(p) : RB_btC(p)) * s;   // (A e)_row
+            const double g_i = (frows ? RB_rF(p) : RB_rC(p)) - ae - (frows ? RB_axF(p) : RB_axC(p)) * cc;
+            const double wv = eo + (frows ? RB_dvF(p) : RB_dvC(p)) * g_i;
+            const double pub = first ? wv : wv + cc;
+            if (lane == 0) sm[oPUB + w + RES_WAVES * p] = pub;
+            if (first) {
+                if (frows) eF[p] = valid ? wv : 0.0; else eC[p] = valid ? wv : 0.0;
+            } else if (frows) {
+                eF[p] = valid ? pub : 0.0;
+                eC[p] = vC[p] ? eC[p] + cc : 0.0;
+            } else {
+                eC[p] = valid ? pub : 0.0;
+                eF[p] = vF[p] ? eF[p] + cc : 0.0;
+            }
+        }
         const int blk0 = frows ? 0 : nf, nblk = frows ? nf : nc;
         const int g0 = frows ? loF : loC, cnt = frows ? hiF - loF : hiC - loC;
         if (first) {
-            if (lane == 0) sm[oPUB + w] = wv;
-            if (frows) eF = valid ? wv : 0.0; else eC = valid ? wv : 0.0;
             RB_HANDOFF(4, nblk, g0, cnt, 0, 0,
                        {
                            sm[oE1S + blk0 + j] = (frows ? sF4[u_] : sC4[u_]) * v;
@@ -362,10 +519,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
                        },
                        (nsp ? 1 : 0), afirst, dum1);
         } else {
-            const double cc = c1;
-            const double en_own = wv + cc;
-            if (lane == 0) sm[oPUB + w] = en_own;
-            if (frows) { eF = valid ? en_own : 0.0; eC = vC ? eC + cc : 0.0; } else { eC = valid ? en_own : 0.0; eF = vF ? eF + cc : 0.0; }
             const int oth0 = frows ? nf : 0, noth = frows ? nc : nf;
             double asec = 0.0;
             RB_HANDOFF(4, nblk, g0, cnt, 0, 0,
@@ -386,22 +539,27 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         }
     };
     auto sweep1 = [&](bool post, bool ezero) __attribute__((always_inline)) {
+        RB_FRESH;
         half1(!post, true, ezero);    // pre: F rows first (Rk{1}); post: C rows first (Rk{1}')
         half1(post, false, ezero);
     };
 
     // weighted-Jacobi sweep on level 2                                   MG_Vcycle.m:15-21; Class_AMG.m:84
     auto sweep2 = [&](bool ezero) __attribute__((always_inline)) {
-        double s = 0.0, eo = 0.0;
-        if (!ezero) {
-            s = wave_sum(res_rowdot<KE2, 8 * oE2>(c2, a2, smb));
-            eo = e2v;
-            s += RB_dg2 * eo;
+        RB_FRESH;
+#pragma unroll
+        for (int p = 0; p < RPW; ++p) {
+            double s = 0.0, eo = 0.0;
+            if (!ezero) {
+                s = wave_sum(res_rowdot<KE2, 8 * oE2>(c2[p], a2[p], smb));
+                eo = e2v[p];
+                s += RB_dg2(p) * eo;
+            }
+            const double g_i = RB_r2(p) - s - RB_ax2(p) * c2s;
+            const double en = eo + RB_dv2(p) * g_i + c2s;
+            if (lane == 0) sm[oPUB + w + RES_WAVES * p] = en;
+            e2v[p] = vC[p] ? en : 0.0;
         }
-        const double g_i = r2v - s - RB_ax2 * c2s;
-        const double en = eo + RB_dv2 * g_i + c2s;
-        if (lane == 0) sm[oPUB + w] = en;
-        e2v = vC ? en : 0.0;
         double asum = 0.0;
         RB_HANDOFF(4, N2, loC, hiC - loC, 0, 0,
                    {
@@ -413,15 +571,117 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         c2s = nsp ? xig2 / xx2 : 0.0;
     };
 
-    // one visit of level 2 and of the one-row tail below it
+    // ---- DEEP: the polynomial level 3 and the remote tail below it -------------------------------------
+    const auto rtin = __builtin_amdgcn_make_buffer_rsrc(D.tin, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
+    const auto rtout = __builtin_amdgcn_make_buffer_rsrc(D.tout, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
+    unsigned tseq = 0;
+    double sumr3 = 0.0;
+    // hand-off among the level-3 rows: N3 values + one "ack" granule per workgroup (a workgroup without a
+    // row of level 3 still has to say that it has finished the step: two-buffer protocol)
+#define RB_HANDOFF3(STORE3, want_sums, t0)                                                           \
+    do {                                                                                           \
+        RB_FRESH;                                                                                  \
+        if (w == 0 && lane == 0) sm[oPUB + PUBW] = 0.0;                                            \
+        RB_HANDOFF(3, N3 + G, lo3, n3own, N3 + b, 1, { if (j < N3) { STORE3; } }, want_sums, t0, dum1); \
+    } while (0)
+    // the sums of this workgroup's rows against [r_3; e_3] (+ (M1 P4) e_4 in the second pass) and their factor
+    // of 1'r_3 -> sm[oPS + 40 + q]
+    // (the rows' coefficients -- entries tid and BT + tid of the two segments, entry tid of (M1 P4) -- are
+    // fetched from L2 at every pass, 21 coalesced loads in flight per thread: held in registers for the whole
+    // solve, as k_resident's POLY3 does with one entry per segment, these 48 registers pushed the per-granule
+    // constants of the hand-offs into scratch, reloaded at every hand-off)
+    auto poly3_rows = [&](int nrows, bool post) __attribute__((always_inline)) {
+        RB_FRESH;
+        double m3r[5][2], m3e[5][2], m3c[4];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int row = q < 4 ? lo3 + q : N3 + b;
+            const bool okr = q < nrows && (q < 4 ? row < hi3 : b < N4);
+            const double* pr = D.p3rows + (size_t)(okr ? row : 0) * RB_P3_LD;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = tid + u * BT;
+                const double vr = pr[j], ve = pr[RB_P3_SEG + j];   // (columns beyond N3: zeros of the pack)
+                m3r[q][u] = okr ? vr : 0.0;
+                m3e[q][u] = okr ? ve : 0.0;
+            }
+            if (q < 4) {
+                const double vc = pr[2 * RB_P3_SEG + (tid < RB_N4MAX ? tid : 0)];
+                m3c[q] = (okr && post && tid < N4) ? vc : 0.0;
+            }
+        }
+        double xr[2], xe[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = tid + u * BT;
+            xr[u] = sm[oR3L + j];     // (zero beyond N3)
+            xe[u] = sm[oE3L + j];
+        }
+        const double xc = (post && tid < N4) ? sm[oE4 + tid] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            if (q < nrows) {
+                double t = __builtin_fma(m3e[q][0], xe[0], m3r[q][0] * xr[0]);
+                t = __builtin_fma(m3r[q][1], xr[1], t);
+                t = __builtin_fma(m3e[q][1], xe[1], t);
+                if (q < 4) t = __builtin_fma(m3c[q], xc, t);
+                const double pq = wave_sum(t);
+                if (lane == 0) sm[oPS + 8 * q + w] = pq;
+            }
+        }
+        __syncthreads();
+        if (tid < nrows) {
+            double sq = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < RES_WAVES; ++ww) sq += sm[oPS + 8 * tid + ww];
+            sm[oPS + 40 + tid] = __builtin_fma(sm[oPS + 48 + tid], sumr3, sq);
+        }
+        __syncthreads();
+    };
+    // one visit of level 3 and, through the tail workgroup, of everything below it
+    auto visit3 = [&]() __attribute__((always_inline)) {
+        RB_FRESH;
+        ++tseq;
+        // e' = M2a r + M1 e and the restricted residual of e' in one pass                 MG_Vcycle.m:20-29
+        poly3_rows(5, false);
+        if (tid == 0 && b < N4)
+            __builtin_amdgcn_raw_buffer_store_b128(res_pack(sm[oPS + 44], tseq), rtin,
+                                                   (int)(tseq & 1) * (RES_GRAN_MAX * 16) + b * 16, 0, 16 /* sc1 */);
+        if (tid < 4) sm[oPUB + tid] = sm[oPS + 40 + tid];
+        RB_HANDOFF3({ sm[oE3L + j] = v; }, 0, dum0);
+        double hv[1];
+        int st = 0;
+        if (!dead) st = res_wait_slow<1>(rtout, tseq, N4, D.tmo, nullptr, hv);   // e_4
+        if (st) {
+            *fail = 1;
+            if (lane == 0) __hip_atomic_store(D.tmo, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < N4) sm[oE4 + tid] = (!dead && !st) ? hv[0] : 0.0;
+        __syncthreads();
+        if (*fail) dead = true;
+        poly3_rows(4, true);                                         // e'' = M2a r + M1 e' + (M1 P4) e_4   :31-41
+        if (tid < 4) sm[oPUB + tid] = sm[oPS + 40 + tid];
+        RB_HANDOFF3({ sm[oE3L + j] = v; }, 0, dum0);
+    };
+
+    // one visit of level 2 and of everything below it
     auto visit2 = [&](bool keep) __attribute__((always_inline)) {
+        RB_FRESH;
         const int nu = D.nu;
         for (int s = 0; s < nu; ++s) sweep2(!keep && s == 0);
-        {   // rr = r - A e on the own row; r_3 = P3' rr by partial sums                  MG_Vcycle.m:27
-            const double s = wave_sum(res_rowdot<KE2, 8 * oE2>(c2, a2, smb)) + RB_dg2 * e2v;
-            const double rr = vC ? r2v - s : 0.0;
+        // rr = r - A e on the own rows                                                     MG_Vcycle.m:27
+        double rr[RPW];
+#pragma unroll
+        for (int p = 0; p < RPW; ++p) {
+            const double s = wave_sum(res_rowdot<KE2, 8 * oE2>(c2[p], a2[p], smb)) + RB_dg2(p) * e2v[p];
+            rr[p] = vC[p] ? RB_r2(p) - s : 0.0;
+        }
+        if (!DEEP) {   // r_3 = P3' rr by partial sums, the one-row tail by every thread
+            double mine = 0.0;
+#pragma unroll
+            for (int p = 0; p < RPW; ++p) mine += vC[p] ? sm[oP3C + rCi[p]] * rr[p] : 0.0;
             double part = 0.0, dumA = 0.0;
-            own_pair_sum(vC ? sm[oP3C + rCi] * rr : 0.0, 0.0, part, dumA);
+            own_pair_sum(mine, 0.0, part, dumA);
             double r3 = 0.0;
             RB_PARTIALS(1, part, 0.0, r3, dum1);
             // PCG.m:68-87 on the 1 x 1 system, by every thread
@@ -439,32 +699,73 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
                 delta_new = r * wi;
                 pp = wi + (delta_new / delta_old) * pp;
             }
-            // e_2 += P3 e_3 on everybody's copy and on the own scalar; 1'(r - A e) moves by -d kappa
+            // e_2 += P3 e_3 on everybody's copy and on the own scalars; 1'(r - A e) moves by -d kappa
             for (int j = tid; j < N2; j += BT) sm[oE2 + j] = sm[oE2 + j] + sm[oP3C + j] * d;
-            e2v = vC ? e2v + sm[oP3C + rCi] * d : 0.0;
+#pragma unroll
+            for (int p = 0; p < RPW; ++p) e2v[p] = vC[p] ? e2v[p] + sm[oP3C + rCi[p]] * d : 0.0;
             xig2 = xig2 - d * kappa;
             c2s = nsp ? xig2 / xx2 : 0.0;
             __syncthreads();
+        } else {
+            // rr_2 to everybody (the rows of P3' gather from it), r_3 = P3' rr_2 by the owners of level 3's rows
+            if (lane == 0) {
+#pragma unroll
+                for (int p = 0; p < RPW; ++p) sm[oPUB + w + RES_WAVES * p] = rr[p];
+            }
+            RB_HANDOFF(4, N2, loC, hiC - loC, 0, 0, { sm[oRR2 + j] = v; }, 0, dum0, dum1);
+            const double s3 = w < n3own ? res_csr_rowdot(D.Pt3, pt3e0, pt3e1, lane, sm, oRR2) : 0.0;
+            if (lane == 0) sm[oPUB + w] = s3;
+            RB_HANDOFF3({ sm[oR3L + j] = v; sm[oE3L + j] = 0.0; p0 += v; }, (nsp ? 1 : 0), sumr3);
+            if (!nsp) sumr3 = 0.0;
+            for (int leg = 0; leg < (D.wcycle ? 2 : 1); ++leg) visit3();              // MG_Wcycle.m:28-30
+            // e_2 += P3 e_3 on the own rows                                            MG_Vcycle.m:31
+#pragma unroll
+            for (int p = 0; p < RPW; ++p) {
+                const double sP = res_csr_rowdot(D.P3d, p3e0[p], p3e1[p], lane, sm, oE3L);
+                const double en = e2v[p] + sP;
+                e2v[p] = vC[p] ? en : 0.0;
+                if (lane == 0) sm[oPUB + w + RES_WAVES * p] = en;
+            }
+            double asum = 0.0;
+            RB_HANDOFF(4, N2, loC, hiC - loC, 0, 0,
+                       {
+                           sm[oE2 + j] = v;
+                           p0 += ax2[u_] * v;
+                       },
+                       (nsp ? 1 : 0), asum, dum1);
+            xig2 = sumr2 - asum;
+            c2s = nsp ? xig2 / xx2 : 0.0;
         }
         for (int s = 0; s < nu; ++s) sweep2(false);
     };
 
     // MG_Vcycle / MG_Wcycle from level 1 down; the correction ends in E1S / eF, eC
     auto cycle = [&]() __attribute__((always_inline)) {
+        RB_FRESH;
         const int nu = D.nu;
         for (int s = 0; s < nu; ++s) sweep1(false, s == 0);
         {   // rr = r - A e; the F part goes out scaled by rho (the restriction's operand), the C part stays
-            const double sF = masked_sum(bitsF, oE1S + nf, nc), sC = masked_sum(bitsC, oE1S, nf);
-            const double rrF = rFv - (RB_dgF * eF - RB_alF * sF);
-            const double rrC = rCv - (RB_dgC * eC - RB_btC * sC);
-            if (lane == 0) sm[oPUB + w] = RB_rhF * rrF;
+            double rrC[RPW];
+#pragma unroll
+            for (int p = 0; p < RPW; ++p) {
+                const double sF = masked_sum(bitsF[p], oE1S + nf, nc), sC = masked_sum(bitsC[p], oE1S, nf);
+                const double rrF = RB_rF(p) - (RB_dgF(p) * eF[p] - RB_alF(p) * sF);
+                rrC[p] = RB_rC(p) - (RB_dgC(p) * eC[p] - RB_btC(p) * sC);
+                if (lane == 0) sm[oPUB + w + RES_WAVES * p] = RB_rhF(p) * rrF;
+            }
             RB_HANDOFF(4, nf, loF, hiF - loF, 0, 0, { sm[oTU + j] = v; }, 0, dum0, dum1);
             // r_2 = P' rr: row c of P' is [W(:,c)', 1 at the C node]; E2 := 0; 1'r_2 by partial sums
-            const double s2 = RB_btC * masked_sum(bitsC, oTU, nf) + rrC;
-            r2v = vC ? s2 : 0.0;
-            e2v = 0.0;
+            double mine = 0.0;
+#pragma unroll
+            for (int p = 0; p < RPW; ++p) {
+                const double s2 = RB_btC(p) * masked_sum(bitsC[p], oTU, nf) + rrC[p];
+                const double r2 = vC[p] ? s2 : 0.0;
+                if (lane == 0) RB_r2(p) = r2;
+                e2v[p] = 0.0;
+                mine += r2;
+            }
             double part = 0.0, dumA = 0.0;
-            own_pair_sum(r2v, 0.0, part, dumA);
+            own_pair_sum(mine, 0.0, part, dumA);
             RB_PARTIALS(1, part, 0.0, sumr2, dum1);
             xig2 = sumr2;
             c2s = nsp ? sumr2 / xx2 : 0.0;
@@ -477,20 +778,31 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
                 if (j < N2) sm[oTU + j] = sC4[q] * sm[oE2 + j];   // (level 2 = the C nodes: beta_j)
             }
             __syncthreads();
-            const double sF = RB_rhF * masked_sum(bitsF, oTU, N2);
-            const double nF = eF + sF, nC = eC + e2v;
-            eF = vF ? nF : 0.0;
-            eC = vC ? nC : 0.0;
+            double nF[RPW], nC[RPW];
+#pragma unroll
+            for (int p = 0; p < RPW; ++p) {
+                const double sF = RB_rhF(p) * masked_sum(bitsF[p], oTU, N2);
+                nF[p] = eF[p] + sF;
+                nC[p] = eC[p] + e2v[p];
+                eF[p] = vF[p] ? nF[p] : 0.0;
+                eC[p] = vC[p] ? nC[p] : 0.0;
+            }
             // the new iterate goes out block by block (a thread's constants are per block)
             double asF = 0.0, asC = 0.0;
-            if (lane == 0) sm[oPUB + w] = nF;
+            if (lane == 0) {
+#pragma unroll
+                for (int p = 0; p < RPW; ++p) sm[oPUB + w + RES_WAVES * p] = nF[p];
+            }
             RB_HANDOFF(4, nf, loF, hiF - loF, 0, 0,
                        {
                            sm[oE1S + j] = sF4[u_] * v;
                            p0 += aF4[u_] * v;
                        },
                        (nsp ? 1 : 0), asF, dum1);
-            if (lane == 0) sm[oPUB + w] = nC;
+            if (lane == 0) {
+#pragma unroll
+                for (int p = 0; p < RPW; ++p) sm[oPUB + w + RES_WAVES * p] = nC[p];
+            }
             RB_HANDOFF(4, nc, loC, hiC - loC, 0, 0,
                        {
                            sm[oE1S + nf + j] = sC4[u_] * v;
@@ -503,9 +815,14 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
     };
 
     auto add_correction = [&]() __attribute__((always_inline)) {   // x += e                          Class_AMG.m:98,101
+        RB_FRESH;
         for (int j = tid; j < N1; j += BT) sm[oXS + j] = sm[oXS + j] + sm[oE1S + j];
-        xF = xF + eF;
-        xC = xC + eC;
+#pragma unroll
+        for (int p = 0; p < RPW; ++p)
+            if (lane == 0) {
+                RB_xF(p) = RB_xF(p) + eF[p];
+                RB_xC(p) = RB_xC(p) + eC[p];
+            }
         __syncthreads();
     };
 
@@ -565,9 +882,14 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         it = fixed_cycles;
     else if (res0 != 0.0)
         it -= 1;                                                                  // :108
+    if (DEEP && b == 0 && tid == 0)   // release the tail workgroup
+        __hip_atomic_store(D.tctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane == 0) {   // every workgroup writes its own rows of x
-        if (vF) xg[rF] = xF;
-        if (vC) xg[nf + rCi] = xC;
+#pragma unroll
+        for (int p = 0; p < RPW; ++p) {
+            if (vF[p]) xg[rF[p]] = RB_xF(p);
+            if (vC[p]) xg[nf + rCi[p]] = RB_xC(p);
+        }
     }
     if (writer) {
         const unsigned anytmo = __hip_atomic_load(D.tmo, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -575,10 +897,13 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         out[1] = rel_res;
         out[2] = res0;
         out[3] = (dead || anytmo != 0) ? 1.0 : 0.0;
-        out[4 + 2 * (maxit + 2) - 1] = (double)seq;   // hand-offs of this launch (see k_resident)
+        out[4 + 2 * (maxit + 2) - 1] = (double)(seq + tseq);   // hand-offs of this launch (see k_resident)
     }
+#undef RB_HANDOFF3
+#undef RB_FRESH
 #undef RB_PARTIALS
 #undef RB_HANDOFF
+#undef RB_OWN
 #undef RB_dgF
 #undef RB_dvF
 #undef RB_bF
@@ -593,4 +918,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
 #undef RB_dg2
 #undef RB_dv2
 #undef RB_ax2
+#undef RB_xF
+#undef RB_xC
+#undef RB_rF
+#undef RB_rC
+#undef RB_r2
 }

@@ -107,7 +107,7 @@ def test_n2048_runs_in_the_big_kernel(ipd, n2048, cycle):
     assert h.attach_mask_operator(np.ones(m), np.ones(n), bench.TK)
     mode, grid, _ = solve_mode(h)
     assert (mode, grid) == (2, 256), (mode, grid)
-    assert resident_kernel_name(h) == "k_resident_big<32>"
+    assert resident_kernel_name(h) == "k_resident_big<32,1,false>"
     with env(IPD_NO_RESIDENT_BIG=1):
         hc = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
         assert hc.attach_mask_operator(np.ones(m), np.ones(n), bench.TK)
