@@ -87,6 +87,8 @@ void amg_prepare_levels(ipd_amg* h);  // dinv, Axi, xx, work vectors
 void amg_cycle(ipd_amg* h, int k, int isnsp, bool wcycle, bool keep_e);
 bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int m, int n, double tk,
                        bool policy, bool transfers_only = false);
+// a component's mask form is only of use beyond k_resident's 2048 rows (the mask-form kernel's deep mode)
+static constexpr int RES_MASK_MIN_ROWS = 2048;
 void amg_solve_dev(ipd_amg* h, const double* b_dev, const double* guess_dev, double* x_dev,
                    int32_t* it, double* rel_res, double* rel_resk, double* rhok);
 void pcg_dev(ipd_ctx* ctx, const Csr& H, const double* e, const double* guess, double tol,

@@ -657,6 +657,16 @@ static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, 
         out->it_num = 0;
         std::vector<int> newidx((size_t)M);
         int* d_new = tmp.alloc<int>((size_t)M);
+        // [q; p] in the order of the unknowns: a large component's own q (its F rows) and p (its C rows) are
+        // gathered from it for the mask form of its level 1 (amg_attach_maskop: the sub-matrix Ae(pk, pk) of a
+        // component has the same rank-one structure, with the component's entries of p and q)
+        double* qp = nullptr;
+        for (int k = 0; k < cc.ncomp && !qp; ++k)
+            if (cc.sizes[k] > RES_MASK_MIN_ROWS && opts.bigph) {
+                qp = tmp.alloc<double>((size_t)M);
+                IPD_HIP(hipMemcpyAsync(qp, q, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+                IPD_HIP(hipMemcpyAsync(qp + n, p, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, ctx->stream));
+            }
         for (int k = 0; k < cc.ncomp; ++k) {                              // :55 large components
             if (cc.sizes[k] <= N0) continue;
             const int nk = cc.sizes[k];
@@ -690,7 +700,19 @@ static void hybrid_amg_cached(ipd_ctx* ctx, const Csr& H0, const double* tdiag, 
             const int isnsp = sum_dk(pk, nk) != 0.0 ? 0 : 1;              // :60-66
             IPD_REQUIRE(fnode > 0 && fnode < nk, IPD_E_NUMERIC,
                         "Hybrid_AMG: a large component lies on one side of the bigraph");
-            auto run = class_amg_prepare(ctx, Ak, fk, opts, isnsp, fnode, gscale, rng, dk, MaskHint(), cache);
+            MaskHint mhk;
+            if (qp && nk > RES_MASK_MIN_ROWS) {
+                double* qpk = tmp.alloc<double>((size_t)nk);
+                hipLaunchKernelGGL(k_gather, dim3(elems_grid(nk)), dim3(256), 0, ctx->stream, nk, d_pk,
+                                   (const double*)qp, qpk);
+                IPD_KERNEL_CHECK();
+                mhk.q = qpk;
+                mhk.p = qpk + fnode;
+                mhk.n = fnode;
+                mhk.m = nk - fnode;
+                mhk.tk = tk;
+            }
+            auto run = class_amg_prepare(ctx, Ak, fk, opts, isnsp, fnode, gscale, rng, dk, mhk, cache);
             defer([run, out, ctx, nk, d_pk, dk, u, k] {
                 int it = 0;
                 double rr = 0.0;
