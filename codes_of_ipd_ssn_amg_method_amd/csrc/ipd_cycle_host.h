@@ -54,6 +54,8 @@ struct CycleState {
     size_t sub4_lds = 0;           // (packed beside d_sub when that one is rooted at level 3)
     SolveDesc* d_sub3 = nullptr;   // image rooted at level 3 for the resident kernel alone (k_sub == 0)
     size_t sub3_lds = 0;
+    SolveDesc* d_sub5 = nullptr;   // image rooted at level 5 for the mask-form kernel's deep mode with level 4 resident
+    size_t sub5_lds = 0;
     int k_sub = 0;
     size_t sub_lds = 0;
     double* x2 = nullptr;
@@ -80,6 +82,7 @@ struct CycleState {
     ResBigDesc resb_desc;
     int resb_ke2 = 16;
     bool resb_deep = false;  // realistic hierarchy: level 3 in polynomial form, remote tail at level 4 (RPW = 2)
+    bool resb_poly4 = false; // ... level 4 in polynomial form as well, remote tail at level 5
     hipGraphExec_t gexec[2] = {nullptr, nullptr};  // captured Class_AMG loop bodies (x->x2, x2->x)
     const double* gb = nullptr;                    // right-hand side the graphs were captured for
     ~CycleState() {
@@ -1544,6 +1547,24 @@ void amg_prepare_levels(ipd_amg* h) {
             st->d_sub3 = build_image(sd.get(), 3, stage, &st->sub3_lds);
         }
     }
+    // (b4) Level 1 beyond k_resident's 2048 rows, six levels or more, the sub-cycle rooted at level 4: the
+    // mask-form resident kernel (deep mode, ipd_resident_big.h) keeps level 4 in polynomial form in its
+    // workgroups as well and roots its tail workgroup at level 5 -- an image of levels 5..J for it alone.
+    if (st->k_sub == 4 && st->d_sub && h->J >= 6 && h->J <= SOLVE_ML && lean_vectors && h->L[1].A.nr > RES_NMAX &&
+        h->L[1].nf > 0 && h->L[4].A.nr <= RB_N4MAX && h->L[5].A.nr <= RB_N5MAX && h->opts.smoth >= 1 &&
+        !(std::getenv("IPD_NO_RES_POLY4") && std::getenv("IPD_NO_RES_POLY4")[0] == '1') &&
+        !(std::getenv("IPD_NO_RESIDENT") && std::getenv("IPD_NO_RESIDENT")[0] == '1')) {
+        const size_t stage = 16;
+        std::unique_ptr<SolveDesc> sd(new SolveDesc());
+        fill_desc(sd.get());
+        sd->k_lds = 5;
+        sd->k_tiny = tiny_from(5);
+        sd->k_blk = blk_from(5);
+        sd->stage_bytes = (int)stage;
+        sd->root_r = h->L[5].r;
+        sd->root_e = h->L[5].e;
+        st->d_sub5 = build_image(sd.get(), 5, stage, &st->sub5_lds);
+    }
     plan_resident(h, st.get());
     if (const char* dbg = std::getenv("IPD_DEBUG_LEVELS"); dbg && dbg[0] == '1') {
         std::fprintf(stderr, "[ipd] J=%d small=%d k_sub=%d resident=%d(G=%d,KE=%d) levels:", h->J,
@@ -1989,6 +2010,16 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
                 const BPolyDev pb = pack_bpoly(ctx, h, st, 3, h->opts.isnsp, 0, true, RB_P3_SEG, RB_P3_LD);
                 st->level_forms.resize((size_t)h->J + 1, 0);
                 st->level_forms[3] |= 64;
+                // level 4 resident as well (POLY4), the tail rooted at level 5
+                const int N5 = h->J >= 6 ? h->L[5].A.nr : 0;
+                const bool poly4 = st->d_sub5 && deep_img == st->d_sub && N4 <= 2 * G && N5 >= 1 && N5 <= G &&
+                                   N5 <= RB_N5MAX && N4 + G <= BT &&
+                                   std::max(RB_LDS_BYTES, st->sub5_lds) <= (size_t)156 * 1024;
+                BPolyDev pb4;
+                if (poly4) {
+                    pb4 = pack_bpoly(ctx, h, st, 4, h->opts.isnsp, 0, true, RB_P4_SEG, RB_P4_LD);
+                    st->level_forms[4] |= 64;
+                }
                 ResBigDesc B{};
                 B.nf = n;
                 B.nc = m;
@@ -2027,6 +2058,9 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
                 B.P3d.va = h->L[3].P.va;
                 B.p3rows = pb.M;
                 B.p3w = pb.W;
+                B.N5 = poly4 ? N5 : 0;
+                B.p4rows = pb4.M;
+                B.p4w = pb4.W;
                 B.nu = h->opts.smoth;
                 B.isnsp = h->opts.isnsp;
                 B.wcycle = h->opts.cycle == 'w';
@@ -2043,7 +2077,8 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
                 B.gran = st->res_block;
                 B.tmo = reinterpret_cast<unsigned*>(st->res_block + 2 * gbytes);
                 B.dbg_skip_seq = 0;
-                B.sub = deep_img;
+                B.sub = poly4 ? st->d_sub5 : deep_img;
+                if (poly4) deep_img_lds = st->sub5_lds;
                 B.tin = st->res_block + 2 * gbytes + 16;
                 B.tout = st->res_block + 2 * gbytes + 16 + 2 * tbytes;
                 B.tctl = reinterpret_cast<unsigned*>(st->res_block + 2 * gbytes + 16 + 4 * tbytes);
@@ -2051,6 +2086,7 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
                 st->resb_ke2 = d2.S <= 64 * 4 ? 4 : 8;
                 st->resb = true;
                 st->resb_deep = true;
+                st->resb_poly4 = poly4;
                 st->res_remote = true;
                 st->res_ke3 = 1;
                 st->res_G = G;
@@ -2522,8 +2558,8 @@ extern "C" int ipd_amg_resident_levels(const ipd_amg* h, int32_t* levels, int32_
         IPD_REQUIRE(h, IPD_E_ARG, "NULL handle");
         const CycleState* st = h->cyc.get();
         const bool on = st && st->res_ok;
-        if (levels) *levels = on ? (st->res_ke3 > 0 ? 3 : 2) : 0;
-        if (tail_root) *tail_root = on ? (st->res_ke3 > 0 ? 4 : 3) : 0;
+        if (levels) *levels = on ? (st->resb_poly4 ? 4 : st->res_ke3 > 0 ? 3 : 2) : 0;
+        if (tail_root) *tail_root = on ? (st->resb_poly4 ? 5 : st->res_ke3 > 0 ? 4 : 3) : 0;
     });
 }
 

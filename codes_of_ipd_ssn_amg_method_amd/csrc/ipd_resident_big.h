@@ -38,11 +38,14 @@ static constexpr int RB_N3MAX = 2 * BT;                // rows of the polynomial
 static constexpr int RB_N4MAX = BT / 2;                // rows of the remote tail's root level (DEEP)
 static constexpr int RB_P3_SEG = RB_N3MAX;             // p3rows layout: [Mr (RB_P3_SEG) | Me (RB_P3_SEG) | Mc (RB_N4MAX)]
 static constexpr int RB_P3_LD = 2 * RB_P3_SEG + RB_N4MAX;
+static constexpr int RB_N5MAX = BT / 4;                // rows of the tail's root level when level 4 is resident too (POLY4)
+static constexpr int RB_P4_SEG = RB_N4MAX;             // p4rows layout: [Mr (RB_P4_SEG) | Me (RB_P4_SEG) | Mc (RB_N5MAX)]
+static constexpr int RB_P4_LD = 2 * RB_P4_SEG + RB_N5MAX;
 // LDS (doubles): E2, TU, P3C / RR2, E1S, XS, reductions, publish slots, own-row constants, fail word;
-// DEEP: R3, E3 (RB_N3MAX each), E4 (RB_N4MAX), 64 partial sums of the polynomial passes
+// DEEP: R3, E3 (RB_N3MAX each), E4, R4 (RB_N4MAX each), E5 (RB_N5MAX), 128 partial sums of the polynomial passes
 static constexpr size_t RB_LDS_DOUBLES = (size_t)2 * RB_NMAX + 3 * RB_HALF + 2 * RES_WAVES +
                                          2 * 8 * RB_RPW_MAX + 20 * 8 * RB_RPW_MAX + 8 +
-                                         2 * RB_N3MAX + RB_N4MAX + 64;
+                                         2 * RB_N3MAX + 2 * RB_N4MAX + RB_N5MAX + 128;
 static constexpr size_t RB_LDS_BYTES = sizeof(double) * RB_LDS_DOUBLES;
 
 struct ResBigDesc {
@@ -70,6 +73,13 @@ struct ResBigDesc {
     ResCsr Pt3, P3d;          // level 2 <-> 3: rows of P3' (N3 x N2) and of P3 (N2 x N3)
     const double* p3rows;     // [N3 + N4][RB_P3_LD]: pack_bpoly's row layout with RB_P3_SEG segments
     const double* p3w;        // N3 + N4: the rows' factors of 1'r_3
+    // POLY4 (N5 > 0): level 4 in polynomial form in the resident workgroups as well (at most two rows each and
+    // one restriction row: N4 <= 2 G, N5 <= G), the tail workgroup rooted at level 5.  With the tail rooted at
+    // level 4 a W cycle streams level 4's operators (0.9 MB at 200 rows) sixteen times through ONE compute
+    // unit: 176 of 444 us on the Newton systems of the m = n = 2048 run.
+    int N5;
+    const double* p4rows;     // [N4 + N5][RB_P4_LD]
+    const double* p4w;        // N4 + N5
     // ... and what its tail workgroup needs (res_tail_workgroup's fields of ResDesc)
     const SolveDesc* sub;     // LDS image of levels 4..J
     unsigned char* tin;       // 2 x RES_GRAN_MAX granules by visit parity: r_4 for the tail
@@ -134,8 +144,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         __shared__ int tail_stat[RES_WAVES];
         ResDesc T{};
         T.sub = D.sub;
-        T.tail_root = 4;
-        T.Nt = D.N4;
+        T.tail_root = D.N5 > 0 ? 5 : 4;
+        T.Nt = D.N5 > 0 ? D.N5 : D.N4;
         T.remote = 1;
         T.three = 1;
         T.wcycle = D.wcycle;
@@ -150,13 +160,15 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         return;
     }
     const int nf = D.nf, nc = D.nc, N1 = nf + nc, N2 = D.N2;
-    const int N3 = DEEP ? D.N3 : 0, N4 = DEEP ? D.N4 : 0;
+    const int N3 = DEEP ? D.N3 : 0, N4 = DEEP ? D.N4 : 0, N5 = DEEP ? D.N5 : 0;
+    const bool poly4 = DEEP && N5 > 0;
     // LDS map (doubles); E2 is a gather target of the register rows: below 64 KB
     constexpr int oE2 = 0, oTU = RB_HALF, oP3C = 2 * RB_HALF, oE1S = 3 * RB_HALF, oXS = oE1S + RB_NMAX;
     constexpr int oRR2 = oP3C;   // DEEP: rr_2 for everybody (there is no one-row tail column then)
     constexpr int oRED = oXS + RB_NMAX, oPUB = oRED + 2 * RES_WAVES, oOWN = oPUB + 2 * 8 * RB_RPW_MAX;
     constexpr int oFAIL = oOWN + 20 * 8 * RB_RPW_MAX;
-    constexpr int oR3L = oFAIL + 8, oE3L = oR3L + RB_N3MAX, oE4 = oE3L + RB_N3MAX, oPS = oE4 + RB_N4MAX;
+    constexpr int oR3L = oFAIL + 8, oE3L = oR3L + RB_N3MAX, oE4 = oE3L + RB_N3MAX, oR4L = oE4 + RB_N4MAX;
+    constexpr int oE5 = oR4L + RB_N4MAX, oPS = oE5 + RB_N5MAX;   // (oPS: 128 doubles)
     int* fail = reinterpret_cast<int*>(sm + oFAIL);
     double* red = sm + oRED;
 
@@ -306,6 +318,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
     // that produce this workgroup's r_3 entries (wave q < n3own) and the rows of P3 of the own level-2 rows
     const int lo3 = DEEP ? (int)(((long long)b * N3) / G) : 0, hi3 = DEEP ? (int)(((long long)(b + 1) * N3) / G) : 0;
     const int n3own = hi3 - lo3;
+    const int lo4 = poly4 ? (int)(((long long)b * N4) / G) : 0, hi4 = poly4 ? (int)(((long long)(b + 1) * N4) / G) : 0;
+    const int n4own = hi4 - lo4;
     int pt3e0 = 0, pt3e1 = 0, p3e0[RPW], p3e1[RPW];
 #pragma unroll
     for (int p = 0; p < RPW; ++p) p3e0[p] = p3e1[p] = 0;
@@ -325,7 +339,12 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
                 p3e1[p] = D.P3d.rp[rCi[p] + 1];
             }
         for (int j = tid; j < RB_N3MAX; j += BT) sm[oR3L + j] = sm[oE3L + j] = 0.0;
-        for (int j = tid; j < RB_N4MAX; j += BT) sm[oE4 + j] = 0.0;
+        for (int j = tid; j < RB_N4MAX; j += BT) sm[oE4 + j] = sm[oR4L + j] = 0.0;
+        for (int j = tid; j < RB_N5MAX; j += BT) sm[oE5 + j] = 0.0;
+        if (poly4 && tid < 3) {
+            const int row = tid < 2 ? lo4 + tid : N4 + b;
+            sm[oPS + 112 + tid] = (tid < 2 ? row < hi4 : b < N5) ? D.p4w[row] : 0.0;
+        }
     }
     // x: scaled gather copy for everybody, the own rows' values as wave scalars
     for (int j = tid; j < N1; j += BT) {
@@ -584,6 +603,21 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         if (w == 0 && lane == 0) sm[oPUB + PUBW] = 0.0;                                            \
         RB_HANDOFF(3, N3 + G, lo3, n3own, N3 + b, 1, { if (j < N3) { STORE3; } }, want_sums, t0, dum1); \
     } while (0)
+    // ... whose ack granule of workgroup b < N4 carries r_4[b] (POLY4: the restricted residual goes to everybody)
+#define RB_HANDOFF3R(ACKV, STORE3, STORE4, want_sums, t0)                                            \
+    do {                                                                                           \
+        RB_FRESH;                                                                                  \
+        if (w == 0 && lane == 0) sm[oPUB + PUBW] = (ACKV);                                         \
+        RB_HANDOFF(3, N3 + G, lo3, n3own, N3 + b, 1,                                               \
+                   { if (j < N3) { STORE3; } else if (j - N3 < N4) { const int j4 = j - N3; STORE4; } }, want_sums, t0, dum1); \
+    } while (0)
+    // the same among the rows of level 4 (N4 + G <= BT granules: one per thread)
+#define RB_HANDOFF4(STORE4)                                                                          \
+    do {                                                                                           \
+        RB_FRESH;                                                                                  \
+        if (w == 0 && lane == 0) sm[oPUB + PUBW] = 0.0;                                            \
+        RB_HANDOFF(1, N4 + G, lo4, n4own, N4 + b, 1, { if (j < N4) { STORE4; } }, 0, dum0, dum1);  \
+    } while (0)
     // the sums of this workgroup's rows against [r_3; e_3] (+ (M1 P4) e_4 in the second pass) and their factor
     // of 1'r_3 -> sm[oPS + 40 + q]
     // (the rows' coefficients -- entries tid and BT + tid of the two segments, entry tid of (M1 P4) -- are
@@ -638,27 +672,96 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         }
         __syncthreads();
     };
-    // one visit of level 3 and, through the tail workgroup, of everything below it
-    auto visit3 = [&]() __attribute__((always_inline)) {
+    // POLY4: the sums of this workgroup's rows of level 4 (at most two, and restriction row b) against
+    // [r_4; e_4] (+ (M1 P5) e_5 in the second pass) -> sm[oPS + 104 + q]; one entry per thread and segment
+    double sumr4 = 0.0;
+    auto poly4_rows = [&](int nrows, bool post) __attribute__((always_inline)) {
         RB_FRESH;
-        ++tseq;
-        // e' = M2a r + M1 e and the restricted residual of e' in one pass                 MG_Vcycle.m:20-29
-        poly3_rows(5, false);
-        if (tid == 0 && b < N4)
-            __builtin_amdgcn_raw_buffer_store_b128(res_pack(sm[oPS + 44], tseq), rtin,
-                                                   (int)(tseq & 1) * (RES_GRAN_MAX * 16) + b * 16, 0, 16 /* sc1 */);
-        if (tid < 4) sm[oPUB + tid] = sm[oPS + 40 + tid];
-        RB_HANDOFF3({ sm[oE3L + j] = v; }, 0, dum0);
+        double m4r[3], m4e[3], m4c[2];
+        const int t4 = tid < RB_N4MAX ? tid : 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int row = q < 2 ? lo4 + q : N4 + b;
+            const bool okr = q < nrows && (q < 2 ? row < hi4 : b < N5) && tid < RB_N4MAX;
+            const double* pr = D.p4rows + (size_t)(okr ? row : 0) * RB_P4_LD;
+            const double vr = pr[t4], ve = pr[RB_P4_SEG + t4];
+            m4r[q] = okr ? vr : 0.0;
+            m4e[q] = okr ? ve : 0.0;
+            if (q < 2) {
+                const double vc = pr[2 * RB_P4_SEG + (tid < RB_N5MAX ? tid : 0)];
+                m4c[q] = (okr && post && tid < N5) ? vc : 0.0;
+            }
+        }
+        const double xr = sm[oR4L + t4], xe = sm[oE4 + t4];
+        const double xc = (post && tid < N5) ? sm[oE5 + tid] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (q < nrows) {
+                double t = __builtin_fma(m4e[q], xe, m4r[q] * xr);
+                if (q < 2) t = __builtin_fma(m4c[q], xc, t);
+                const double pq = wave_sum(t);
+                if (lane == 0) sm[oPS + 64 + 8 * q + w] = pq;
+            }
+        }
+        __syncthreads();
+        if (tid < nrows) {
+            double sq = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < RES_WAVES; ++ww) sq += sm[oPS + 64 + 8 * tid + ww];
+            sm[oPS + 104 + tid] = __builtin_fma(sm[oPS + 112 + tid], sumr4, sq);
+        }
+        __syncthreads();
+    };
+    // waits for the tail's answer (n values) and leaves it at sm[off ..]
+    auto tail_answer = [&](int n, int off) __attribute__((always_inline)) {
+        RB_FRESH;
         double hv[1];
         int st = 0;
-        if (!dead) st = res_wait_slow<1>(rtout, tseq, N4, D.tmo, nullptr, hv);   // e_4
+        if (!dead) st = res_wait_slow<1>(rtout, tseq, n, D.tmo, nullptr, hv);
         if (st) {
             *fail = 1;
             if (lane == 0) __hip_atomic_store(D.tmo, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (tid < N4) sm[oE4 + tid] = (!dead && !st) ? hv[0] : 0.0;
+        if (tid < n) sm[off + tid] = (!dead && !st) ? hv[0] : 0.0;
         __syncthreads();
         if (*fail) dead = true;
+    };
+    // one visit of level 4 (POLY4) and, through the tail workgroup, of everything below it
+    auto visit4 = [&]() __attribute__((always_inline)) {
+        RB_FRESH;
+        ++tseq;
+        poly4_rows(3, false);                                        // e_4' and r_5 = P5'(r_4 - A_4 e_4')
+        if (tid == 0 && b < N5)
+            __builtin_amdgcn_raw_buffer_store_b128(res_pack(sm[oPS + 106], tseq), rtin,
+                                                   (int)(tseq & 1) * (RES_GRAN_MAX * 16) + b * 16, 0, 16 /* sc1 */);
+        if (tid < 2) sm[oPUB + tid] = sm[oPS + 104 + tid];
+        RB_HANDOFF4({ sm[oE4 + j] = v; });
+        tail_answer(N5, oE5);                                        // e_5
+        poly4_rows(2, true);                                         // e_4'' = M2a r + M1 e' + (M1 P5) e_5
+        if (tid < 2) sm[oPUB + tid] = sm[oPS + 104 + tid];
+        RB_HANDOFF4({ sm[oE4 + j] = v; });
+    };
+    // one visit of level 3 and of everything below it
+    auto visit3 = [&]() __attribute__((always_inline)) {
+        RB_FRESH;
+        // e' = M2a r + M1 e and the restricted residual of e' in one pass                 MG_Vcycle.m:20-29
+        poly3_rows(5, false);
+        if (poly4) {   // r_4 to everybody in the ack granules of level 3's hand-off; e_4 := 0
+            if (tid < 4) sm[oPUB + tid] = sm[oPS + 40 + tid];
+            double s4 = 0.0;
+            RB_HANDOFF3R((b < N4 ? sm[oPS + 44] : 0.0), { sm[oE3L + j] = v; },
+                         { sm[oR4L + j4] = v; sm[oE4 + j4] = 0.0; p0 += v; }, (nsp ? 1 : 0), s4);
+            sumr4 = nsp ? s4 : 0.0;
+            for (int leg = 0; leg < (D.wcycle ? 2 : 1); ++leg) visit4();              // MG_Wcycle.m:28-30
+        } else {
+            ++tseq;
+            if (tid == 0 && b < N4)
+                __builtin_amdgcn_raw_buffer_store_b128(res_pack(sm[oPS + 44], tseq), rtin,
+                                                       (int)(tseq & 1) * (RES_GRAN_MAX * 16) + b * 16, 0, 16 /* sc1 */);
+            if (tid < 4) sm[oPUB + tid] = sm[oPS + 40 + tid];
+            RB_HANDOFF3({ sm[oE3L + j] = v; }, 0, dum0);
+            tail_answer(N4, oE4);                                    // e_4
+        }
         poly3_rows(4, true);                                         // e'' = M2a r + M1 e' + (M1 P4) e_4   :31-41
         if (tid < 4) sm[oPUB + tid] = sm[oPS + 40 + tid];
         RB_HANDOFF3({ sm[oE3L + j] = v; }, 0, dum0);
@@ -900,6 +1003,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         out[4 + 2 * (maxit + 2) - 1] = (double)(seq + tseq);   // hand-offs of this launch (see k_resident)
     }
 #undef RB_HANDOFF3
+#undef RB_HANDOFF3R
+#undef RB_HANDOFF4
 #undef RB_FRESH
 #undef RB_PARTIALS
 #undef RB_HANDOFF

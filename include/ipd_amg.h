@@ -412,8 +412,9 @@ int ipd_amg_cycle_bytes(const ipd_amg* h, double* bytes_per_cycle);
  * one workgroup's LDS -- then *grid counts that tail workgroup too); *timeouts = launches of mode 2
  * that gave up and were redone in mode 0.                                                      */
 int ipd_amg_solve_mode(const ipd_amg* h, int32_t* mode, int32_t* grid, int32_t* timeouts);
-/* Mode 2 only: *levels = levels kept in the registers of the resident workgroups (2 or 3),
- * *tail_root = level at which the rest starts (3, or 4 below a resident level 3); zeros otherwise. */
+/* Mode 2 only: *levels = levels kept by the resident workgroups (2, 3, or 4: the mask-form kernel's deep
+ * mode with levels 3 and 4 in polynomial form), *tail_root = level at which the rest starts (levels + 1);
+ * zeros otherwise.                                                                                  */
 int ipd_amg_resident_levels(const ipd_amg* h, int32_t* levels, int32_t* tail_root);
 /* Mode 2 only: name = the kernel instantiation a solve of this hierarchy launches, as a rocprofv3
  * kernel trace spells it ("k_resident<16,16,0>", "k_resident_big<32>"; "" in the other modes; cap =

@@ -79,7 +79,7 @@ def test_deep_mode_against_the_oracle_and_the_launches(ipd, newton2048, cycle):
     from codes_of_ipd_ssn_amg_method_amd import _lib
     lev, root = c_int32(), c_int32()
     _lib.check(_lib.lib.ipd_amg_resident_levels(h.handle, byref(lev), byref(root)))
-    assert (lev.value, root.value) == (3, 4)
+    assert (lev.value, root.value) in ((3, 4), (4, 5))      # (4, 5): level 4 resident as well (six levels and more)
     with env(IPD_NO_RESIDENT_DEEP=1):
         hc = _deep_hierarchy(ipd, Ae, N, tk, cycle)
     assert solve_mode(hc)[0] == 0 and hc.level_sizes() == h.level_sizes()

@@ -8,7 +8,7 @@ import bench
 from tests.test_gpu_bench_workload import env, options, solve_mode, resident_kernel_name
 N = 2048
 ks = [int(a) for a in sys.argv[1].split(",")]
-variants = [("default", {})] + [("presleep %d" % v, {"IPD_RES_PRESLEEP": str(v)}) for v in (0, 4, 8, 20, 28, 40, 56)] + [("default", {}), ("v-cycle", {"CYCLE": "v"}), ("skip1 (poly streams)", {"IPD_DEBUG_SKIP": "1"}), ("skip2 (pcg)", {"IPD_DEBUG_SKIP": "2"}),
+variants = [("default", {}), ("G 230", {"IPD_RESIDENT_G": "230"}), ("G 255", {"IPD_RESIDENT_G": "255"}), ("no poly4", {"IPD_NO_RES_POLY4": "1"}), ("v-cycle", {"CYCLE": "v"}), ("skip1 (poly streams)", {"IPD_DEBUG_SKIP": "1"}), ("skip2 (pcg)", {"IPD_DEBUG_SKIP": "2"}),
             ("skip15 (all tail work)", {"IPD_DEBUG_SKIP": "15"}), ("launches", {"IPD_NO_RESIDENT_DEEP": "1"})]
 for k in ks:
     Ae, f, guess, nf, s, bk1, tk = bench.capture_newton_system(ipd, N, k)
