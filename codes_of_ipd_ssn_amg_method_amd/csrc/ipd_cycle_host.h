@@ -1446,6 +1446,20 @@ void amg_prepare_levels(ipd_amg* h) {
             // first level from which every level is small ...
             int k_small = h->J + 1;
             for (int k = h->J; k >= 2 && small_level(k); --k) k_small = k;
+            // Level 1 of 2049..4096 rows, six levels or more: the mask-form resident kernel's deep mode keeps
+            // levels 3 AND 4 in polynomial form in its workgroups and roots its tail workgroup at level 5
+            // (ipd_resident_big.h, POLY4) -- ONE image, rooted at level 5, serves it and the launches (which
+            // then run level 4 as launches: the fall-back).  (An image rooted at level 4 for the launches
+            // beside one rooted at level 5 for the resident kernel packed levels 5..J twice: 0.2 ms per hierarchy.)
+            const int nf1 = h->L[1].nf, nc1 = h->L[1].A.nr - nf1;
+            const bool root5 = h->J >= 6 && h->L[1].A.nr > RES_NMAX && nf1 > 0 && nf1 <= RB_HALF && nc1 <= RB_HALF &&
+                               h->L[2].A.nr == nc1 && h->L[3].A.nr <= RB_N3MAX && h->L[4].A.nr <= RB_N4MAX &&
+                               h->L[5].A.nr <= RB_N5MAX && h->opts.smoth >= 1 && !h->opts.twogrid &&
+                               !(std::getenv("IPD_NO_RES_POLY4") && std::getenv("IPD_NO_RES_POLY4")[0] == '1') &&
+                               !(std::getenv("IPD_NO_RESIDENT_DEEP") && std::getenv("IPD_NO_RESIDENT_DEEP")[0] == '1') &&
+                               !(std::getenv("IPD_NO_RESIDENT_BIG") && std::getenv("IPD_NO_RESIDENT_BIG")[0] == '1') &&
+                               !(std::getenv("IPD_NO_RESIDENT") && std::getenv("IPD_NO_RESIDENT")[0] == '1');
+            if (root5) k_small = std::max(k_small, 5);
             if (k_small < h->J) {
                 // ... and everything below it fits in LDS (the stage area holds N_root doubles)
                 for (int kroot = k_small; kroot < h->J; ++kroot) {
@@ -1547,23 +1561,10 @@ void amg_prepare_levels(ipd_amg* h) {
             st->d_sub3 = build_image(sd.get(), 3, stage, &st->sub3_lds);
         }
     }
-    // (b4) Level 1 beyond k_resident's 2048 rows, six levels or more, the sub-cycle rooted at level 4: the
-    // mask-form resident kernel (deep mode, ipd_resident_big.h) keeps level 4 in polynomial form in its
-    // workgroups as well and roots its tail workgroup at level 5 -- an image of levels 5..J for it alone.
-    if (st->k_sub == 4 && st->d_sub && h->J >= 6 && h->J <= SOLVE_ML && lean_vectors && h->L[1].A.nr > RES_NMAX &&
-        h->L[1].nf > 0 && h->L[4].A.nr <= RB_N4MAX && h->L[5].A.nr <= RB_N5MAX && h->opts.smoth >= 1 &&
-        !(std::getenv("IPD_NO_RES_POLY4") && std::getenv("IPD_NO_RES_POLY4")[0] == '1') &&
-        !(std::getenv("IPD_NO_RESIDENT") && std::getenv("IPD_NO_RESIDENT")[0] == '1')) {
-        const size_t stage = 16;
-        std::unique_ptr<SolveDesc> sd(new SolveDesc());
-        fill_desc(sd.get());
-        sd->k_lds = 5;
-        sd->k_tiny = tiny_from(5);
-        sd->k_blk = blk_from(5);
-        sd->stage_bytes = (int)stage;
-        sd->root_r = h->L[5].r;
-        sd->root_e = h->L[5].e;
-        st->d_sub5 = build_image(sd.get(), 5, stage, &st->sub5_lds);
+    // (b4) the image rooted at level 5 (see root5 above) is the one the deep mode's tail workgroup takes
+    if (st->k_sub == 5 && st->d_sub && !st->sub_semi_root && h->J >= 6 && h->L[1].A.nr > RES_NMAX) {
+        st->d_sub5 = st->d_sub;
+        st->sub5_lds = st->sub_lds;
     }
     plan_resident(h, st.get());
     if (const char* dbg = std::getenv("IPD_DEBUG_LEVELS"); dbg && dbg[0] == '1') {
@@ -1798,7 +1799,7 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
         const char* nbg = std::getenv("IPD_NO_RESIDENT_BIG");
         const char* ndp = std::getenv("IPD_NO_RESIDENT_DEEP");
         const bool cyc = h->opts.cycle == 'w' || h->opts.cycle == 'v';
-        if (st->k_sub == 4 && st->d_sub) {
+        if ((st->k_sub == 4 && st->d_sub) || (st->k_sub == 5 && st->d_sub5)) {   // (rooted at 5: POLY4 only, below)
             deep_img = st->d_sub;
             deep_img_lds = st->sub_lds;
         } else if (st->k_sub == 3 && st->d_sub4) {
@@ -1986,7 +1987,11 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
         LevelDev d2 = st->run[2].dev;
         if (d2.S <= 0 && st->run[2].maxoff > 0) d2.S = -((st->run[2].maxoff + 3) / 4 * 4);   // private copy wanted
         const int S2 = std::abs(d2.S);
-        if (G + 1 <= st->num_cu && G <= std::min(n, m) && S2 > 0 && S2 <= 64 * 8) {
+        // level 4 resident as well (POLY4), the tail rooted at level 5: the only form an image rooted at level 5 serves
+        const int N5 = h->J >= 6 ? h->L[5].A.nr : 0;
+        const bool poly4 = st->d_sub5 && st->k_sub == 5 && N4 <= 2 * G && N5 >= 1 && N5 <= G && N5 <= RB_N5MAX &&
+                           N4 + G <= BT && std::max(RB_LDS_BYTES, st->sub5_lds) <= (size_t)156 * 1024;
+        if (G + 1 <= st->num_cu && G <= std::min(n, m) && S2 > 0 && S2 <= 64 * 8 && (poly4 || st->k_sub != 5)) {
             if (d2.S < 0) {
                 d2.S = S2;
                 const Csr& A2 = h->L[2].A;
@@ -2010,11 +2015,6 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
                 const BPolyDev pb = pack_bpoly(ctx, h, st, 3, h->opts.isnsp, 0, true, RB_P3_SEG, RB_P3_LD);
                 st->level_forms.resize((size_t)h->J + 1, 0);
                 st->level_forms[3] |= 64;
-                // level 4 resident as well (POLY4), the tail rooted at level 5
-                const int N5 = h->J >= 6 ? h->L[5].A.nr : 0;
-                const bool poly4 = st->d_sub5 && deep_img == st->d_sub && N4 <= 2 * G && N5 >= 1 && N5 <= G &&
-                                   N5 <= RB_N5MAX && N4 + G <= BT &&
-                                   std::max(RB_LDS_BYTES, st->sub5_lds) <= (size_t)156 * 1024;
                 BPolyDev pb4;
                 if (poly4) {
                     pb4 = pack_bpoly(ctx, h, st, 4, h->opts.isnsp, 0, true, RB_P4_SEG, RB_P4_LD);
