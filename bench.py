@@ -244,6 +244,9 @@ def main():
                          "(default: from 4 M level-1 entries on, as the solvers do: below that the "
                          "padded CSR sweep is the faster launch, 5.2 us against 5.7 us)")
     ap.add_argument("--no-maskop", action="store_true", help="CSR sweeps on level 1 always")
+    ap.add_argument("--no-poly2", action="store_true",
+                    help="level 2 of the resident kernel as sweeps (33 hand-offs per V cycle) instead of the "
+                         "composed polynomial form (24)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -309,6 +312,12 @@ def main():
     if args.mask != "newton" and not args.no_maskop:
         # level-resident kernel: level 1 <-> 2 transfers from the bit mask (what Hybrid_AMG does itself)
         xmask = h.attach_mask_transfers(np.ones(m), np.ones(n), TK)
+    # level 2 composed over a visit (ipd_amg_attach_level2_poly): the fixed-hierarchy throughput the metric is --
+    # many cycles on ONE hierarchy -- is what its 0.5 ms pack is for; it applies to three-level hierarchies with a
+    # one-row tail and V cycles (the metric's workload), and is reported in config.level2_form
+    poly2 = False
+    if args.mask != "newton" and args.cycle == "v" and not args.no_poly2 and world == 1:
+        poly2 = h.attach_level2_poly()
     db = _lib.DeviceBuffer.from_array(f)
     dx = _lib.DeviceBuffer.from_array(guess)
 
@@ -484,6 +493,8 @@ def main():
                    "M": M, "E": int(s.sum()), "levels": h.level_sizes(),
                    "level_nnz": [h.level_dims(k)[1] for k in range(1, h.J + 1)],
                    "level1_operator": "bit mask + scale vectors" if maskop else "CSR",
+                   "level2_form": ("polynomial, composed over a visit (ipd_amg_attach_level2_poly)" if poly2
+                                   else "Jacobi sweeps"),
                    "resident_transfers": (("bit mask + scale vectors" if xmask_lib else "CSR rows of P', P")
                                           if resident else None),
                    "parallelism": ("row-block sharded x%d, RCCL all-gather" % world) if sharded

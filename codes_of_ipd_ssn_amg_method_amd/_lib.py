@@ -124,7 +124,7 @@ EXPORTS = [
     "ipd_apd_opts_init", "ipd_apd_create", "ipd_apd_destroy", "ipd_apd_dims", "ipd_apd_warmup",
     "ipd_apd_set_state", "ipd_apd_get_state", "ipd_apd_run", "ipd_apd_history",
     "ipd_apd_records", "ipd_apd_reuse_stats", "ipd_apd_begin", "ipd_apd_eval", "ipd_apd_bench_eval", "ipd_prof_read", "ipd_amg_bench_subcycle",
-    "ipd_amg_attach_mask_operator", "ipd_amg_attach_mask_transfers", "ipd_twogrid_bigph", "ipd_twogrid", "ipd_hybrid_twogrid", "ipd_amg4pot_twogrid",
+    "ipd_amg_attach_mask_operator", "ipd_amg_attach_mask_transfers", "ipd_amg_attach_level2_poly", "ipd_twogrid_bigph", "ipd_twogrid", "ipd_hybrid_twogrid", "ipd_amg4pot_twogrid",
     "ipd_aug_pcg", "ipd_pcg4pot", "ipd_spd_solve", "ipd_amg_resident_levels", "ipd_amg_resident_kernel", "ipd_amg_level_forms", "ipd_amg_poly_operator",
 ]
 

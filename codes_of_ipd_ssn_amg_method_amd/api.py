@@ -260,6 +260,14 @@ class AMGHierarchy:
         self.ctx.sync()
         return bool(got.value)
 
+    def attach_level2_poly(self) -> bool:
+        """``ipd_amg_attach_level2_poly``: level 2 of the level-resident kernel composed over a whole visit
+        (three levels, one-row tail, V cycle: ONE hand-off per visit instead of ten).  True when in use."""
+        got = c_int32(0)
+        check(lib.ipd_amg_attach_level2_poly(self.handle, byref(got)))
+        self.ctx.sync()
+        return bool(got.value)
+
     def level_dims(self, k: int):
         rows, nnz = c_int64(), c_int64()
         check(lib.ipd_amg_level_dims(self.handle, c_int(k), byref(rows), byref(nnz)))

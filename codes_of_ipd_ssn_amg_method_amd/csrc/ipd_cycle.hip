@@ -2909,6 +2909,33 @@ __global__ __launch_bounds__(256) void k_bpoly_final(const BPolyEntry e, int nZ,
     }
 }
 
+// Level 2 of the resident kernel, composed over a whole visit (ResDesc::p2rows; pack_bpoly in its row layout
+// has run): B = M1 M2a + M2a into the Me segment of the rows (tiles below nT), wB = M1 w + w into W (one wave
+// per row behind).  M1 = Y's second block, M2a = Y's first block with columns scaled by D^-1, w = Y's column 2 Np.
+__global__ __launch_bounds__(256) void k_bpoly_compose(const BPolyEntry e, int nT) {
+    const int N = e.N, Np = e.Np, l = threadIdx.x & 63;
+    const double* Y = e.Y;
+    if ((int)blockIdx.x >= nT) {
+        const int i = ((int)blockIdx.x - nT) * 4 + (threadIdx.x >> 6);
+        if (i >= N) return;
+        double acc = 0.0;
+        for (int j = l; j < N; j += 64) acc += Y[i + (size_t)(Np + j) * Np] * Y[j + (size_t)(2 * Np) * Np];
+        acc = wave_sum(acc);
+        if (l == 0) e.W[i] = acc + Y[i + (size_t)(2 * Np) * Np];
+        return;
+    }
+    const int ni = Np / 16, tile = blockIdx.x;
+    const int I0 = 16 * (tile % ni), J0 = 16 * (tile / ni);
+    const bp_d4 c = bp_tile(Y + (size_t)Np * Np, 1, Np, Y, 1, Np, Np, I0, J0);
+    if (threadIdx.x >= 64) return;
+    const int j = J0 + (l & 15);
+    for (int g = 0; g < 4; ++g) {
+        const int i = I0 + (l >> 4) + 4 * g;
+        if (i < N && j < N)
+            e.rows[(size_t)i * e.rows_ld + e.rows_seg + j] = (c[g] + Y[i + (size_t)j * Np]) * e.dv[j];
+    }
+}
+
 static constexpr int RELOC_MAX = 640;
 __host__ __device__ constexpr size_t sol_r16(size_t b) { return (b + 15) / 16 * 16; }
 static constexpr size_t SOL_HEAD = sol_r16(sizeof(SolveDesc)) + sol_r16(4 * RELOC_MAX);

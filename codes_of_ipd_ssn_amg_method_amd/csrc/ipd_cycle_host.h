@@ -81,6 +81,7 @@ struct CycleState {
     bool res_off = false;    // IPD_NO_RESIDENT=1 when the hierarchy was set up
     ResBigDesc resb_desc;
     int resb_ke2 = 16;
+    bool res_poly2 = false;  // k_resident<16,16,0,true>: level 2 composed over a visit (ipd_amg_attach_level2_poly)
     bool resb_deep = false;  // realistic hierarchy: level 3 in polynomial form, remote tail at level 4 (RPW = 2)
     bool resb_poly4 = false; // ... level 4 in polynomial form as well, remote tail at level 5
     hipGraphExec_t gexec[2] = {nullptr, nullptr};  // captured Class_AMG loop bodies (x->x2, x2->x)
@@ -255,6 +256,7 @@ struct BPolyDev {
     double* M = nullptr;
     double* W = nullptr;
     int LD = 0;
+    BPolyEntry e{};   // the pack's operands (scratch: valid until the call scope ends)
 };
 static BPolyDev pack_bpoly(ipd_ctx* ctx, ipd_amg* h, CycleState* st, int k, int isnsp, int LD, bool rows,
                            int rows_seg = 512, int rows_ld = RES_P3_LD) {
@@ -326,6 +328,7 @@ static BPolyDev pack_bpoly(ipd_ctx* ctx, ipd_amg* h, CycleState* st, int k, int 
     const int nK = (int)((N * N + N + 255) / 256);
     hipLaunchKernelGGL(k_bpoly_final, dim3((unsigned)(nZ + nC + nK)), dim3(256), 0, ctx->stream, e, nZ, nC);
     IPD_KERNEL_CHECK();
+    b.e = e;
     return b;
 }
 
@@ -654,6 +657,10 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
         hipLaunchKernelGGL((k_resident_big<KE2, RPW, DEEP>), dim3(grid), dim3(BT), st->res_lds, ctx->stream, B, \
                            b_dev, x, st->res_out, fixed_cycles);                                    \
     } while (0)
+#ifdef IPD_DEV_ONLY_RES16
+        (void)B;
+        fits = false;
+#else
         if (st->resb_deep) {
             if (st->resb_ke2 == 4)
                 IPD_RESB_LAUNCH(4, 2, true);
@@ -663,28 +670,37 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
             IPD_RESB_LAUNCH(16, 1, false);
         else
             IPD_RESB_LAUNCH(32, 1, false);
+#endif
 #undef IPD_RESB_LAUNCH
     } else
-#define IPD_RES_LAUNCH(KE, KE3)                                                                     \
+#define IPD_RES_LAUNCH4(KE, KE3, P2)                                                                   \
     do {                                                                                            \
-        IPD_OPTIN_LDS(ctx, (k_resident<KE, KE, KE3>), 156 * 1024);                                  \
+        IPD_OPTIN_LDS(ctx, (k_resident<KE, KE, KE3, P2>), 156 * 1024);                                  \
         if (st->res_capacity < 0) {                                                                 \
             int nb_ = 0;                                                                            \
-            IPD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, (k_resident<KE, KE, KE3>), BT, st->res_lds)); \
+            IPD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, (k_resident<KE, KE, KE3, P2>), BT, st->res_lds)); \
             st->res_capacity = nb_ * st->num_cu;                                                    \
         }                                                                                           \
         if (grid > st->res_capacity) {                                                              \
             fits = false;                                                                           \
             break;                                                                                  \
         }                                                                                           \
-        hipLaunchKernelGGL((k_resident<KE, KE, KE3>), dim3(grid), dim3(BT), st->res_lds, ctx->stream, \
+        hipLaunchKernelGGL((k_resident<KE, KE, KE3, P2>), dim3(grid), dim3(BT), st->res_lds, ctx->stream, \
                            D, b_dev, x, st->res_out, fixed_cycles);                                 \
     } while (0)
-#ifdef IPD_DEV_ONLY_BIG   // (development: compile the mask-form kernels alone, see tools/kernel_regs.py)
+#define IPD_RES_LAUNCH(KE, KE3) IPD_RES_LAUNCH4(KE, KE3, false)
+#if defined(IPD_DEV_ONLY_BIG)   // (development: compile the mask-form kernels alone, see tools/kernel_regs.py)
     (void)D;
     fits = false;
+#elif defined(IPD_DEV_ONLY_RES16)   // (... or the metric's instantiations alone)
+    if (st->res_poly2)
+        IPD_RES_LAUNCH4(16, 0, true);
+    else
+        IPD_RES_LAUNCH(16, 0);
 #else
-    if (st->res_ke3 == 0) {
+    if (st->res_poly2) {
+        IPD_RES_LAUNCH4(16, 0, true);
+    } else if (st->res_ke3 == 0) {
         if (st->res_ke == 4)
             IPD_RES_LAUNCH(4, 0);
         else if (st->res_ke == 8)
@@ -709,6 +725,7 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
     }
 #endif
 #undef IPD_RES_LAUNCH
+#undef IPD_RES_LAUNCH4
     if (!fits) {
         st->res_ok = false;
         return false;
@@ -2111,6 +2128,48 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
     return true;
 }
 
+// Level 2 of the level-resident kernel in polynomial form, composed over a whole visit (ResDesc::p2rows):
+// three levels with a one-row tail, V cycle, 16-entry slices -- the metric's workload.  Packing costs five
+// dense products of N2^3 (0.5 ms at N2 = 1024) against 18 us saved per cycle: it pays where many cycles run
+// on one hierarchy (bench.py's fixed-hierarchy throughput), never in a solve of such a system, which takes one
+// or two cycles -- so the solvers do not attach it themselves.
+static bool amg_attach_poly2(ipd_amg* h) {
+    ipd_ctx* ctx = h->ctx;
+    CycleState* st = state_of(h);
+    if (!st || !st->res_ok || st->resb || st->res_poly2 || st->res_remote || st->res_ke3 != 0 || st->res_ke != 16) return false;
+    const ResDesc& R = st->res_desc;
+    const int N2 = R.L2.N, nf = R.L1.nf;
+    if (h->J != 3 || R.Nt != 1 || R.three || h->opts.cycle != 'v' || h->opts.smoth < 1 || N2 > RES_NMAX / 2 ||
+        nf > RES_NMAX / 2 || N2 > 64 * 16)
+        return false;
+    const int seg = RES_NMAX / 2, ld = 2 * seg + 128;
+    const BPolyDev pb = pack_bpoly(ctx, h, st, 2, h->opts.isnsp, 0, true, seg, ld);
+    const int Np = pb.e.Np, nT = (Np / 16) * (Np / 16);
+    // (IPD_OPTIN_LDS is not needed: the tiles use static LDS only)
+    hipLaunchKernelGGL(k_bpoly_compose, dim3((unsigned)(nT + (N2 + 3) / 4)), dim3(256), 0, ctx->stream, pb.e, nT);
+    IPD_KERNEL_CHECK();
+    st->res_desc.p2rows = pb.M;
+    st->res_desc.p2w = pb.W;
+    st->res_desc.p2seg = seg;
+    st->res_desc.p2ld = ld;
+    st->res_poly2 = true;
+    st->res_capacity = -1;
+    st->level_forms.resize((size_t)h->J + 1, 0);
+    st->level_forms[2] |= 128;
+    ctx->sync();   // the pack's scratch operands die with the call scope
+    return true;
+}
+
+extern "C" int ipd_amg_attach_level2_poly(ipd_amg* h, int32_t* attached) {
+    return ipd_guard([&] {
+        IPD_REQUIRE(h, IPD_E_ARG, "NULL handle");
+        h->ctx->set_device();
+        CallScope scope(h->ctx);
+        const bool ok = amg_attach_poly2(h);
+        if (attached) *attached = ok ? 1 : 0;
+    });
+}
+
 extern "C" int ipd_amg_attach_mask_operator(ipd_amg* h, const double* p_dev, const double* q_dev,
                                             int64_t m, int64_t n, double tk, int32_t* attached) {
     return ipd_guard([&] {
@@ -2578,7 +2637,8 @@ extern "C" int ipd_amg_resident_kernel(const ipd_amg* h, char* name, int32_t cap
                 std::snprintf(buf, sizeof buf, "k_resident_big<%d,%d,%s>", st->resb_ke2, st->resb_deep ? 2 : 1,
                               st->resb_deep ? "true" : "false");
             else
-                std::snprintf(buf, sizeof buf, "k_resident<%d,%d,%d>", st->res_ke, st->res_ke, st->res_ke3);
+                std::snprintf(buf, sizeof buf, st->res_poly2 ? "k_resident<%d,%d,%d,true>" : "k_resident<%d,%d,%d>",
+                              st->res_ke, st->res_ke, st->res_ke3);
         }
         std::snprintf(name, (size_t)cap, "%s", buf);
         if (handoffs) *handoffs = st ? st->res_last_handoffs : 0;

@@ -78,6 +78,17 @@ struct ResDesc {
     // prolongation).
     const double* p3rows;
     const double* p3w;
+    // Level 2 in polynomial form, COMPOSED over a whole visit (template argument POLY2; three levels with a
+    // one-row tail, V cycle -- the metric's workload; ipd_amg_attach_level2_poly).  The nu pre-sweeps, the
+    // residual, the restriction to the one-row tail, its prolongation and the nu post-sweeps of a visit that
+    // starts from e = 0 (AMG/MG_Vcycle.m:14-41) are the affine map
+    //     e_2 = B r_2 + wB (1'r_2) + mp e_3,   e_3 = PCG(h33, s'r_2 + ws (1'r_2)),
+    // B = M1 M2a + M2a, wB = M1 w + w, mp = M1 p3, s = P3' - (P3'A) M2a (pack_bpoly's operators, one more dense
+    // product): row i of p2rows holds B(i,:) at [p2seg ..), mp_i at [2 p2seg], row N2 holds s; p2w = [wB; ws].
+    // A visit of level 2 is then ONE hand-off instead of ten.
+    const double* p2rows;
+    const double* p2w;
+    int p2seg, p2ld;
     // Remote tail (hierarchies with more than three levels): workgroup gridDim.x - 1 holds the LDS
     // image of the single-workgroup sub-cycle rooted at level 3 (k_subcycle's code and data) and
     // serves the visits of everything below level 2: the other workgroups hand it r_3 = P3' rr_2
@@ -386,9 +397,10 @@ __device__ __forceinline__ void res_tail_workgroup(const ResDesc& D, char* dyn_r
 // rules (bench hook).  dbg (optional, 16 words): [0] shader clocks spent waiting in sweeps by
 // workgroup 0, [1] clocks of the whole loop, [2] number of hand-offs, [3] 100 MHz ticks of the loop,
 // [4] clocks in the barrier before the publish, [5] in the store phase, [6] in the closing barrier.
-template <int KE1, int KE2, int KE3 = 0>
+template <int KE1, int KE2, int KE3 = 0, bool POLY2 = false>
 __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const double* __restrict__ bvec,
                                                     double* xg, double* out, int fixed_cycles) {
+    static_assert(!POLY2 || KE3 == 0, "POLY2: three-level hierarchies");
     constexpr bool THREE = KE3 > 0;
     constexpr bool POLY3 = KE3 == 1;   // level 3 in polynomial form (ResDesc::p3rows)
     constexpr int K3 = (THREE && !POLY3) ? KE3 : 2;
@@ -447,7 +459,18 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     double aF[KE1], aC[KE1], a2[KE2];
     res_load_slice<KE1>(D.L1, rF, vF, lane, cF, aF);
     res_load_slice<KE1>(D.L1, rC, vC, lane, cC, aC);
-    res_load_slice<KE2>(D.L2, r2, v2, lane, c2, a2);
+    if (POLY2) {
+#pragma unroll
+        for (int q = 0; q < KE2; ++q) {
+            const int e = lane + 64 * q;
+            const double bv = D.p2rows[(size_t)r2 * D.p2ld + D.p2seg + (e < N2 ? e : 0)];
+            a2[q] = (v2 && e < N2) ? bv : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < KE2 / 2; ++q) c2[q] = 0u;
+    } else {
+        res_load_slice<KE2>(D.L2, r2, v2, lane, c2, a2);
+    }
     unsigned c3[K3 / 2];
     double a3[K3];
     if (THREE && !POLY3) res_load_slice<K3>(D.L3, r3, v3, lane, c3, a3);
@@ -482,8 +505,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         sm[oOWN + 3 * RES_WAVES + w] = D.L1.diag[rC];
         sm[oOWN + 4 * RES_WAVES + w] = D.L1.dinv[rC];
         sm[oOWN + 5 * RES_WAVES + w] = bvec[rC];
-        sm[oOWN + 6 * RES_WAVES + w] = D.L2.diag[r2];
-        sm[oOWN + 7 * RES_WAVES + w] = D.L2.dinv[r2];
+        sm[oOWN + 6 * RES_WAVES + w] = POLY2 ? D.p2w[r2] : D.L2.diag[r2];                                    // (POLY2: wB)
+        sm[oOWN + 7 * RES_WAVES + w] = POLY2 ? D.p2rows[(size_t)r2 * D.p2ld + 2 * D.p2seg] : D.L2.dinv[r2];   // (POLY2: mp)
         sm[oOWN + 8 * RES_WAVES + w] = (THREE && !POLY3) ? D.L3.diag[r3] : 0.0;
         sm[oOWN + 9 * RES_WAVES + w] = (THREE && !POLY3) ? D.L3.dinv[r3] : 0.0;
         rowp[12 * w + 0] = D.Pt2.rp[r2];
@@ -574,13 +597,19 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     if (tail1) {
         for (int j = tid; j < N2; j += BT) {
             double v = 0.0;
-            for (int t = D.P3.rp[j]; t < D.P3.rp[j + 1]; ++t)
-                if (D.P3.ci[t] == 0) v = D.P3.va[t];
+            if (POLY2) {
+                v = D.p2rows[(size_t)N2 * D.p2ld + j];   // the stacked restriction row s
+            } else {
+                for (int t = D.P3.rp[j]; t < D.P3.rp[j + 1]; ++t)
+                    if (D.P3.ci[t] == 0) v = D.P3.va[t];
+            }
             sm[oP3C + j] = v;
         }
         for (int t = D.A3.rp[0]; t < D.A3.rp[1]; ++t)
             if (D.A3.ci[t] == 0) h33 = D.A3.va[t];
     }
+    if (POLY2)   // the dense rows of B are walked in whole 64-entry steps: zeros behind r_2
+        for (int j = N2 + tid; j < RES_NMAX / 2; j += BT) sm[oR2 + j] = 0.0;
     if (tid == 0) *fail = 0;
     __syncthreads();
 
@@ -594,6 +623,16 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         dbg_acc[2] = __builtin_amdgcn_s_memrealtime();
     }
 
+    // Addresses are re-derived from FRESH copies of the thread's indices at every use site (RES_FRESH shadows
+    // tid / w / lane by copies laundered through an empty volatile asm): left alone, LLVM reassociates every
+    // `index + constant` of the own-row slots, the hand-off stores and the transfers into a loop-invariant part
+    // and hoists it out of the cycle loop -- dozens of address registers (the LDS map ends beyond the 64 KB an
+    // immediate offset reaches) that pushed row-slice data of <16, 16, 0> into scratch: 29 reloads per cycle
+    // in round 3, none now (tools/kernel_regs.py).
+#define RES_FRESH                                                                                  \
+    const int tid0_ = tid, w0_ = w, lane0_ = lane;                                                 \
+    int tid = tid0_, w = w0_, lane = lane0_;                                                       \
+    asm volatile("" : "+v"(tid), "+v"(w), "+v"(lane))
     // ---- hand-off wrapper: sweep + barrier + store + (optional) block sums + barrier ------------
     // STORE(j, v) is called for every granule of the thread; EXTRA() runs once per thread in the
     // store phase (fix-ups on rows the thread does not sweep); both may add to p0 / p1, whose block
@@ -606,6 +645,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 #define RES_HANDOFF(NJ, n, gA, cA, gB, cB, STORE, EXTRA, want_sums, t0, t1)                        \
     do {                                                                                           \
         double hv_[NJ];                                                                            \
+        RES_FRESH;                                                                                 \
         ++seq;                                                                                     \
         if (dbg) dbg_acc[3] -= __builtin_amdgcn_s_memtime();                                       \
         __syncthreads();                                                                           \
@@ -661,6 +701,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 
     // sum of the LDS vector at `off` over the set bits of `bits` (entry lane + 64 q <-> bit q), n entries
     auto masked_sum = [&](unsigned bits, int off, int n) __attribute__((always_inline)) {
+        RES_FRESH;
         double s0 = 0.0, s1 = 0.0;
         // (entry lane + 64 q at a constant distance from entry `lane`: one address register and immediate offsets;
         // entries beyond n lie inside the vector's LDS slot -- n <= RES_NMAX / 2 -- and their mask bits are zero)
@@ -680,6 +721,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         return wave_sum(s0 + s1);
     };
     double c1 = 0.0, c2s = 0.0;     // kernel-space scalars of the next sweep on level 1 / 2
+    double sumr2p = 0.0;            // POLY2: 1'r_2 of the visit
+    const double p2ws = POLY2 ? D.p2w[N2] : 0.0;
     double res = 0.0, res0 = 0.0, prev = 0.0;
     double dum0 = 0.0, dum1 = 0.0;
     (void)dum0;
@@ -687,6 +730,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 
     // r = b - A x (rows of this wave), ||r||, c1 for a zero start; E1 := 0        Class_AMG.m:89,96,103
     auto top = [&]() __attribute__((always_inline)) {
+        RES_FRESH;
         const double sF = wave_sum(res_rowdot<KE1, 8 * oX>(cF, aF, smb));
         const double sC = wave_sum(res_rowdot<KE1, 8 * oX>(cC, aC, smb));
         if (lane == 0) {
@@ -711,6 +755,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // other half still holds the old iterate); second half: + the shift by c of both halves and
     // the scalar of the next sweep.                         MG_Vcycle.m:15-21,34-38; Class_AMG.m:56-59
     auto half1 = [&](bool frows, bool first, bool ezero) __attribute__((always_inline)) {
+        RES_FRESH;
         double s = 0.0, eo = 0.0;
         const int row = frows ? rowF : rowC;
         const bool valid = frows ? vF : vC;
@@ -748,12 +793,14 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         }
     };
     auto sweep1 = [&](bool post, bool ezero) __attribute__((always_inline)) {
+        RES_FRESH;
         if (!(lfirst && ezero && !post)) half1(!post, true, ezero);   // else: done by top()    // pre: F rows first (Rk{1}); post: C rows first (Rk{1}')
         half1(post, false, ezero);
     };
 
     // weighted-Jacobi sweep on level 2                                   MG_Vcycle.m:15-21; Class_AMG.m:84
     auto sweep2 = [&](bool ezero) __attribute__((always_inline)) {
+        RES_FRESH;
         double s = 0.0, eo = 0.0;
         if (!ezero) {
             s = wave_sum(res_rowdot<KE2, 8 * oE2>(c2, a2, smb));
@@ -787,6 +834,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // of the next sweep.
     auto remote_tail = [&](const ResCsr& Pin, int oRRs, int oEd, int oRd, int oAXd, double xxd, int Nout,
                            double& cnext) __attribute__((always_inline)) {
+        RES_FRESH;
         ++tseq;
         const int rin = b + G * w;
         if (rin < Nt) {
@@ -826,6 +874,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // guess), prolongation into the level above (oEd, with oRd / oAXd for the next scalar).
     auto local_tail = [&](const ResCsr& PtT, const ResCsr& AT, const ResCsr& PT, int oRRs, int oEd, int oRd,
                           int oAXd, double xxd, int Nabove, double& cnext) __attribute__((always_inline)) {
+        RES_FRESH;
         if (Nt == 1) {
             // one row: its entries are dealt to all the waves, the eight partial sums are added in
             // wave order (a single wave walking 1024 entries took four dependent trips)
@@ -898,6 +947,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         if (nsp) cnext = res_red8(red) / xxd;
         };
     auto tail = [&]() __attribute__((always_inline)) {
+        RES_FRESH;
         if (D.remote) {
             remote_tail(D.Pt3, oRR2, oE2, oR2, oAX2, xx2, N2, c2s);
             return;
@@ -952,6 +1002,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         RES_HANDOFF(2, N3 + G, lo3, hi3 - lo3, N3 + b, 1, { if (j < N3) { STORE3; } }, {}, want_sums, t0, dum1); \
     } while (0)
     auto sweep3 = [&](bool ezero) __attribute__((always_inline)) {
+        RES_FRESH;
         if (THREE) {
             double s = 0.0, eo = 0.0;
             if (!ezero) {
@@ -977,6 +1028,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // polynomial form: the sums of this workgroup's rows against [r_3; e_3] (+ their factor of 1'r_3)
     // -> sm[oR3 + 40 + q]; the caller's next barrier publishes them
     auto poly3_rows = [&](int nrows, bool post) __attribute__((always_inline)) {
+        RES_FRESH;
         const double xr = tid < N3 ? sm[oR3L + tid] : 0.0, xe = tid < N3 ? sm[oE3L + tid] : 0.0;
         const double xc = (post && tid < Nt) ? sm[oRR3L + tid] : 0.0;
 #pragma unroll
@@ -998,6 +1050,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         __syncthreads();
     };
     auto visit3 = [&](bool keep) __attribute__((always_inline)) {
+        RES_FRESH;
         if (POLY3) {
             ++tseq;
             // e' = M2a r + M1 e and the restricted residual of e' in one pass                 MG_Vcycle.m:20-29
@@ -1040,7 +1093,47 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 
     // one visit of level 2 and everything below it
     auto visit2 = [&](bool keep) __attribute__((always_inline)) {
+        RES_FRESH;
         const int nu = D.nu;
+        if (POLY2) {   // the whole visit as one composed pass (ResDesc::p2rows): ONE hand-off
+            // r_3 = s'r_2 + ws (1'r_2) and the one-row tail's PCG (PCG.m:68-87) by every workgroup
+            double s3 = 0.0;
+            for (int j = tid; j < N2; j += BT) s3 += sm[oP3C + j] * sm[oR2 + j];
+            s3 = wave_sum(s3);
+            if (lane == 0) red[w] = s3;
+            __syncthreads();
+            double r = res_red8(red) + p2ws * sumr2p;
+            double pp = r / h33, d = 0.0;
+            double delta_new = r * pp;
+            const double thresh = 1e-11 * 1e-11 * delta_new;
+            for (long long it = 0; it < D.pcg_maxit && delta_new > thresh; ++it) {
+                const double delta_old = delta_new;
+                const double q = h33 * pp;
+                const double alpha = delta_old / (q * pp);
+                d += alpha * pp;
+                r = r - alpha * q;
+                const double wi = r / h33;
+                delta_new = r * wi;
+                pp = wi + (delta_new / delta_old) * pp;
+            }
+            // e_2 = B r_2 + wB (1'r_2) + mp e_3 on the own row: a dense row against R2 (entry lane + 64 q at a
+            // constant distance: immediate offsets, no column registers)
+            const double* rb = sm + oR2 + lane;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+            for (int q = 0; q < KE2; q += 4) {
+                t0 += a2[q] * rb[64 * q];
+                t1 += a2[q + 1] * rb[64 * (q + 1)];
+                t2 += a2[q + 2] * rb[64 * (q + 2)];
+                t3 += a2[q + 3] * rb[64 * (q + 3)];
+            }
+            const double val = wave_sum((t0 + t1) + (t2 + t3)) + dg2 * sumr2p + dv2 * d;
+            if (lane == 0) sm[oPUB + w] = val;
+            RES_HANDOFF(4, N2, lo2, hi2 - lo2, 0, 0, { sm[oE2 + j] = v; }, {}, 0, dum0, dum1);
+            (void)keep;
+            (void)nu;
+            return;
+        }
         for (int s = (lfirst2 && !keep) ? 1 : 0; s < nu; ++s) sweep2(!keep && s == 0);
         // rr = r - A e                                                           MG_Vcycle.m:27
         {
@@ -1076,6 +1169,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 
     // MG_Vcycle / MG_Wcycle from level 1 down; the correction ends in E1
     auto cycle = [&]() __attribute__((always_inline)) {
+        RES_FRESH;
         const int nu = D.nu;
         for (int s = 0; s < nu; ++s) sweep1(false, s == 0);
         {   // rr = r - A e on both blocks
@@ -1104,7 +1198,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
             RES_HANDOFF(4, N2, lo2, hi2 - lo2, 0, 0, { sm[oR2 + j] = v; sm[oE2 + j] = 0.0; p0 += v; }, {},
                         (nsp ? 1 : 0), sumr, dum1);
             c2s = nsp ? sumr / xx2 : 0.0;
-            if (lfirst2) {   // sweep2(true) of the first visit, same thread-to-entry map and sums
+            sumr2p = sumr;
+            if (lfirst2 && !POLY2) {   // sweep2(true) of the first visit, same thread-to-entry map and sums
                 const double cc = c2s;
                 double p0 = 0.0;
                 for (int j = tid; j < N2; j += BT) {
@@ -1148,6 +1243,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     };
 
     auto add_correction = [&]() __attribute__((always_inline)) {   // x += e                                       Class_AMG.m:98,101
+        RES_FRESH;
         for (int j = tid; j < N1; j += BT) sm[oX + j] = sm[oX + j] + sm[oE1 + j];
         __syncthreads();
     };
@@ -1237,6 +1333,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         D.dbg[8] = dbg_acc[7];
     }
 #undef RES_HANDOFF3
+#undef RES_FRESH
 #undef RES_HANDOFF
 #undef dgF
 #undef dvF

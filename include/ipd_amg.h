@@ -384,6 +384,15 @@ int ipd_amg_attach_mask_operator(ipd_amg* h, const double* p_dev, const double* 
  * hierarchy does not run in that kernel or P does not have the form.  The solvers do this themselves. */
 int ipd_amg_attach_mask_transfers(ipd_amg* h, const double* p_dev, const double* q_dev,
                                   int64_t m, int64_t n, double tk, int32_t* attached);
+/* Level 2 of the level-resident kernel in polynomial form, composed over a whole visit: for a three-level
+ * hierarchy with a one-row tail and V cycles (the metric's workload) the smoth pre-sweeps, the residual, the
+ * restriction, the tail's prolongation and the smoth post-sweeps of a visit of level 2 (AMG/MG_Vcycle.m:14-41
+ * with Class_AMG.m:84's Jacobi smoother) are ONE dense affine map of r_2 (and of the tail's PCG result), packed
+ * here by smoth dense products on the f64 matrix cores; a V cycle is then 24 chip-wide hand-offs instead of 33.
+ * Same linear operator as the sweeps, different association (rounding at the 1e-16 level per pass).  Packing
+ * costs about 0.5 ms at 1024 rows: for many cycles on ONE hierarchy, not for a solve of such a system (one or
+ * two cycles) -- the solvers never attach it.  *attached = 0: the hierarchy does not run in that kernel form. */
+int ipd_amg_attach_level2_poly(ipd_amg* h, int32_t* attached);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------- */
 /* Runs `cycles` iterations of the Class_AMG loop body (residual, one V/W
@@ -425,7 +434,8 @@ int ipd_amg_resident_levels(const ipd_amg* h, int32_t* levels, int32_t* tail_roo
 int ipd_amg_resident_kernel(const ipd_amg* h, char* name, int32_t cap, int64_t* handoffs,
                             int32_t* cycles, int32_t* mask_transfers);
 /* forms[k], k < count (level k = 1..J; forms[0] = 0): how level k runs where it is held in a single
- * workgroup's LDS image (bit mask over the images packed for this hierarchy): 1 thread-per-row sweeps,
+ * workgroup's LDS image (bit mask over the images packed for this hierarchy; 64 / 128: level 3-4 / level 2 of a
+ * resident kernel in polynomial form, held by the resident workgroups): 1 thread-per-row sweeps,
  * 2 the same with dense rows in registers, 4 one-wave sweeps, 8 one-wave polynomial form (the nu sweeps,
  * residual and transfers of a visit as two dense passes), 16 block-wide polynomial form (49..144 rows,
  * operators streamed from L2); 0: in no image (launches or the resident workgroups' registers).      */

@@ -208,6 +208,98 @@ def test_metric_workload_mask_form_transfers(ipd, metric_system, cycle):
     hc.close()
 
 
+def test_metric_workload_level2_composed(ipd, metric_system):
+    """What `python bench.py` times since round 4: level 2 of the resident kernel in polynomial form, composed
+    over a whole visit (ipd_amg_attach_level2_poly; AMG/MG_Vcycle.m:14-41 with Class_AMG.m:84's Jacobi smoother
+    as ONE dense affine map per visit: 24 hand-offs per V cycle instead of 33).  Against the ORACLE directly
+    (K loop bodies through A(x - x_oracle), the history of a whole solve), against the sweep form of the same
+    kernel, the K timed loop bodies against Class_AMG itself bit for bit, and refused where it does not apply."""
+    m, n, s, Ae, f, guess = metric_system
+    opts = options("v", n)
+    h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    hs = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    for hh in (h, hs):
+        assert hh.attach_mask_transfers(np.ones(m), np.ones(n), bench.TK)
+    assert h.attach_level2_poly() and not h.attach_level2_poly()          # (the second call: already attached)
+    assert resident_kernel_name(h) == "k_resident<16,16,0,true>" and resident_kernel_name(hs) == "k_resident<16,16,0>"
+    assert h.level_forms()[1] & 128
+    A = sp.csr_matrix(Ae)
+    nf_ = np.linalg.norm(f)
+    K = 3
+    a = bench_cycles(h, f, guess, K)[0]
+    b = bench_cycles(hs, f, guess, K)[0]
+    xo, reso, ho = oracle_cycles(Ae, f, guess, opts, K)
+    assert np.linalg.norm(A @ (a - xo)) <= 1e-9 * nf_
+    assert np.linalg.norm(A @ (a - b)) <= 1e-9 * nf_
+    assert np.linalg.norm(A @ a - f) <= 1e-9 * reso[0]
+    assert np.array_equal(a, bench_cycles(h, f, guess, K)[0])            # run-to-run deterministic
+    # hand-offs per cycle, as the library counts them (ipd_amg_resident_kernel): 24 against 33
+    from ctypes import c_int64, create_string_buffer
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    per = []
+    for hh in (h, hs):
+        bench_cycles(hh, f, guess, 10)
+        nb, ho_, cy = create_string_buffer(64), c_int64(), c_int32()
+        _lib.check(_lib.lib.ipd_amg_resident_kernel(hh.handle, nb, c_int32(64), byref(ho_), byref(cy), None))
+        assert cy.value == 10
+        per.append((ho_.value - 1) / 10)
+    assert per == [24.0, 33.0], per
+    # a whole solve: history against the oracle's and the sweep form's
+    x, it, rel, relk, rhok = h.solve(f, guess)
+    xs, its, rels, relks, rhoks = hs.solve(f, guess)
+    assert solve_mode(h)[2] == 0
+    same_history(it, relk, its, relks)
+    o = dict(opts)
+    o.update(guess=guess)
+    xo2, ito, relo, relko, _ = O.Class_AMG(Ae, f, o, O.matlab_rng())
+    same_history(it, relk, ito, relko)
+    assert np.linalg.norm(A @ (x - xo2)) <= 1e-9 * nf_
+    # K iterations of Class_AMG itself on a hierarchy with the same form attached: the same kernel, bit for bit
+    h2 = ipd.AMGHierarchy(Ae, options("v", n, maxit=K, retol=0.0), ipd.MatlabRand())
+    assert h2.attach_mask_transfers(np.ones(m), np.ones(n), bench.TK) and h2.attach_level2_poly()
+    x2, it2, rel2, relk2, rho2 = h2.solve(f, guess)
+    assert it2 == K and np.array_equal(x2, a)
+    # not for W cycles (the second leg starts from an iterate), not for realistic hierarchies
+    hw = ipd.AMGHierarchy(Ae, options("w", n), ipd.MatlabRand())
+    assert not hw.attach_level2_poly()
+    for hh in (h, hs, h2, hw):
+        hh.close()
+
+
+@pytest.mark.parametrize("m,n,rho,pq", [(512, 512, 1.0, False), (700, 900, 1.0, True), (1000, 1000, 0.9, True)])
+def test_level2_composed_on_other_dense_systems(ipd, m, n, rho, pq):
+    """The composed level 2 on ragged sizes (N2 below the 1024 the dense rows are walked to), random p and q,
+    and a mask with holes: against the oracle and the sweep form."""
+    s = PR.mask_bernoulli(m, n, rho, seed=5)
+    pd = PR.make_prob(m, n, s, pq_random=pq)
+    H0 = O.ASAt(s, pd["p"], pd["q"])
+    Ae = sp.csr_matrix(O.build_Ae(H0, pd["T"], pd["p"], pd["q"], pd["bk1"], pd["tk"])[0])
+    if sp.csgraph.connected_components(Ae)[0] != 1:
+        pytest.skip("mask not connected")
+    f = np.concatenate([pd["q"], -pd["p"]]) * pd["z"]
+    guess = pd["bk1"] * pd["tk"] * np.random.RandomState(4).random_sample(m + n)
+    opts = options("v", n)
+    h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    hs = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+    if solve_mode(h)[0] != 2 or h.J != 3 or h.level_sizes()[2] != 1 or not resident_kernel_name(h).startswith("k_resident<16,16,0"):
+        pytest.skip("hierarchy %s (%s): the composed form takes three levels, a one-row tail, 16-entry slices" % (
+            h.level_sizes(), resident_kernel_name(h)))
+    assert h.attach_level2_poly()
+    x, it, rel, relk, rhok = h.solve(f, guess)
+    xs, its, rels, relks, rhoks = hs.solve(f, guess)
+    assert solve_mode(h)[2] == 0
+    same_history(it, relk, its, relks)
+    A = sp.csr_matrix(Ae)
+    assert np.linalg.norm(A @ (x - xs)) <= 1e-9 * np.linalg.norm(f)
+    o = dict(opts)
+    o.update(guess=guess)
+    xo, ito, relo, relko, _ = O.Class_AMG(Ae, f, o, O.matlab_rng())
+    same_history(it, relk, ito, relko)
+    assert np.linalg.norm(A @ (x - xo)) <= 1e-9 * np.linalg.norm(f)
+    h.close()
+    hs.close()
+
+
 @pytest.mark.parametrize("m,n,rho", [(700, 900, 1.0), (1000, 1000, 0.9), (1024, 1024, 0.5)])
 def test_mask_form_transfers_ragged(ipd, m, n, rho):
     """Rectangular and ragged masks, p and q not constant: the mask-form transfers against the CSR ones."""
