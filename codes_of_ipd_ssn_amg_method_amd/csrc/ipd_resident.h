@@ -623,16 +623,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         dbg_acc[2] = __builtin_amdgcn_s_memrealtime();
     }
 
-    // Addresses are re-derived from FRESH copies of the thread's indices at every use site (RES_FRESH shadows
-    // tid / w / lane by copies laundered through an empty volatile asm): left alone, LLVM reassociates every
-    // `index + constant` of the own-row slots, the hand-off stores and the transfers into a loop-invariant part
-    // and hoists it out of the cycle loop -- dozens of address registers (the LDS map ends beyond the 64 KB an
-    // immediate offset reaches) that pushed row-slice data of <16, 16, 0> into scratch: 29 reloads per cycle
-    // in round 3, none now (tools/kernel_regs.py).
-#define RES_FRESH                                                                                  \
-    const int tid0_ = tid, w0_ = w, lane0_ = lane;                                                 \
-    int tid = tid0_, w = w0_, lane = lane0_;                                                       \
-    asm volatile("" : "+v"(tid), "+v"(w), "+v"(lane))
     // ---- hand-off wrapper: sweep + barrier + store + (optional) block sums + barrier ------------
     // STORE(j, v) is called for every granule of the thread; EXTRA() runs once per thread in the
     // store phase (fix-ups on rows the thread does not sweep); both may add to p0 / p1, whose block
@@ -645,7 +635,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 #define RES_HANDOFF(NJ, n, gA, cA, gB, cB, STORE, EXTRA, want_sums, t0, t1)                        \
     do {                                                                                           \
         double hv_[NJ];                                                                            \
-        RES_FRESH;                                                                                 \
         ++seq;                                                                                     \
         if (dbg) dbg_acc[3] -= __builtin_amdgcn_s_memtime();                                       \
         __syncthreads();                                                                           \
@@ -701,7 +690,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 
     // sum of the LDS vector at `off` over the set bits of `bits` (entry lane + 64 q <-> bit q), n entries
     auto masked_sum = [&](unsigned bits, int off, int n) __attribute__((always_inline)) {
-        RES_FRESH;
         double s0 = 0.0, s1 = 0.0;
         // (entry lane + 64 q at a constant distance from entry `lane`: one address register and immediate offsets;
         // entries beyond n lie inside the vector's LDS slot -- n <= RES_NMAX / 2 -- and their mask bits are zero)
@@ -730,7 +718,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 
     // r = b - A x (rows of this wave), ||r||, c1 for a zero start; E1 := 0        Class_AMG.m:89,96,103
     auto top = [&]() __attribute__((always_inline)) {
-        RES_FRESH;
         const double sF = wave_sum(res_rowdot<KE1, 8 * oX>(cF, aF, smb));
         const double sC = wave_sum(res_rowdot<KE1, 8 * oX>(cC, aC, smb));
         if (lane == 0) {
@@ -755,7 +742,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // other half still holds the old iterate); second half: + the shift by c of both halves and
     // the scalar of the next sweep.                         MG_Vcycle.m:15-21,34-38; Class_AMG.m:56-59
     auto half1 = [&](bool frows, bool first, bool ezero) __attribute__((always_inline)) {
-        RES_FRESH;
         double s = 0.0, eo = 0.0;
         const int row = frows ? rowF : rowC;
         const bool valid = frows ? vF : vC;
@@ -793,14 +779,12 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         }
     };
     auto sweep1 = [&](bool post, bool ezero) __attribute__((always_inline)) {
-        RES_FRESH;
         if (!(lfirst && ezero && !post)) half1(!post, true, ezero);   // else: done by top()    // pre: F rows first (Rk{1}); post: C rows first (Rk{1}')
         half1(post, false, ezero);
     };
 
     // weighted-Jacobi sweep on level 2                                   MG_Vcycle.m:15-21; Class_AMG.m:84
     auto sweep2 = [&](bool ezero) __attribute__((always_inline)) {
-        RES_FRESH;
         double s = 0.0, eo = 0.0;
         if (!ezero) {
             s = wave_sum(res_rowdot<KE2, 8 * oE2>(c2, a2, smb));
@@ -834,7 +818,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // of the next sweep.
     auto remote_tail = [&](const ResCsr& Pin, int oRRs, int oEd, int oRd, int oAXd, double xxd, int Nout,
                            double& cnext) __attribute__((always_inline)) {
-        RES_FRESH;
         ++tseq;
         const int rin = b + G * w;
         if (rin < Nt) {
@@ -874,7 +857,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // guess), prolongation into the level above (oEd, with oRd / oAXd for the next scalar).
     auto local_tail = [&](const ResCsr& PtT, const ResCsr& AT, const ResCsr& PT, int oRRs, int oEd, int oRd,
                           int oAXd, double xxd, int Nabove, double& cnext) __attribute__((always_inline)) {
-        RES_FRESH;
         if (Nt == 1) {
             // one row: its entries are dealt to all the waves, the eight partial sums are added in
             // wave order (a single wave walking 1024 entries took four dependent trips)
@@ -947,7 +929,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         if (nsp) cnext = res_red8(red) / xxd;
         };
     auto tail = [&]() __attribute__((always_inline)) {
-        RES_FRESH;
         if (D.remote) {
             remote_tail(D.Pt3, oRR2, oE2, oR2, oAX2, xx2, N2, c2s);
             return;
@@ -1002,7 +983,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         RES_HANDOFF(2, N3 + G, lo3, hi3 - lo3, N3 + b, 1, { if (j < N3) { STORE3; } }, {}, want_sums, t0, dum1); \
     } while (0)
     auto sweep3 = [&](bool ezero) __attribute__((always_inline)) {
-        RES_FRESH;
         if (THREE) {
             double s = 0.0, eo = 0.0;
             if (!ezero) {
@@ -1028,7 +1008,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // polynomial form: the sums of this workgroup's rows against [r_3; e_3] (+ their factor of 1'r_3)
     // -> sm[oR3 + 40 + q]; the caller's next barrier publishes them
     auto poly3_rows = [&](int nrows, bool post) __attribute__((always_inline)) {
-        RES_FRESH;
         const double xr = tid < N3 ? sm[oR3L + tid] : 0.0, xe = tid < N3 ? sm[oE3L + tid] : 0.0;
         const double xc = (post && tid < Nt) ? sm[oRR3L + tid] : 0.0;
 #pragma unroll
@@ -1050,7 +1029,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         __syncthreads();
     };
     auto visit3 = [&](bool keep) __attribute__((always_inline)) {
-        RES_FRESH;
         if (POLY3) {
             ++tseq;
             // e' = M2a r + M1 e and the restricted residual of e' in one pass                 MG_Vcycle.m:20-29
@@ -1093,7 +1071,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 
     // one visit of level 2 and everything below it
     auto visit2 = [&](bool keep) __attribute__((always_inline)) {
-        RES_FRESH;
         const int nu = D.nu;
         if (POLY2) {   // the whole visit as one composed pass (ResDesc::p2rows): ONE hand-off
             // r_3 = s'r_2 + ws (1'r_2) and the one-row tail's PCG (PCG.m:68-87) by every workgroup
@@ -1169,7 +1146,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
 
     // MG_Vcycle / MG_Wcycle from level 1 down; the correction ends in E1
     auto cycle = [&]() __attribute__((always_inline)) {
-        RES_FRESH;
         const int nu = D.nu;
         for (int s = 0; s < nu; ++s) sweep1(false, s == 0);
         {   // rr = r - A e on both blocks
@@ -1243,7 +1219,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     };
 
     auto add_correction = [&]() __attribute__((always_inline)) {   // x += e                                       Class_AMG.m:98,101
-        RES_FRESH;
         for (int j = tid; j < N1; j += BT) sm[oX + j] = sm[oX + j] + sm[oE1 + j];
         __syncthreads();
     };
@@ -1333,7 +1308,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         D.dbg[8] = dbg_acc[7];
     }
 #undef RES_HANDOFF3
-#undef RES_FRESH
 #undef RES_HANDOFF
 #undef dgF
 #undef dvF

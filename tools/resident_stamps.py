@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rho", type=float, default=1.0)
     ap.add_argument("--cycle", default="v")
     ap.add_argument("--cycles", type=int, default=200)
+    ap.add_argument("--no-poly2", action="store_true", help="level 2 as sweeps (33 hand-offs per V cycle)")
     a = ap.parse_args()
     import codes_of_ipd_ssn_amg_method_amd as ipd
     from codes_of_ipd_ssn_amg_method_amd import _lib
@@ -30,6 +31,8 @@ def main():
     opts = dict(retol=1e-11, bigph=1, maxit=30, theta=0.25, smoth=5, cycle=a.cycle, isnsp=1, inter=1, fnode=n)
     h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
     print("level 1 <-> 2 transfers from the bit mask:", h.attach_mask_transfers(np.ones(m), np.ones(n), bench.TK))
+    if a.cycle == "v" and not a.no_poly2:
+        print("level 2 composed over a visit (ipd_amg_attach_level2_poly):", h.attach_level2_poly())
     db = _lib.DeviceBuffer.from_array(f)
     dx = _lib.DeviceBuffer.from_array(guess)
     st = (c_int64 * 10)()
