@@ -109,8 +109,7 @@ void ipd_lds_optin(const void* kernel, int device, int bytes) {
 }
 
 static bool mailbox_enabled() {
-    static const bool on = getenv("IPD_NO_MAILBOX") == nullptr;
-    return on;
+    return true;
 }
 
 bool ipd_ctx::mailbox_begin(unsigned* ticket) {
@@ -258,7 +257,7 @@ extern "C" int ipd_ctx_create(int device, ipd_ctx** out) {
         c->scratch.reset(new Arena(&c->pool));
         c->pinned_bytes = size_t(1) << 20;
         IPD_HIP(hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault));
-        if (!(getenv("IPD_NO_UPLOAD_RING") && getenv("IPD_NO_UPLOAD_RING")[0] == '1')) {
+        {
             void* ring = nullptr;
             c->up_ring_bytes = size_t(4) << 20;
             IPD_HIP(hipHostMalloc(&ring, c->up_ring_bytes, hipHostMallocDefault));

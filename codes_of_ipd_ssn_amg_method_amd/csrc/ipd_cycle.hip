@@ -648,14 +648,7 @@ static int pick_lanes(long long nnz, int nrows, int blocks_target) {
     // 6: 1.62 / 0.81.  Long rows (dense masks): 12 -- with 2 the 512..1024-entry rows of the
     // regime-D transfers spread over 512-1024 lanes and the cross-wave reduction costs more than
     // the shorter walk saves (k_xfer 6.6 -> 10.0 us, V cycle 0.200 -> 0.206 ms).
-    static const double forced = [] {
-        const char* e = std::getenv("IPD_LANE_ENTRIES");
-        return e ? std::atof(e) : 0.0;
-    }();
-    static const double forced_long = [] {
-        const char* e = std::getenv("IPD_LANE_ENTRIES_LONG");
-        return e ? std::atof(e) : 0.0;
-    }();
+    const double forced = 0.0, forced_long = 0.0;
     // regime D, m=n=1024 / 2048, ms per V cycle: 3: 0.2007 / 0.387, 4.5: 0.1968 / 0.378,
     // 6: 0.1960 / 0.376, 9: 0.1975 / 0.374, 17: 0.1969 / 0.370
     // (with 512-thread blocks: 6: 0.1903 / 0.337, 12: 0.1866 / 0.324, 24: 0.1891 / 0.320)

@@ -210,10 +210,8 @@ static void build_padded(ipd_ctx* ctx, Arena& ar, const Csr& A, int rows_per_lau
     if (A.nr > 65535 || A.nr == 0) return;
     const double avg_off = (double)(A.nnz - A.nr) / (double)A.nr;
     // small levels too: one dependent round trip less per launch (measured -6 % solve time on
-    // the m=n=1024 Class 1 run); IPD_PAD_MINAVG restores a threshold on the mean row length
-    double min_avg = 0.5;
-    if (const char* e = std::getenv("IPD_PAD_MINAVG")) min_avg = std::atof(e);
-    if (avg_off < min_avg) return;
+    // the m=n=1024 Class 1 run)
+    if (avg_off < 0.5) return;
     const int grid = std::max(1, std::min(cdiv(A.nr, 4), 4096));
     const int S = (maxlen + 3) / 4 * 4;
     if (S == 0 || (double)S > 1.3 * avg_off + 16.0) return;
@@ -234,11 +232,9 @@ static void build_padded(ipd_ctx* ctx, Arena& ar, const Csr& A, int rows_per_lau
     // m=n=2048 (2048-entry rows, bandwidth-bound): 1: 0.376 ms per V cycle, 2: 0.342, 4: 0.332,
     // 8/16: 0.332; m=n=1024 unchanged (0.197), m=n=4096 Class 1 run 5.37 -> 5.29 s
     // (with 512-thread blocks: 4: 0.337, 8: 0.324-0.330, 16: 0.325)
-    int batches = 8;
-    if (const char* e = std::getenv("IPD_PAD_BATCHES")) batches = std::max(1, std::atoi(e));
+    const int batches = 8;
     while (L < BT && L * (ROW_U / 4) * batches < nvec) L <<= 1;
-    double fill = 1.0;   // one workgroup per CU (0.5 left half the chip idle on a 1024-row level: 6.16 -> 5.79 us)
-    if (const char* e = std::getenv("IPD_PAD_FILL")) fill = std::atof(e);
+    const double fill = 1.0;   // one workgroup per CU (0.5 left half the chip idle on a 1024-row level: 6.16 -> 5.79 us)
     while (L < BT && (double)rows_per_launch * L < fill * cu * BT && L < nvec) L <<= 1;
     dev->L = L;
     dev->G = pick_blocks(rows_per_launch, L, cu);
@@ -352,7 +348,7 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     // (built below, once the hierarchy is known to be taken).  d1 / d2 carry the stride either way.
     LevelDev d1 = st->run[1].dev;
     LevelDev d2 = st->run[2].dev;
-    const bool nopriv = std::getenv("IPD_NO_RESIDENT_PRIVPAD") && std::getenv("IPD_NO_RESIDENT_PRIVPAD")[0] == '1';
+    const bool nopriv = false;
     bool priv1 = false, priv2 = false;
     if (d1.S <= 0 && st->run[1].maxoff > 0 && !nopriv) {
         d1.S = (st->run[1].maxoff + 3) / 4 * 4;
@@ -443,7 +439,6 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     // level 3 in polynomial form (ResDesc::p3rows): remote tail, one restriction row per workgroup at most,
     // at most four rows of level 3 per workgroup
     const bool poly3 = three && remote && h->opts.smoth >= 1 && h->L[4].A.nr <= G && h->L[4].A.nr <= 128 && Nt <= 4 * G && Nt <= BT &&
-                       !(std::getenv("IPD_NO_RES_POLY3") && std::getenv("IPD_NO_RES_POLY3")[0] == '1') &&
                        !(std::getenv("IPD_NO_POLY") && std::getenv("IPD_NO_POLY")[0] == '1');
     if (poly3) ke3 = 1;
     const size_t lds = remote ? std::max<size_t>(RES_LDS_BYTES, tail_lds) : RES_LDS_BYTES;
@@ -523,7 +518,7 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     D.pcg_maxit = h->opts.pcg_maxit;
     // bigraph transfers P = [W; I]: the kernel adds the identity entries instead of walking them
     D.wident = 0;
-    if (N2 == nc && !(std::getenv("IPD_RES_NO_IDENT") && std::getenv("IPD_RES_NO_IDENT")[0] == '1')) {
+    if (N2 == nc) {
         int* bad = h->ctx->scratch->alloc<int>(1);
         IPD_HIP(hipMemsetAsync(bad, 0, sizeof(int), h->ctx->stream));
         hipLaunchKernelGGL(k_res_check_ident, dim3(cdiv(N2, 256)), dim3(256), 0, h->ctx->stream, nf, N2,
@@ -531,11 +526,9 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
         IPD_KERNEL_CHECK();
         D.wident = h->ctx->fetch1(bad) == 0 ? 1 : 0;
     }
-    D.localfirst = (std::getenv("IPD_RES_NO_LOCALFIRST") && std::getenv("IPD_RES_NO_LOCALFIRST")[0] == '1') ? 0 : 1;
-    D.pollsleep = 1;
-    if (const char* e = std::getenv("IPD_RES_POLLSLEEP")) D.pollsleep = std::max(0, std::min(64, std::atoi(e)));
+    D.localfirst = 1;
+    D.pollsleep = 1;   // (0..2 sleeps between polls made no difference, from 3 on it was worse)
     D.presleep = 13;   // measured: 0 -> 0.0869, 8 -> 0.0796, 12..14 -> 0.0770, 16 -> 0.0784 ms per V cycle (a failing poll delays the publishes it waits for)
-    if (const char* e = std::getenv("IPD_RES_PRESLEEP")) D.presleep = std::max(0, std::min(64, std::atoi(e)));
     const size_t gbytes = (size_t)RES_GRAN_MAX * 16;
     st->res_block_bytes = 2 * gbytes + 16 + (remote ? 4 * gbytes + 16 : 0);
     st->res_block = reinterpret_cast<unsigned char*>(ar.alloc_bytes(st->res_block_bytes));
@@ -917,10 +910,7 @@ void amg_prepare_levels(ipd_amg* h) {
         st->run[(size_t)h->J].pcg = a;
     }
     st->num_cu = cu;
-    {
-        const char* nf = std::getenv("IPD_NO_FUSE");
-        st->fuse_enabled = !(nf && nf[0] == '1');
-    }
+    st->fuse_enabled = true;
     st->hist = ar.alloc<double>(8);
     st->x2 = ar.alloc<double>((size_t)h->L[1].A.nr);
     h->x = ar.alloc<double>((size_t)h->L[1].A.nr);
@@ -991,18 +981,14 @@ void amg_prepare_levels(ipd_amg* h) {
                     !(std::getenv("IPD_NO_BLK") && std::getenv("IPD_NO_BLK")[0] == '1');
     // (polynomial form: a level whose stacked operator [e'; r_c] has more than 32 rows -- one lane per row in
     // a single wave -- runs block-wide instead, out of LDS all the same: is_lpoly below)
-    bool use_lpoly = !(std::getenv("IPD_NO_LPOLY") && std::getenv("IPD_NO_LPOLY")[0] == '1') &&
-                           !(std::getenv("IPD_NO_BLK") && std::getenv("IPD_NO_BLK")[0] == '1');
+    bool use_lpoly = !(std::getenv("IPD_NO_BLK") && std::getenv("IPD_NO_BLK")[0] == '1');
     auto find_tiny_lo = [&](int rows_max) {
         int lo = h->J + 1;
-        if (const char* e = std::getenv("IPD_TINY_ROWS")) rows_max = std::max(1, std::min(64, std::atoi(e)));
-        const char* nt = std::getenv("IPD_NO_TINY");
-        if (!(nt && nt[0] == '1'))
-            for (int k = h->J; k >= 2; --k) {
-                if (h->L[k].A.nr > rows_max) break;
-                if (rows_max > 32 && use_lpoly && k < h->J && h->L[k].A.nr + h->L[k + 1].A.nr > 32) break;
-                lo = k;
-            }
+        for (int k = h->J; k >= 2; --k) {
+            if (h->L[k].A.nr > rows_max) break;
+            if (rows_max > 32 && use_lpoly && k < h->J && h->L[k].A.nr + h->L[k + 1].A.nr > 32) break;
+            lo = k;
+        }
         return lo;
     };
     tiny_lo = find_tiny_lo(use_poly ? 48 : 32);
@@ -1018,7 +1004,7 @@ void amg_prepare_levels(ipd_amg* h) {
         const char* nb = std::getenv("IPD_NO_BLK");
         if (nb && nb[0] == '1') lean_vectors = false;
     }
-    const bool use_lmap = !(std::getenv("IPD_NO_LMAP") && std::getenv("IPD_NO_LMAP")[0] == '1') && lean_vectors;
+    const bool use_lmap = lean_vectors;
     // small, nearly full thread-per-row levels: dense copy instead of the CSR arrays (see SolveLevel::blk_dense)
     const bool use_bdense = lean_vectors && !(std::getenv("IPD_NO_BLKDENSE") && std::getenv("IPD_NO_BLKDENSE")[0] == '1');
     auto is_lpoly = [&](int k) {
@@ -1388,8 +1374,7 @@ void amg_prepare_levels(ipd_amg* h) {
     // Level 2 as a semi-cached level (r, e, e2 in LDS; matrix rows from L2) with levels 3..J fully
     // cached: returns the dynamic LDS needed behind a staging area of `stage` bytes, 0 = no
     auto semi_plan = [&](size_t stage) -> size_t {
-        const char* nse = std::getenv("IPD_NO_SEMI");
-        if ((nse && nse[0] == '1') || !lean_vectors || h->J < 3 || h->J > SOLVE_ML) return 0;
+        if (!lean_vectors || h->J < 3 || h->J > SOLVE_ML) return 0;
         const Level& l2 = h->L[2];
         if (l2.A.nr > BT || l2.A.nr <= 64 || (double)l2.A.nnz > 12.0 * l2.A.nr ||
             (double)h->L[3].P.nnz > 12.0 * l2.A.nr)
@@ -1416,13 +1401,6 @@ void amg_prepare_levels(ipd_amg* h) {
             const size_t stage = r16(sizeof(double) * maxlen);
             size_t used = 0;
             int k_lds = plan_lds(stage, &used);
-            {
-                const char* nc = std::getenv("IPD_NO_LDSCACHE");
-                if (nc && nc[0] == '1') {
-                    k_lds = h->J + 1;
-                    used = stage + 256;
-                }
-            }
             sd->k_lds = k_lds;
             st->solve_cached = k_lds <= h->J;
             sd->k_tiny = tiny_from(k_lds);
@@ -1498,8 +1476,7 @@ void amg_prepare_levels(ipd_amg* h) {
                         (double)h->L[kroot].A.nnz <= 12.0 * h->L[kroot].A.nr &&
                         (double)h->L[kroot + 1].P.nnz <= 12.0 * h->L[kroot].A.nr &&
                         used + 3 * r16(8 * (size_t)h->L[kroot].A.nr) <= 150 * 1024) {
-                        const char* ns3 = std::getenv("IPD_NO_SEMI_ROOT");
-                        semi_root = !(ns3 && ns3[0] == '1');
+                        semi_root = true;
                     }
                     if (k_lds > kroot && !semi_root) continue;
                     std::unique_ptr<SolveDesc> sd(new SolveDesc());
@@ -1530,7 +1507,6 @@ void amg_prepare_levels(ipd_amg* h) {
         h->J >= 5 && h->opts.smoth >= 1 && h->L[1].nf > 0 &&
         h->L[4].A.nr <= 128 &&
         h->L[4].A.nr <= std::max(cdiv(std::max(h->L[1].nf, h->L[1].A.nr - h->L[1].nf), RES_WAVES), cdiv(h->L[2].A.nr, RES_WAVES)) &&
-        !(std::getenv("IPD_NO_RES_POLY3") && std::getenv("IPD_NO_RES_POLY3")[0] == '1') &&
         !(std::getenv("IPD_NO_POLY") && std::getenv("IPD_NO_POLY")[0] == '1');
     if (st->k_sub == 3 && (st->sub_semi_root || poly3_likely) && st->d_sub && h->J >= 5 && h->J <= SOLVE_ML && h->L[3].A.nr <= BT &&
         h->L[4].A.nr <= BT && st->run[3].maxoff <= 512 && h->L[1].nf > 0 &&
@@ -1802,7 +1778,7 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
     const Level& lv = h->L[1];
     // the level-resident kernel takes its level 1 <-> 2 transfers from the mask whatever the size
     const bool for_resident = st->res_ok && !st->res_desc.three && st->res_desc.wident && h->J == 3 &&
-                              !(std::getenv("IPD_RES_NO_XMASK") && std::getenv("IPD_RES_NO_XMASK")[0] == '1');
+                              true;
     bool sweeps_too = !transfers_only;
     const bool big_forced = std::getenv("IPD_RESIDENT_BIG") && std::getenv("IPD_RESIDENT_BIG")[0] == '1';
     // Realistic hierarchy with a level 1 beyond k_resident's 2048 rows (the Newton systems of the m = n = 2048
@@ -1831,8 +1807,6 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
     }
     if (transfers_only && !for_resident && !big_forced && !deep_cand) return false;
     if (policy) {
-        const char* off = std::getenv("IPD_NO_MASKOP");
-        if (off && off[0] == '1') return false;
         const char* on = std::getenv("IPD_MASKOP");
         if (!(on && on[0] == '1') && (double)lv.A.nnz < 4.0e6) {
             if (!for_resident && !deep_cand) return false;
@@ -1971,7 +1945,6 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
                 B.pcg_maxit = h->opts.pcg_maxit;
                 B.pollsleep = 1;
                 B.presleep = 13;
-                if (const char* e = std::getenv("IPD_RES_PRESLEEP")) B.presleep = std::max(0, std::min(64, std::atoi(e)));
                 const size_t gbytes = (size_t)RB_GRAN * 16;
                 st->res_block_bytes = 2 * gbytes + 16;
                 st->res_block = reinterpret_cast<unsigned char*>(ar.alloc_bytes(st->res_block_bytes));
@@ -2087,7 +2060,6 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
                 B.pcg_maxit = h->opts.pcg_maxit;
                 B.pollsleep = 1;
                 B.presleep = 13;
-                if (const char* e = std::getenv("IPD_RES_PRESLEEP")) B.presleep = std::max(0, std::min(64, std::atoi(e)));
                 const size_t gbytes = (size_t)RB_GRAN * 16, tbytes = (size_t)RES_GRAN_MAX * 16;
                 st->res_block_bytes = 2 * gbytes + 16 + 4 * tbytes + 16;
                 st->res_block = reinterpret_cast<unsigned char*>(ar.alloc_bytes(st->res_block_bytes));
@@ -2852,11 +2824,9 @@ extern "C" int ipd_amg_bench_subcycle(ipd_amg* h, int reps, double* total_ms, in
         IPD_HIP(hipMemsetAsync(dbg, 0, 128, ctx->stream));
         // patch the debug pointer into the image header
         const size_t off = offsetof(SolveDesc, dbg);
-        // IPD_BENCH_NODBG=1: no stamps -- a stamp is two s_memrealtime reads and a read-modify-write of
-        // global memory (~0.5 us each): the per-stage figures are for proportions, the launch time
-        // without them is the one to quote
-        const bool nodbg = std::getenv("IPD_BENCH_NODBG") && std::getenv("IPD_BENCH_NODBG")[0] == '1';
-        if (!nodbg) ctx->upload_bytes(reinterpret_cast<char*>(st->d_sub) + off, &dbg, sizeof(dbg));
+        // (a stamp is two s_memrealtime reads and a read-modify-write of global memory, ~0.5 us each: the
+        // per-stage figures are for proportions)
+        ctx->upload_bytes(reinterpret_cast<char*>(st->d_sub) + off, &dbg, sizeof(dbg));
         {   // a right-hand side that is not zero (a zero one ends every coarse PCG at once)
             std::vector<double> rr((size_t)h->L[st->k_sub].N);
             unsigned lcg = 12345u;
@@ -2889,9 +2859,6 @@ extern "C" int ipd_amg_bench_subcycle(ipd_amg* h, int reps, double* total_ms, in
             stamps[0] = hs[8] * 100 / (hs[3] - hs[2]), hs[0] = stamps[0];
         if (stamps)
             for (int i = 0; i < 8; ++i) stamps[i] = hs[i];
-        if (const char* e = std::getenv("IPD_DEBUG_SWEEP"); e && e[0] == '1')
-            std::fprintf(stderr, "[ipd] one-wave levels, per launch (us): sweeps %.2f pcg %.2f resid+restrict %.2f prolong %.2f\n",
-                         hs[9] / 100.0, hs[10] / 100.0, hs[11] / 100.0, hs[12] / 100.0);
         long long* none = nullptr;
         ctx->upload_bytes(reinterpret_cast<char*>(st->d_sub) + off, &none, sizeof(none));
     });

@@ -659,7 +659,6 @@ void kkt_asat(ipd_ctx* ctx, Arena& dst, const uint8_t* s, const double* p, const
     unsigned sticket = 0;
     const bool small = ctx->asat_nnz_hint > 0 && ctx->asat_nnz_hint <= 65536 && pl.nib <= 16 && pl.njb <= 16 &&
                        cdiv(M, 256) <= 64 &&
-                       !(getenv("IPD_NO_ASAT_SMALL") && getenv("IPD_NO_ASAT_SMALL")[0] == '1') &&
                        ctx->mailbox_begin(&sticket);
     if (!small) IPD_HIP(hipMemsetAsync(rp + M + 1, 0, sizeof(int), ctx->stream));
     if (m % 8 == 0 && (reinterpret_cast<uintptr_t>(s) & 7) == 0)

@@ -787,8 +787,7 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
             const size_t lds = std::max<size_t>((size_t)nc * 8, 16);
             IPD_OPTIN_LDS(ctx, k_spgemm_rows, 128 * 1024);
             const int threads = (Y.nr > 0 && (double)Y.nnz / Y.nr >= 96.0) ? 256 : 64;
-            const char* nwv = getenv("IPD_NO_SPGEMM_WAVE");
-            if (threads == 64 && !(nwv && nwv[0] == '1')) {
+            if (threads == 64) {
                 IPD_OPTIN_LDS(ctx, k_spgemm_rows_w<8>, 128 * 1024);
                 hipLaunchKernelGGL(k_spgemm_rows_w<8>, dim3(std::min(nr, 16384)), dim3(64), lds, ctx->stream, nr,
                                    nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense, rowcnt, rowbits);

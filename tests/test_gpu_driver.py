@@ -157,11 +157,13 @@ def check_run(out, ref, keys, late_counts=True, rtol=1e-7):
     # itself stops at retol = 1e-11, Class_AMG.m:95), so the count of a late iteration is rounding
     # noise: the ORACLE's own late counts move when its Newton directions are perturbed by one
     # unit in the last place (tests/test_oracle_drivers.py::test_late_newton_counts_are_rounding_noise:
-    # 5-6 of the last 11 iterations change), and one flipped test costs one or two further steps.
+    # 5-6 of the last 11 iterations change by one step under a 1e-15 perturbation, one of them by two steps
+    # under 2e-15), and one flipped test costs one or two further steps.
     a, b = out["SsN_itnum"].astype(int), np.asarray(ref["SsN_itnum"])
     assert a.shape == b.shape and np.array_equal(a[:15], b[:15])
     if late_counts:
         assert np.abs(a - b).max() <= 2 and np.array_equal(a[:len(a) // 2], b[:len(a) // 2])
+        assert np.count_nonzero(a != b) <= max(2, len(a) // 4)      # (few iterations, not only small steps)
     for key in keys:
         a, b = np.asarray(out[key]), np.asarray(ref[key])
         assert a.shape == b.shape

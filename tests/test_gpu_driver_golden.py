@@ -28,6 +28,7 @@ def compare(out, g, keys, rtol=1e-6):
     # tests/test_oracle_drivers.py::test_late_newton_counts_are_rounding_noise), same bound as
     # tests/test_gpu_driver.py::check_run
     assert np.array_equal(ssn[:half], ref[:half]) and np.abs(ssn - ref).max() <= 2
+    assert np.count_nonzero(ssn != ref) <= max(2, len(ref) // 4)
     for key in keys:
         a, b = out[key], g[key]
         assert a.shape == b.shape, key
