@@ -441,6 +441,14 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     const bool poly3 = three && remote && h->opts.smoth >= 1 && h->L[4].A.nr <= G && h->L[4].A.nr <= 128 && Nt <= 4 * G && Nt <= BT &&
                        !(std::getenv("IPD_NO_POLY") && std::getenv("IPD_NO_POLY")[0] == '1');
     if (poly3) ke3 = 1;
+    // level 4 resident as well (ResDesc::p4rows), the tail workgroup rooted at level 5
+    const int N5r = h->J >= 6 ? h->L[5].A.nr : 0;
+    const bool poly4 = poly3 && st->d_sub5 && h->L[1].A.nr <= RES_NMAX && N5r >= 1 && N5r <= 64 && N5r <= G &&
+                       h->L[4].A.nr <= RES_P4_SEG && h->L[4].A.nr + G <= BT;
+    if (poly4) {
+        tail_img = st->d_sub5;
+        tail_lds = st->sub5_lds;
+    }
     const size_t lds = remote ? std::max<size_t>(RES_LDS_BYTES, tail_lds) : RES_LDS_BYTES;
     if (lds > 156 * 1024) return;
     Arena& ar = *h->arena;
@@ -487,7 +495,7 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     D.A3 = csr(l3.A);
     D.Nt = Nin;
     D.three = three ? 1 : 0;
-    D.tail_root = three ? 4 : 3;
+    D.tail_root = poly4 ? 5 : three ? 4 : 3;
     D.A4 = csr(three ? h->L[4].A : l3.A);
     if (three) {
         LevelDev d3 = st->run[3].dev;
@@ -497,6 +505,13 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
             D.p3w = pb.W;
             st->level_forms.resize((size_t)h->J + 1, 0);
             st->level_forms[3] |= 64;
+            if (poly4) {
+                const BPolyDev pb4 = pack_bpoly(h->ctx, h, st, 4, h->opts.isnsp, 0, true, RES_P4_SEG, RES_P4_LD);
+                D.p4rows = pb4.M;
+                D.p4w = pb4.W;
+                D.N5 = N5r;
+                st->level_forms[4] |= 64;
+            }
         } else if (d3.S <= 0) {   // private padded copy of level 3, stride = its longest row
             d3.S = (st->run[3].maxoff + 3) / 4 * 4;
             private_pad(l3.A, d3);
@@ -545,6 +560,7 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     if (const char* e = std::getenv("IPD_RES_DEBUG_SKIP_PUBLISH")) D.dbg_skip_seq = (unsigned)std::max(0, std::atoi(e));
     st->res_desc = D;
     st->res_remote = remote;
+    st->resb_poly4 = poly4;
     st->res_ke3 = ke3;
     st->res_G = G;
     st->res_ke = ke;
@@ -1558,6 +1574,17 @@ void amg_prepare_levels(ipd_amg* h) {
     if (st->k_sub == 5 && st->d_sub && !st->sub_semi_root && h->J >= 6 && h->L[1].A.nr > RES_NMAX) {
         st->d_sub5 = st->d_sub;
         st->sub5_lds = st->sub_lds;
+    }
+    // (b5) ... and k_resident's POLY3 mode (level 1 of at most 2048 rows) keeps level 4 in polynomial form in its
+    // workgroups as well when there are six levels or more (ResDesc::p4rows).  Its tail workgroup takes the
+    // image rooted at level 4 that the POLY3 mode uses anyway and enters it at level 5 (an image of its own,
+    // rooted at level 5, packed levels 5..J a second time: +85 us per hierarchy, more than the cycles gained).
+    if (!st->d_sub5 && poly3_likely && h->J >= 6 && h->L[1].A.nr <= RES_NMAX &&
+        ((st->k_sub == 3 && st->d_sub4) || (st->k_sub == 4 && st->d_sub && !st->sub_semi_root)) &&
+        h->L[4].A.nr <= RES_P4_SEG && h->L[5].A.nr <= 64 &&
+        !(std::getenv("IPD_NO_RES_POLY4") && std::getenv("IPD_NO_RES_POLY4")[0] == '1')) {
+        st->d_sub5 = st->k_sub == 3 ? st->d_sub4 : st->d_sub;
+        st->sub5_lds = st->k_sub == 3 ? st->sub4_lds : st->sub_lds;
     }
     plan_resident(h, st.get());
     if (const char* dbg = std::getenv("IPD_DEBUG_LEVELS"); dbg && dbg[0] == '1') {

@@ -44,6 +44,8 @@ static constexpr int RES_GRAN_MAX = RES_NMAX;  // granules per hand-off buffer
 static constexpr size_t RES_LDS_BYTES = sizeof(double) * ((size_t)9 * RES_NMAX + RES_NMAX / 2 + 3 * RES_TAIL_MAX + 16 * RES_WAVES + 12);
 static constexpr unsigned RES_SPIN_MAX = 1u << 18;
 static constexpr int RES_P3_LD = 1152;         // row stride of ResDesc::p3rows: 512 + 512 + 128
+static constexpr int RES_P4_SEG = 128;         // ... of ResDesc::p4rows: 128 + 128 + 64
+static constexpr int RES_P4_LD = 2 * RES_P4_SEG + 64;
 
 struct ResLevelDesc {
     int N, nf, S;
@@ -89,6 +91,15 @@ struct ResDesc {
     const double* p2rows;
     const double* p2w;
     int p2seg, p2ld;
+    // Level 4 in polynomial form in the resident workgroups as well (round 4, POLY3 hierarchies of six levels
+    // and more; N5 > 0): row b < N4 of [M2a | M1] and the restriction row N4 + b (b < N5) per workgroup, fetched
+    // from L2 at every pass (row stride RES_P4_LD: [Mr (128) | Me (128) | Mc (64)]); the restricted residual of
+    // level 3 goes to EVERYBODY in the ack granules of level 3's hand-off, and the tail workgroup is rooted
+    // at level 5 (ResDesc::sub then holds levels 5..J, tail_root = 5).  With the tail at level 4 its two legs
+    // per visit of level 3 were 50 us of serial work on the late Newton systems (4 per W cycle: 200 of 296 us).
+    int N5;
+    const double* p4rows;
+    const double* p4w;
     // Remote tail (hierarchies with more than three levels): workgroup gridDim.x - 1 holds the LDS
     // image of the single-workgroup sub-cycle rooted at level 3 (k_subcycle's code and data) and
     // serves the visits of everything below level 2: the other workgroups hand it r_3 = P3' rr_2
@@ -355,7 +366,7 @@ __device__ __forceinline__ void res_tail_workgroup(const ResDesc& D, char* dyn_r
     c.part = blkpart;
     c.sumr = blkpart + 48;
     c.dbg = nullptr;
-    const int k0 = D.tail_root, N3 = D.Nt, N2 = k0 == 3 ? D.L2.N : D.L3.N;   // inbox / outbox rows
+    const int k0 = D.tail_root, N3 = k0 == 5 ? D.N5 : D.Nt, N2 = k0 == 3 ? D.L2.N : D.L3.N;   // inbox / outbox rows
     const ResCsr& Pout = k0 == 3 ? D.P3 : D.P4;
     const bool two_legs = D.wcycle && k0 < LD->J;
     const auto rin = __builtin_amdgcn_make_buffer_rsrc(D.tin, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
@@ -438,6 +449,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     // third resident level (THREE): its vectors sit in the upper halves of level 2's slots (N2 <= 1024,
     // N3 <= 512); E3 is a gather target and must lie below 64 KB
     constexpr int oE3L = oE2 + RES_NMAX / 2, oR3L = oRR2 + RES_NMAX / 2, oRR3L = oRR2 + 3 * RES_NMAX / 4;
+    // POLY4 (the RR3L region holds 512 doubles, e_4 takes 128): r_4, e_5, partial sums and the rows' factors
+    constexpr int oR4L = oRR3L + 128, oE5L = oRR3L + 256, oPS4 = oRR3L + 320;
     constexpr int oAX3L = oAX2 + RES_NMAX / 2;
     const int N3 = THREE ? D.L3.N : 0;
     double* red = sm + oRED;
@@ -495,6 +508,10 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         if (tid < 5) {
             const int row = tid < 4 ? lo3 + tid : N3 + b;
             sm[oE3 + tid] = (tid < 4 ? row < hi3 : b < Nt) ? D.p3w[row] : 0.0;
+        }
+        if (D.N5 > 0 && tid < 2) {   // POLY4: the factors of 1'r_4 of row b and of restriction row N4 + b
+            const int row = tid == 0 ? b : Nt + b;
+            sm[oPS4 + 20 + tid] = (tid == 0 ? b < Nt : b < D.N5) ? D.p4w[row] : 0.0;
         }
     }
     // the rows' own scalars live in LDS (a register pair each would stay live for the whole solve)
@@ -982,6 +999,19 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         if (w == 0 && lane == 0) sm[oPUB + RES_WAVES] = 0.0;                                             \
         RES_HANDOFF(2, N3 + G, lo3, hi3 - lo3, N3 + b, 1, { if (j < N3) { STORE3; } }, {}, want_sums, t0, dum1); \
     } while (0)
+    // POLY4: the ack granule of workgroup b < N4 carries r_4[b] (the restricted residual goes to everybody) ...
+#define RES_HANDOFF3R(ACKV, STORE3, STORE4, want_sums, t0)                                               \
+    do {                                                                                                 \
+        if (w == 0 && lane == 0) sm[oPUB + RES_WAVES] = (ACKV);                                          \
+        RES_HANDOFF(2, N3 + G, lo3, hi3 - lo3, N3 + b, 1,                                                \
+                    { if (j < N3) { STORE3; } else if (j - N3 < Nt) { const int j4 = j - N3; STORE4; } }, {}, want_sums, t0, dum1); \
+    } while (0)
+    // ... and the hand-off among the rows of level 4: row b of workgroup b < N4, an ack granule of everybody
+#define RES_HANDOFF4(STORE4)                                                                             \
+    do {                                                                                                 \
+        if (w == 0 && lane == 0) sm[oPUB + RES_WAVES] = 0.0;                                             \
+        RES_HANDOFF(1, Nt + G, b, (b < Nt ? 1 : 0), Nt + b, 1, { if (j < Nt) { STORE4; } }, {}, 0, dum0, dum1); \
+    } while (0)
     auto sweep3 = [&](bool ezero) __attribute__((always_inline)) {
         if (THREE) {
             double s = 0.0, eo = 0.0;
@@ -1028,27 +1058,101 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         }
         __syncthreads();
     };
+    // POLY4: workgroup b's row of level 4 (b < N4 = Nt) and restriction row N4 + b (b < N5) against [r_4; e_4]
+    // (+ (M1 P5) e_5 in the second pass) -> sm[oPS4 + 16 + q]; coefficients from L2 at every pass, one entry per
+    // thread and segment (threads 0..127).  e_4 lives where the tail's answer of the POLY3 mode does (oRR3L).
+    const int N5 = POLY3 ? D.N5 : 0;
+    const bool poly4 = POLY3 && N5 > 0;
+    double sumr4 = 0.0;
+    auto poly4_rows = [&](int nrows, bool post) __attribute__((always_inline)) {
+        // rows q = 0: row b of [M2a | M1] (b < N4), q = 1: restriction row N4 + b (b < N5; first pass only)
+        double m4r[2], m4e[2], m4c;
+        const int t4 = tid < RES_P4_SEG ? tid : 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = q == 0 ? b : Nt + b;
+            const bool okr = q < nrows && (q == 0 ? b < Nt : b < N5) && tid < RES_P4_SEG;
+            const double* pr = D.p4rows + (size_t)(okr ? row : 0) * RES_P4_LD;
+            const double vr = pr[t4], ve = pr[RES_P4_SEG + t4];
+            m4r[q] = okr ? vr : 0.0;
+            m4e[q] = okr ? ve : 0.0;
+            if (q == 0) {
+                const double vc = pr[2 * RES_P4_SEG + (tid < 64 ? tid : 0)];
+                m4c = (okr && post && tid < N5) ? vc : 0.0;
+            }
+        }
+        const double xr = tid < Nt ? sm[oR4L + t4] : 0.0, xe = tid < Nt ? sm[oRR3L + t4] : 0.0;
+        const double xc = (post && tid < N5) ? sm[oE5L + tid] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q < nrows) {
+                double t = __builtin_fma(m4e[q], xe, m4r[q] * xr);
+                if (q == 0) t = __builtin_fma(m4c, xc, t);
+                const double pq = wave_sum(t);
+                if (lane == 0) sm[oPS4 + 8 * q + w] = pq;
+            }
+        }
+        __syncthreads();
+        if (tid < nrows) {
+            double sq = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < RES_WAVES; ++ww) sq += sm[oPS4 + 8 * tid + ww];
+            sm[oPS4 + 16 + tid] = __builtin_fma(sm[oPS4 + 20 + tid], sumr4, sq);
+        }
+        __syncthreads();
+    };
     auto visit3 = [&](bool keep) __attribute__((always_inline)) {
         if (POLY3) {
-            ++tseq;
             // e' = M2a r + M1 e and the restricted residual of e' in one pass                 MG_Vcycle.m:20-29
             poly3_rows(5, false);
-            if (tid == 0 && b < Nt)
-                __builtin_amdgcn_raw_buffer_store_b128(res_pack(sm[oR3 + 44], tseq), rtin,
-                                                       (int)(tseq & 1) * (RES_GRAN_MAX * 16) + b * 16, 0,
-                                                       16 /* sc1 */);
-            if (tid < 4) sm[oPUB + tid] = sm[oR3 + 40 + tid];
-            RES_HANDOFF3({ sm[oE3L + j] = v; }, 0, dum0);
-            double hv[1];
-            int st = 0;
-            if (!dead) st = res_wait_slow<1>(rtout, tseq, Nt, D.tmo, nullptr, hv);   // e_4 (Nt <= G <= BT values)
-            if (st) {
-                *fail = 1;
-                if (lane == 0) __hip_atomic_store(D.tmo, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (poly4) {   // r_4 to everybody (ack granules), e_4 := 0; then level 4's own visits      MG_Wcycle.m:28-30
+                if (tid < 4) sm[oPUB + tid] = sm[oR3 + 40 + tid];
+                double s4 = 0.0;
+                RES_HANDOFF3R((b < Nt ? sm[oR3 + 44] : 0.0), { sm[oE3L + j] = v; },
+                              { sm[oR4L + j4] = v; sm[oRR3L + j4] = 0.0; p0 += v; }, (nsp ? 1 : 0), s4);
+                sumr4 = nsp ? s4 : 0.0;
+                for (int leg = 0; leg < (D.wcycle ? 2 : 1); ++leg) {
+                    ++tseq;
+                    poly4_rows(2, false);                              // e_4' (row b) and r_5[b] = P5'(r_4 - A_4 e_4')
+                    if (tid == 0 && b < N5)
+                        __builtin_amdgcn_raw_buffer_store_b128(res_pack(sm[oPS4 + 17], tseq), rtin,
+                                                               (int)(tseq & 1) * (RES_GRAN_MAX * 16) + b * 16, 0,
+                                                               16 /* sc1 */);
+                    if (tid == 0) sm[oPUB] = sm[oPS4 + 16];
+                    RES_HANDOFF4({ sm[oRR3L + j] = v; });
+                    double hv5[1];
+                    int st5 = 0;
+                    if (!dead) st5 = res_wait_slow<1>(rtout, tseq, N5, D.tmo, nullptr, hv5);   // e_5
+                    if (st5) {
+                        *fail = 1;
+                        if (lane == 0) __hip_atomic_store(D.tmo, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (tid < N5) sm[oE5L + tid] = (!dead && !st5) ? hv5[0] : 0.0;
+                    __syncthreads();
+                    if (*fail) dead = true;
+                    poly4_rows(1, true);                               // e_4'' = M2a r + M1 e' + (M1 P5) e_5
+                    if (tid == 0) sm[oPUB] = sm[oPS4 + 16];
+                    RES_HANDOFF4({ sm[oRR3L + j] = v; });
+                }
+            } else {
+                ++tseq;
+                if (tid == 0 && b < Nt)
+                    __builtin_amdgcn_raw_buffer_store_b128(res_pack(sm[oR3 + 44], tseq), rtin,
+                                                           (int)(tseq & 1) * (RES_GRAN_MAX * 16) + b * 16, 0,
+                                                           16 /* sc1 */);
+                if (tid < 4) sm[oPUB + tid] = sm[oR3 + 40 + tid];
+                RES_HANDOFF3({ sm[oE3L + j] = v; }, 0, dum0);
+                double hv[1];
+                int st = 0;
+                if (!dead) st = res_wait_slow<1>(rtout, tseq, Nt, D.tmo, nullptr, hv);   // e_4 (Nt <= G <= BT values)
+                if (st) {
+                    *fail = 1;
+                    if (lane == 0) __hip_atomic_store(D.tmo, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (tid < Nt) sm[oRR3L + tid] = (!dead && !st) ? hv[0] : 0.0;
+                __syncthreads();
+                if (*fail) dead = true;
             }
-            if (tid < Nt) sm[oRR3L + tid] = (!dead && !st) ? hv[0] : 0.0;
-            __syncthreads();
-            if (*fail) dead = true;
             poly3_rows(4, true);                                         // e'' = M2a r + M1 e' + (M1 P4) e_4   :31-41
             if (tid < 4) sm[oPUB + tid] = sm[oR3 + 40 + tid];
             RES_HANDOFF3({ sm[oE3L + j] = v; }, 0, dum0);
@@ -1308,6 +1412,8 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         D.dbg[8] = dbg_acc[7];
     }
 #undef RES_HANDOFF3
+#undef RES_HANDOFF3R
+#undef RES_HANDOFF4
 #undef RES_HANDOFF
 #undef dgF
 #undef dvF

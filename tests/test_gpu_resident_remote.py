@@ -78,11 +78,12 @@ def test_remote_tail_matches_the_multi_launch_path(ipd, newton_system, cycle):
     from codes_of_ipd_ssn_amg_method_amd import _lib
     lev, root = c_int32(), c_int32()
     _lib.check(_lib.lib.ipd_amg_resident_levels(h.handle, byref(lev), byref(root)))
-    assert (lev.value, root.value) in ((2, 3), (3, 4))
+    assert (lev.value, root.value) in ((2, 3), (3, 4), (4, 5))   # (4, 5): level 4 in polynomial form as well (round 4)
     # k = 10: level 3 is far too big for any LDS image, so it must be resident; for the other two the
     # planner's choice depends on a few hundred bytes of LDS budget -- what was measured when the test
     # was written is recorded in `want_levels`, either mode is valid and is checked the same way
-    assert lev.value == want_levels or want_levels != 3 or h.level_dims(3)[1] <= 12 * h.level_dims(3)[0], (
+    lev3_ = min(lev.value, 3)
+    assert lev3_ == want_levels or want_levels != 3 or h.level_dims(3)[1] <= 12 * h.level_dims(3)[0], (
         lev.value, want_levels, h.level_sizes())
     assert root.value == lev.value + 1
     with env(IPD_NO_RESIDENT_REMOTE=1):

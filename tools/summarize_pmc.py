@@ -24,10 +24,12 @@ def main():
     res_cycles = None
     workload = {"n1": 1024, "mask": "bernoulli", "rho": 1.0, "cycle": "v"}
     per_dispatch = collections.defaultdict(dict)
+    for arg in sys.argv[2:]:   # (the dispatch split below needs it whatever the argument order)
+        if arg.startswith("RESIDENT_CYCLES="):
+            res_cycles = [int(v) for v in arg.split("=", 1)[1].split(",")]
     for arg in sys.argv[2:]:
         name, path = arg.split("=", 1)
         if name == "RESIDENT_CYCLES":
-            res_cycles = [int(v) for v in path.split(",")]
             continue
         if name == "WORKLOAD":
             kv = dict(t.split(":", 1) for t in path.split(","))
@@ -37,14 +39,22 @@ def main():
                 workload["newton_k"] = int(kv["newton_k"])
             continue
         agg = collections.defaultdict(list)
+        resident = []   # (dispatch id, kernel, value) of every resident-kernel dispatch, in dispatch order
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == name:
                 agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+                if "k_resident" in r["Kernel_Name"]:
+                    resident.append((int(r.get("Dispatch_Id", len(resident))), r["Kernel_Name"], float(r["Counter_Value"])))
         for k, v in agg.items():
             res[k][name + "_KiB_mean"] = sum(v) / len(v)
             res[k]["dispatches_" + name] = len(v)
-            if "k_resident" in k:
-                per_dispatch[k][name] = v
+        # the bench's warm-up and timed launches are the LAST dispatches of the process (a `--mask newton` line
+        # runs the device driver first: hundreds of resident launches of other instantiations before them)
+        resident.sort()
+        if res_cycles and len(resident) >= len(res_cycles):
+            last = resident[-len(res_cycles):]
+            if len({k for _, k, _ in last}) == 1:
+                per_dispatch[last[0][1]][name] = [v for _, _, v in last]
     for k, d in res.items():
         f = d.get("FETCH_SIZE_KiB_mean")
         w = d.get("WRITE_SIZE_KiB_mean")
