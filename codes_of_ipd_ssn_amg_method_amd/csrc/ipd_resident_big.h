@@ -146,6 +146,7 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         T.sub = D.sub;
         T.tail_root = D.N5 > 0 ? 5 : 4;
         T.Nt = D.N5 > 0 ? D.N5 : D.N4;
+        T.N5 = D.N5;             // (res_tail_workgroup: the inbox of a tail rooted at level 5 has N5 rows)
         T.remote = 1;
         T.three = 1;
         T.wcycle = D.wcycle;
