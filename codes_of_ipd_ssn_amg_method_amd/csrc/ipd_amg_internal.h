@@ -19,6 +19,10 @@ struct AmgOpts {
     // size (:25-38), coarse solve PCG(Ac, rrc, struct('retol',[],'maxit',1e2,'precd',2)) (:72-73)
     bool twogrid = false;
     long long pcg_maxit = 10000;   // MG_Vcycle.m:43 PCG(A,r): PCG.m:20 defaults
+    // AMG4POT's two solves run side by side (Class2/AMG4POT.m:46-47): at most one of them finds the compute units
+    // for a resident kernel of 200+ workgroups, the other runs as launches -- the planner then keeps the LDS
+    // image the launches do best with (rooted at level 4) instead of the one the resident kernel does best with
+    bool concurrent_pair = false;
 };
 AmgOpts amg_fill_twogrid_defaults(const ipd_amg_opts* o);
 AmgOpts amg_fill_defaults(const ipd_amg_opts* o);

@@ -1465,7 +1465,7 @@ void amg_prepare_levels(ipd_amg* h) {
             const int nf1 = h->L[1].nf, nc1 = h->L[1].A.nr - nf1;
             const bool root5 = h->J >= 6 && h->L[1].A.nr > RES_NMAX && nf1 > 0 && nf1 <= RB_HALF && nc1 <= RB_HALF &&
                                h->L[2].A.nr == nc1 && h->L[3].A.nr <= RB_N3MAX && h->L[4].A.nr <= RB_N4MAX &&
-                               h->L[5].A.nr <= RB_N5MAX && h->opts.smoth >= 1 && !h->opts.twogrid &&
+                               h->L[5].A.nr <= RB_N5MAX && h->opts.smoth >= 1 && !h->opts.twogrid && !h->opts.concurrent_pair &&
                                !(std::getenv("IPD_NO_RES_POLY4") && std::getenv("IPD_NO_RES_POLY4")[0] == '1') &&
                                !(std::getenv("IPD_NO_RESIDENT_DEEP") && std::getenv("IPD_NO_RESIDENT_DEEP")[0] == '1') &&
                                !(std::getenv("IPD_NO_RESIDENT_BIG") && std::getenv("IPD_NO_RESIDENT_BIG")[0] == '1') &&

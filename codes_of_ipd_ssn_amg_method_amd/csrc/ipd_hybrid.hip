@@ -864,6 +864,8 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
     // in the reference's order -- and their solve phases then run at the same time on two
     // streams: each is a chain of latency-bound launches that leaves the device mostly idle.
     ipd_ctx* aux = ipd_ctx_aux(ctx);
+    AmgOpts popts = opts;
+    popts.concurrent_pair = true;
     Deferred first, second;
     bool have_first = false;
     const char* nd = getenv("IPD_NO_DONOR");
@@ -877,7 +879,7 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
                 cache.donors = step->prev;
                 cache.shared_count = &step->shared;
             }
-            hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o,
+            hybrid_amg_cached(ctx, H0, tdiag, p, q, m, n, bk1, tk, rhs, popts, rng, x, o,
                               donors ? &cache : nullptr, &first);
             cache.record_donors = false;
             cache.use_donors = donors;
@@ -895,7 +897,7 @@ void amg4pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
         // an injected component order (ipd_ctx_set_component_order) holds for both solves: without the
         // shared component cache (IPD_NO_DONOR=1) the second call finds the components itself
         aux->comp_order = ctx->comp_order;
-        hybrid_amg_cached(aux, H0, tdiag, p, q, m, n, bk1, tk, rhs, opts, rng, x, o,
+        hybrid_amg_cached(aux, H0, tdiag, p, q, m, n, bk1, tk, rhs, popts, rng, x, o,
                           donors ? &cache : nullptr, &second);
         std::exception_ptr err;
         std::thread other([&] {
