@@ -1973,10 +1973,13 @@ bool amg_attach_maskop(ipd_amg* h, const double* p_dev, const double* q_dev, int
                 B.pollsleep = 1;
                 B.presleep = 13;
                 const size_t gbytes = (size_t)RB_GRAN * 16;
-                st->res_block_bytes = 2 * gbytes + 16;
+                B.ranks = 1;   // rank groups with a granule buffer each (test hook, see ResBigDesc::ranks)
+                if (const char* e = std::getenv("IPD_RESIDENT_RANKS")) B.ranks = std::max(1, std::min(8, std::atoi(e)));
+                if (B.ranks > G) B.ranks = 1;
+                st->res_block_bytes = (size_t)B.ranks * 2 * gbytes + 16;
                 st->res_block = reinterpret_cast<unsigned char*>(ar.alloc_bytes(st->res_block_bytes));
                 B.gran = st->res_block;
-                B.tmo = reinterpret_cast<unsigned*>(st->res_block + 2 * gbytes);
+                B.tmo = reinterpret_cast<unsigned*>(st->res_block + (size_t)B.ranks * 2 * gbytes);
                 B.dbg_skip_seq = 0;
                 st->resb_desc = B;
                 st->resb_ke2 = d2.S <= 64 * 16 ? 16 : 32;

@@ -653,6 +653,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
     do {                                                                                           \
         double hv_[NJ];                                                                            \
         ++seq;                                                                                     \
+        /* a give-up of the previous hand-off (its closing barrier has ordered the flag): read here, where the */ \
+        /* LDS round trip hides under the barrier, not behind the closing barrier on the critical path          */ \
+        if (*fail) dead = true;                                                                    \
         if (dbg) dbg_acc[3] -= __builtin_amdgcn_s_memtime();                                       \
         __syncthreads();                                                                           \
         if (dbg) dbg_acc[3] += __builtin_amdgcn_s_memtime();                                       \
@@ -702,7 +705,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
             t0 = res_red8(red);                                                                    \
             if ((want_sums) > 1) t1 = res_red8(red + RES_WAVES);                                   \
         }                                                                                          \
-        if (*fail) dead = true;                                                                 \
     } while (0)
 
     // sum of the LDS vector at `off` over the set bits of `bits` (entry lane + 64 q <-> bit q), n entries
@@ -763,11 +765,15 @@ __global__ __launch_bounds__(BT, 2) void k_resident(const ResDesc D, const doubl
         const int row = frows ? rowF : rowC;
         const bool valid = frows ? vF : vC;
         const int rr_ = valid ? row : 0;
-        if (!(ezero && first)) s = wave_sum(frows ? res_rowdot<KE1, 8 * oE1>(cF, aF, smb) : res_rowdot<KE1, 8 * oE1>(cC, aC, smb));
+        // the row's own scalars first: their LDS round trips overlap the gathers of the row (read after the
+        // wave sum they were one more dependent LDS latency on every half sweep's critical path)
         if (!ezero) eo = sm[oE1 + rr_];
-        s += (frows ? dgF : dgC) * eo;
-        const double g_i = sm[oR1 + rr_] - s - sm[oAX1 + rr_] * c1;
-        const double wv = eo + (frows ? dvF : dvC) * g_i;
+        const double dg_ = frows ? dgF : dgC, dv_ = frows ? dvF : dvC;
+        const double r_own = sm[oR1 + rr_], ax_own = sm[oAX1 + rr_];
+        if (!(ezero && first)) s = wave_sum(frows ? res_rowdot<KE1, 8 * oE1>(cF, aF, smb) : res_rowdot<KE1, 8 * oE1>(cC, aC, smb));
+        s += dg_ * eo;
+        const double g_i = r_own - s - ax_own * c1;
+        const double wv = eo + dv_ * g_i;
         const int blk0 = frows ? 0 : nf, nblk = frows ? nf : nc;
         if (lane == 0) sm[oPUB + w] = wv;
         const int g0 = (frows ? loF : loC) - blk0, cnt = frows ? hiF - loF : hiC - loC;

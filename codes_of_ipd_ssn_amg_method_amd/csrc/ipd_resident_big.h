@@ -68,6 +68,13 @@ struct ResBigDesc {
     unsigned* tmo;
     int presleep, pollsleep;
     unsigned dbg_skip_seq;
+    // Rank groups (IPD_RESIDENT_RANKS=R, three-level mode): the workgroups are split into R
+    // contiguous groups, each with a granule buffer of its OWN (R copies behind one another); a publish writes
+    // the granule into every group's copy and a sweep reads only its own group's.  Nothing else is shared
+    // between workgroups, so this is the data path of a row-block sharded run whose groups sit on R GPUs with
+    // peer-mapped buffers over xGMI (a publish = one write-through store per peer, polls stay local); on one
+    // GPU it is an emulation, bit-identical to ranks = 1 (tests/test_gpu_resident_big.py).
+    int ranks;
     // DEEP: level 3 in polynomial form + remote tail rooted at level 4 (see the header comment)
     int N3, N4;
     ResCsr Pt3, P3d;          // level 2 <-> 3: rows of P3' (N3 x N2) and of P3 (N2 x N3)
@@ -87,14 +94,16 @@ struct ResBigDesc {
     unsigned* tctl;           // [0] != 0: the solve is over, the tail workgroup leaves
 };
 
-__device__ __forceinline__ void rb_publish(__amdgpu_buffer_rsrc_t rs, unsigned seq, int gidx, double v) {
-    __builtin_amdgcn_raw_buffer_store_b128(res_pack(v, seq), rs, (int)(seq & 1) * (RB_GRAN * 16) + gidx * 16, 0,
-                                           16 /* sc1: write-through */);
+__device__ __forceinline__ void rb_publish(__amdgpu_buffer_rsrc_t rs, unsigned seq, int gidx, double v, int ranks = 1) {
+    for (int r = 0; r < ranks; ++r)   // one copy of the buffer per rank group (ResBigDesc::ranks)
+        __builtin_amdgcn_raw_buffer_store_b128(res_pack(v, seq), rs,
+                                               r * (2 * RB_GRAN * 16) + (int)(seq & 1) * (RB_GRAN * 16) + gidx * 16, 0,
+                                               16 /* sc1: write-through */);
 }
 template <int NJ>
 __device__ __forceinline__ bool rb_sweep(__amdgpu_buffer_rsrc_t rs, unsigned seq, int n, bool dead, unsigned* tmo,
-                                         double (&v)[NJ], int pollsleep) {
-    const int base = (int)(seq & 1) * (RB_GRAN * 16);
+                                         double (&v)[NJ], int pollsleep, int group = 0) {
+    const int base = group * (2 * RB_GRAN * 16) + (int)(seq & 1) * (RB_GRAN * 16);
     const int j0 = threadIdx.x;
     unsigned spins = 0;
     bool bad = false;
@@ -377,7 +386,9 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
     const int tid0_ = tid, w0_ = w, lane0_ = lane;                                                 \
     int tid = tid0_, w = w0_, lane = lane0_;                                                       \
     asm volatile("" : "+v"(tid), "+v"(w), "+v"(lane))
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(D.gran, 0, 2 * RB_GRAN * 16, 0x00020000);
+    const int ranks = DEEP ? 1 : (D.ranks > 1 ? D.ranks : 1);
+    const int mygroup = (int)(((long long)b * ranks) / G);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(D.gran, 0, ranks * 2 * RB_GRAN * 16, 0x00020000);
     unsigned seq = 0;
     bool dead = false;
 
@@ -411,16 +422,17 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
         double hv_[NJ];                                                                            \
         RB_FRESH;                                                                                  \
         ++seq;                                                                                     \
+        if (*fail) dead = true;   /* (the previous hand-off's give-up: read under the barrier) */  \
         __syncthreads();                                                                           \
         if (w == 0) {                                                                              \
             const int l8_ = lane & (PUBW - 1);                                                     \
             const bool second_ = lane >= PUBW;                                                     \
             if (lane < 2 * PUBW && l8_ < (second_ ? (cB) : (cA)) &&                                \
                 !(seq == D.dbg_skip_seq && b == G - 1))                                            \
-                rb_publish(rs, seq, (second_ ? (gB) : (gA)) + l8_, sm[oPUB + lane]);               \
+                rb_publish(rs, seq, (second_ ? (gB) : (gA)) + l8_, sm[oPUB + lane], ranks);        \
         }                                                                                          \
         for (int ps_ = 0; ps_ < D.presleep; ++ps_) __builtin_amdgcn_s_sleep(1);                    \
-        if (rb_sweep<NJ>(rs, seq, (n), dead, D.tmo, hv_, D.pollsleep)) {                            \
+        if (rb_sweep<NJ>(rs, seq, (n), dead, D.tmo, hv_, D.pollsleep, mygroup)) {                   \
             *fail = 1;                                                                             \
             if (lane == 0) __hip_atomic_store(D.tmo, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
         }                                                                                          \
@@ -445,7 +457,6 @@ __global__ __launch_bounds__(BT, 2) void k_resident_big(const ResBigDesc D, cons
             t0 = res_red8(sm + oRED);                                                                    \
             if ((want_sums) > 1) t1 = res_red8(sm + oRED + RES_WAVES);                                   \
         }                                                                                          \
-        if (*fail) dead = true;                                                                    \
     } while (0)
     // exchange of K <= 2 partial sums per workgroup: t0 / t1 = their totals (same order everywhere)
 #define RB_PARTIALS(K, v0, v1, t0, t1)                                                             \

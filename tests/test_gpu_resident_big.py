@@ -139,3 +139,46 @@ def test_n2048_runs_in_the_big_kernel(ipd, n2048, cycle):
     assert np.linalg.norm(A @ (x - xs)) <= 1e-9 * nf_
     h.close()
     hc.close()
+
+
+@pytest.mark.parametrize("m,n,cycle", [(1024, 1024, "v"), (700, 900, "w")])
+def test_rank_groups_are_bit_identical(ipd, m, n, cycle):
+    """the mask-form kernel with its workgroups split into R rank groups, each polling a granule
+    buffer of its OWN into which every publish is replicated (ResBigDesc::ranks, IPD_RESIDENT_RANKS=R) -- the
+    data path of a row-block sharded run over peer-mapped xGMI buffers (one write-through store per peer, local
+    polls), emulated on one GPU.  Nothing else is shared between workgroups: the iterates, cycle counts and
+    residual histories equal the ungrouped run's bit for bit."""
+    pd, Ae, f = _system(m, n, 1.0, m != n)
+    guess = pd["bk1"] * pd["tk"] * np.random.RandomState(4).random_sample(m + n)
+    opts = options(cycle, n)
+    ref = None
+    for R in (1, 2, 4, 8):
+        with env(IPD_RESIDENT_BIG=1, IPD_RESIDENT_RANKS=R):
+            h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+            assert h.attach_mask_operator(pd["p"], pd["q"], pd["tk"])
+        assert resident_kernel_name(h).startswith("k_resident_big<") and resident_kernel_name(h).endswith(",1,false>")
+        x, it, rel, relk, rhok = h.solve(f, guess)
+        assert solve_mode(h)[2] == 0
+        a = bench_cycles(h, f, guess, 3)[0]
+        if ref is None:
+            ref = (x, it, np.asarray(relk), a)
+        else:
+            assert it == ref[1] and np.array_equal(x, ref[0]) and np.array_equal(np.asarray(relk), ref[2]), R
+            assert np.array_equal(a, ref[3]), R
+        h.close()
+
+
+def test_rank_groups_at_config4_size(ipd, n2048):
+    """The same at m = n = 2048 (BASELINE config 4's size, 256 workgroups): eight rank groups of 32 workgroups --
+    the partition north_star names -- against the ungrouped launch, bit for bit."""
+    m, n, Ae, f, guess, ho = n2048
+    opts = options("v", n)
+    out = []
+    for R in (1, 8):
+        with env(IPD_RESIDENT_RANKS=R):
+            h = ipd.AMGHierarchy(Ae, opts, ipd.MatlabRand())
+            assert h.attach_mask_operator(np.ones(m), np.ones(n), bench.TK)
+        assert solve_mode(h)[:2] == (2, 256)
+        out.append(bench_cycles(h, f, guess, 3)[0])
+        h.close()
+    assert np.array_equal(out[0], out[1])
