@@ -146,6 +146,9 @@ struct ipd_ctx {
     unsigned mailbox_ticket = 0;
     int num_cu = 256;
     long long asat_nnz_hint = 0;   // entries of the last ASAt result (sizes the next one's arrays)
+    // entries of P, Pt*A and Ac of the last hierarchy's level k (amg_transfer's lazy counts: the kernel-choice
+    // heuristics of the next hierarchy's products run on these estimates; 0 = none yet)
+    int xfer_hint[40][3] = {};
     void* asat_agg = nullptr;      // k_asat_small's chained-scan words (ipd_kkt.hip)
     // injected visiting order of the connected components (ipd_ctx_set_component_order): the
     // smallest member of the component to visit k-th; empty = by smallest member ascending
@@ -242,7 +245,8 @@ void csr_upload_from_csc(ipd_ctx* ctx, Arena& a, const ipd_csc* A, bool symmetri
 void csr_download_as_csc(ipd_ctx* ctx, const Csr& m, bool already_transposed, ipd_csc_out* out);
 void csr_transpose(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* At);  // deterministic
 void csr_spmv(ipd_ctx* ctx, const Csr& A, const double* x, double* y);
-void exclusive_scan_i32(ipd_ctx* ctx, const int* in, int* out, int n);  // out has n+1 entries
+void exclusive_scan_i32(ipd_ctx* ctx, const int* in, int* out, int n,   // out has n+1 entries
+                        int* total_dev = nullptr);                       // ... the total also goes there (device)
 int exclusive_scan_total(ipd_ctx* ctx, const int* in, int* out, int n);
 void exclusive_scan_total2(ipd_ctx* ctx, const int* in1, int* out1, const int* in2, int* out2, int n,
                            int* total1, int* total2);  // same, returns out[n]
@@ -250,7 +254,11 @@ void fill_i32(ipd_ctx* ctx, int* p, int v, size_t n);
 void fill_f64(ipd_ctx* ctx, double* p, double v, size_t n);
 void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n);
 // C = X*Y with MATLAB ordering (ascending inner index, no FMA, exact zeros dropped)
-void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C);
+// total_dev != NULL ("lazy count"): no host round trip -- C's arrays are sized by the dense bound nr*nc (the
+// caller has checked SPGEMM_LAZY_MAX), C->nnz is that bound until the caller has fetched *total_dev; the nnz of
+// X and Y are then only read by the kernel-choice heuristic (estimates will do: both kernels give the same bits)
+constexpr size_t SPGEMM_LAZY_MAX = size_t(1) << 21;
+void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, int* total_dev = nullptr);
 void csr_expand_dense(ipd_ctx* ctx, const Csr& A, double* dense, int ld);  // dense pre-zeroed
 void dense_rowcount(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, int* rowcnt);
 void dense_compact(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, const Csr& out);

@@ -1045,6 +1045,8 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
     const int N = A.nr;
     Csr P;
     P.nr = N;
+    bool lazy = false;        // the interpolation's entry count stays on the device (see "lazy counts" below)
+    int* counts = nullptr;    // device: entries of P, P'A, Ac
     if (level == 1 && o.bigph) {                                             // transfer.m:19-25
         const int nf = (int)o.fnode;
         IPD_REQUIRE(nf > 0 && nf < N, IPD_E_ARG, "transfer: fnode must satisfy 0 < fnode < N");
@@ -1056,9 +1058,16 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
                            A.rp, A.ci, rowlen, bad);
         IPD_KERNEL_CHECK();
         P.rp = dst.alloc<int>((size_t)N + 1);
-        P.nnz = exclusive_scan_total(ctx, rowlen, P.rp, N);
-        IPD_REQUIRE(ctx->fetch1(bad) == 0, IPD_E_UNSUPPORTED,
-                    "transfer: bigph level 1 needs a diagonal Aff block (transfer.m:20-21)");
+        {   // entry count and the "Aff is not diagonal" flag in ONE round trip (they sit side by side)
+            int* two = tmp.alloc<int>(2);
+            exclusive_scan_i32(ctx, rowlen, P.rp, N, two);
+            IPD_HIP(hipMemcpyAsync(two + 1, bad, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+            int h2[2] = {0, 0};
+            ctx->fetch(two, h2, 2);
+            P.nnz = h2[0];
+            IPD_REQUIRE(h2[1] == 0, IPD_E_UNSUPPORTED,
+                        "transfer: bigph level 1 needs a diagonal Aff block (transfer.m:20-21)");
+        }
         P.ci = dst.alloc<int>((size_t)P.nnz);
         P.va = dst.alloc<double>((size_t)P.nnz);
         hipLaunchKernelGGL(k_bigph_fill, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, nf,
@@ -1093,6 +1102,12 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         IPD_REQUIRE((size_t)Nc * 16 <= 128 * 1024, IPD_E_LIMIT,
                     "transfer: more than 8192 coarse nodes on a non-bigraph level");
         P.nc = Nc;
+        // lazy counts (see below): the previous hierarchy left estimates for this level and the dense bounds
+        // of P, P'A and Ac are small
+        lazy = level >= 1 && level < 40 && ctx->xfer_hint[level][0] > 0 && ctx->xfer_hint[level][1] > 0 &&
+               ctx->xfer_hint[level][2] > 0 && (size_t)N * (size_t)Nc <= SPGEMM_LAZY_MAX &&
+               (size_t)Nc * (size_t)Nc <= SPGEMM_LAZY_MAX;
+        if (lazy) counts = tmp.alloc<int>(3);
         if (!small_done) {
             hipLaunchKernelGGL(k_rowmax, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp, A.ci,
                                A.va, maxrow, diag);
@@ -1170,9 +1185,14 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
             IPD_KERNEL_CHECK();
         }
         P.rp = dst.alloc<int>((size_t)N + 1);
-        P.nnz = exclusive_scan_total(ctx, rowcnt, P.rp, N);
-        P.ci = dst.alloc<int>((size_t)P.nnz);
-        P.va = dst.alloc<double>((size_t)P.nnz);
+        if (lazy) {   // dense bound, no round trip: the count is fetched with the products' below
+            exclusive_scan_i32(ctx, rowcnt, P.rp, N, counts);
+            P.nnz = (int)((size_t)N * (size_t)Nc);
+        } else {
+            P.nnz = exclusive_scan_total(ctx, rowcnt, P.rp, N);
+        }
+        P.ci = dst.alloc<int>((size_t)std::max(P.nnz, 1));
+        P.va = dst.alloc<double>((size_t)std::max(P.nnz, 1));
         hipLaunchKernelGGL(k_dense_compact2, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, Nc,
                            dense, P.rp, P.ci, P.va);
         IPD_KERNEL_CHECK();
@@ -1185,8 +1205,41 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
     // Ac = Pro'*A*Pro, evaluated left to right                               transfer.m:66
     Csr Pt, T1, C;
     csr_transpose(ctx, dst, P, &Pt);
-    csr_spgemm(ctx, T1out ? dst : tmp, Pt, A, &T1);
-    csr_spgemm(ctx, dst, T1, P, &C);
+    const int Ncc = P.nc;
+    // Lazy counts (round 4): where the dense bounds are small the entry counts of P'A and Ac (and of P, above)
+    // stay on the device until all three are fetched in ONE round trip at the end -- four host round trips per
+    // level became two.  The products' kernel choice meanwhile runs on the previous hierarchy's counts of the
+    // same level (ipd_ctx::xfer_hint; both kernels give the same bits, tests/test_gpu_product.py).
+    int* const hint = (level >= 1 && level < 40) ? ctx->xfer_hint[level] : nullptr;
+    const bool lazy_prod = hint && hint[1] > 0 && hint[2] > 0 && (lazy || P.nnz >= 0) &&
+                           (size_t)Ncc * (size_t)N <= SPGEMM_LAZY_MAX && (size_t)Ncc * (size_t)Ncc <= SPGEMM_LAZY_MAX;
+    if (lazy_prod) {
+        int* c3 = lazy ? counts : tmp.alloc<int>(3);
+        Csr Pe = P, Pte = Pt;
+        if (lazy) Pe.nnz = Pte.nnz = std::max(1, std::min(hint[0], P.nnz));   // (estimates for the heuristic only)
+        csr_spgemm(ctx, T1out ? dst : tmp, Pte, A, &T1, c3 + 1);
+        Csr T1e = T1;
+        T1e.nnz = std::max(1, std::min(hint[1], T1.nnz));
+        csr_spgemm(ctx, dst, T1e, Pe, &C, c3 + 2);
+        int h3[3] = {0, 0, 0};
+        if (lazy) {
+            ctx->fetch(c3, h3, 3);
+            P.nnz = Pt.nnz = h3[0];
+        } else {
+            ctx->fetch(c3 + 1, h3 + 1, 2);
+        }
+        T1.nnz = h3[1];
+        C.nnz = h3[2];
+    } else {
+        IPD_REQUIRE(!lazy, IPD_E_NUMERIC, "transfer: lazy interpolation count without lazy products");
+        csr_spgemm(ctx, T1out ? dst : tmp, Pt, A, &T1);
+        csr_spgemm(ctx, dst, T1, P, &C);
+    }
+    if (hint) {
+        hint[0] = P.nnz;
+        hint[1] = T1.nnz;
+        hint[2] = C.nnz;
+    }
     if (T1out) *T1out = T1;
     *Ac = C;
     *Pout = P;

@@ -66,9 +66,10 @@ __device__ __forceinline__ int exscan_block(const int* __restrict__ in, int* out
     return carry;
 }
 __global__ __launch_bounds__(1024) void k_exscan(const int* __restrict__ in, int* out, int n,
-                                                 volatile unsigned* box, unsigned ticket) {
+                                                 volatile unsigned* box, unsigned ticket, int* extra) {
     __shared__ int wsum[16];
     const int carry = exscan_block(in, out, n, wsum);
+    if (threadIdx.x == 0 && extra) *extra = carry;
     if (threadIdx.x == 0 && box) {   // post the total to the host mailbox (ipd_ctx::mailbox_wait)
         box[16] = (unsigned)carry;
         __threadfence_system();
@@ -90,9 +91,9 @@ __global__ __launch_bounds__(1024) void k_exscan2(const int* __restrict__ in1, i
     }
 }
 
-void exclusive_scan_i32(ipd_ctx* ctx, const int* in, int* out, int n) {
+void exclusive_scan_i32(ipd_ctx* ctx, const int* in, int* out, int n, int* total_dev) {
     hipLaunchKernelGGL(k_exscan, dim3(1), dim3(1024), 0, ctx->stream, in, out, n,
-                       (volatile unsigned*)nullptr, 0u);
+                       (volatile unsigned*)nullptr, 0u, total_dev);
     IPD_KERNEL_CHECK();
 }
 
@@ -104,7 +105,7 @@ int exclusive_scan_total(ipd_ctx* ctx, const int* in, int* out, int n) {
         return ctx->fetch1(out + n);
     }
     hipLaunchKernelGGL(k_exscan, dim3(1), dim3(1024), 0, ctx->stream, in, out, n, ctx->mailbox,
-                       ticket);
+                       ticket, (int*)nullptr);
     IPD_KERNEL_CHECK();
     int total = 0;
     ctx->mailbox_wait(ticket, &total, sizeof(int));
@@ -745,7 +746,7 @@ static bool spgemm_prefers_tiles(const Csr& X, const Csr& Y, size_t* bytes) {
     return t_tiles < t_rows;
 }
 
-void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
+void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, int* total_dev) {
     IPD_REQUIRE(X.nc == Y.nr, IPD_E_ARG, "spgemm: inner dimensions differ");
     const int nr = X.nr, nc = Y.nc;
     Arena& tmp = *ctx->scratch;
@@ -798,7 +799,12 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C) {
             IPD_KERNEL_CHECK();
         }
     }
-    out.nnz = exclusive_scan_total(ctx, rowcnt, out.rp, nr);
+    if (total_dev) {   // lazy count: dense bound, no round trip
+        exclusive_scan_i32(ctx, rowcnt, out.rp, nr, total_dev);
+        out.nnz = (int)((size_t)nr * (size_t)nc);
+    } else {
+        out.nnz = exclusive_scan_total(ctx, rowcnt, out.rp, nr);
+    }
     out.ci = dst.alloc<int>((size_t)out.nnz);
     out.va = dst.alloc<double>((size_t)out.nnz);
     if (out.nnz) {
