@@ -271,6 +271,33 @@ extern "C" int ipd_ctx_create(int device, ipd_ctx** out) {
     });
 }
 
+// zero pool (ipd_internal.h): created on first use, 64 MiB
+void* ipd_ctx::zalloc(size_t bytes) {
+    constexpr size_t POOL = size_t(64) << 20;
+    if (bytes > POOL / 2) return nullptr;
+    if (!zpool) {
+        void* p = nullptr;
+        if (hipMalloc(&p, POOL) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        IPD_HIP(hipMemsetAsync(p, 0, POOL, stream));
+        zpool = static_cast<char*>(p);
+        zpool_bytes = POOL;
+        zpool_used = 0;
+    }
+    const size_t need = (bytes + 255) & ~size_t(255);
+    if (zpool_used + need > zpool_bytes) return nullptr;
+    void* r = zpool + zpool_used;
+    zpool_used += need;
+    return r;
+}
+
+void ipd_ctx::zreset() {
+    if (zpool && zpool_used) IPD_HIP(hipMemsetAsync(zpool, 0, zpool_used, stream));
+    zpool_used = 0;
+}
+
 // lazily created companion context (same device, own stream/arenas/pinned buffer)
 ipd_ctx* ipd_ctx_aux(ipd_ctx* ctx) {
     if (!ctx->aux) {
@@ -296,6 +323,7 @@ extern "C" void ipd_ctx_destroy(ipd_ctx* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
     if (ctx->asat_agg) (void)hipFree(ctx->asat_agg);
+    if (ctx->zpool) (void)hipFree(ctx->zpool);
     if (ctx->mailbox) (void)hipHostFree(const_cast<unsigned*>(ctx->mailbox));
     for (hipEvent_t& ev : ctx->tev)
         if (ev) (void)hipEventDestroy(ev);

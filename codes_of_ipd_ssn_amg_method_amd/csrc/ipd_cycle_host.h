@@ -282,8 +282,7 @@ static BPolyDev pack_bpoly(ipd_ctx* ctx, ipd_amg* h, CycleState* st, int k, int 
     e.LD = LD;
     // one zeroed block of scratch: A, S, P, T1, Pw[0], Pw[1], Y, dv, u, cs
     const size_t sc = 4 * Np * Np + 2 * Np * Ncp + Np * xcols + 3 * Np;
-    double* blk = ctx->scratch->alloc<double>(sc);
-    IPD_HIP(hipMemsetAsync(blk, 0, sc * sizeof(double), ctx->stream));
+    double* blk = zeroed<double>(ctx, sc);
     e.A = blk;
     e.S = e.A + Np * Np;
     e.P = e.S + Np * Np;
@@ -534,8 +533,7 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     // bigraph transfers P = [W; I]: the kernel adds the identity entries instead of walking them
     D.wident = 0;
     if (N2 == nc) {
-        int* bad = h->ctx->scratch->alloc<int>(1);
-        IPD_HIP(hipMemsetAsync(bad, 0, sizeof(int), h->ctx->stream));
+        int* bad = zeroed<int>(h->ctx, 1);
         hipLaunchKernelGGL(k_res_check_ident, dim3(cdiv(N2, 256)), dim3(256), 0, h->ctx->stream, nf, N2,
                            csr(l2.P), csr(l2.Pt), bad);
         IPD_KERNEL_CHECK();
@@ -767,8 +765,7 @@ void amg_prepare_levels(ipd_amg* h) {
     const int cu = ctx->num_cu;
     // first pass: per-level vectors and the longest off-diagonal row of every level (one
     // readback for all levels), second pass: padded copies and launch geometry
-    int* maxoff = ctx->scratch->alloc<int>((size_t)h->J + 1);
-    IPD_HIP(hipMemsetAsync(maxoff, 0, sizeof(int) * ((size_t)h->J + 1), ctx->stream));
+    int* maxoff = zeroed<int>(ctx, (size_t)h->J + 1);
     // levels whose constant data come from the donor hierarchy (see ipd_amg::donor)
     const ipd_amg* donor = h->donor.get();
     const CycleState* dst_ = donor ? donor->cyc.get() : nullptr;

@@ -35,10 +35,12 @@ __device__ __forceinline__ double qp_of(const double* __restrict__ p, const doub
     return i < n ? q[i] : -p[i - n];  // qp = [q; -p]
 }
 
-// row lengths of Ae: the pattern of H0 plus a full diagonal
-__global__ __launch_bounds__(256) void k_ae_count(int M, const int* __restrict__ rp,
-                                                  const int* __restrict__ ci,
-                                                  int* __restrict__ rowlen) {
+// row lengths of Ae: the pattern of H0 plus a full diagonal; flags a zero in p or q (Hybrid_AMG.m:18-19); the last
+// workgroup scans the lengths into Ae's row pointers and posts total and flag to the host
+__global__ __launch_bounds__(256) void k_ae_count(int M, int n, const int* __restrict__ rp,
+                                                  const int* __restrict__ ci, const double* __restrict__ p,
+                                                  const double* __restrict__ q, int* rowlen,
+                                                  const ScanTail st) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -46,8 +48,10 @@ __global__ __launch_bounds__(256) void k_ae_count(int M, const int* __restrict__
         bool has = false;
         for (int t = rp[i] + lane; t < rp[i + 1]; t += 64) has |= (ci[t] == i);
         const bool hasd = __any(has);
-        if (lane == 0) rowlen[i] = rp[i + 1] - rp[i] + (hasd ? 0 : 1);
+        if (lane == 0)
+            scan_put(rowlen, i, rp[i + 1] - rp[i] + (hasd ? 0 : 1), (i < n ? q[i] : p[i - n]) == 0.0);
     }
+    scan_tail(st);
 }
 
 __global__ __launch_bounds__(256) void k_ae_fill(int M, int n, const int* __restrict__ rp,
@@ -113,31 +117,23 @@ __global__ void k_dk(int M, int n, const double* __restrict__ p, const double* _
         dK[i] = tdiag ? (qi * tdiag[i]) * qi : 0.0;
     }
 }
-__global__ void k_has_zero(int m, int n, const double* __restrict__ p, const double* __restrict__ q,
-                           int* __restrict__ flag) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m + n; i += gridDim.x * blockDim.x) {
-        const double v = i < n ? q[i] : p[i - n];
-        if (v == 0.0) *flag = 1;
-    }
-}
-
 static void build_Ae(ipd_ctx* ctx, Arena& dst, const Csr& H0, const double* tdiag, const double* p,
                      const double* q, int m, int n, double bk1, double tk, Csr* Ae) {
     const int M = m + n;
     IPD_REQUIRE(H0.nr == M && H0.nc == M, IPD_E_ARG, "Hybrid_AMG: H0 must be (n+m) x (n+m)");
     Arena& tmp = *ctx->scratch;
-    int* flag = tmp.alloc<int>(1);
-    IPD_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_has_zero, dim3(elems_grid(M)), dim3(256), 0, ctx->stream, m, n, p, q, flag);
-    int* rowlen = tmp.alloc<int>((size_t)M + 1);
-    hipLaunchKernelGGL(k_ae_count, dim3(rows_grid(M)), dim3(256), 0, ctx->stream, M, H0.rp, H0.ci,
-                       rowlen);
-    IPD_KERNEL_CHECK();
+    int* rowlen = zeroed<int>(ctx, (size_t)M + 1);   // (biased counts: see ScanTail)
     Csr a;
     a.nr = a.nc = M;
     a.rp = dst.alloc<int>((size_t)M + 1);
-    a.nnz = exclusive_scan_total(ctx, rowlen, a.rp, M);
-    IPD_REQUIRE(ctx->fetch1(flag) == 0, IPD_E_ARG, "p or q contains 0 !!!!!");  // Hybrid_AMG.m:18-19
+    TailTotal tt(ctx, rowlen, a.rp, M);   // entry count and the "p or q has a zero" flag in one message
+    hipLaunchKernelGGL(k_ae_count, dim3(rows_grid(M)), dim3(256), 0, ctx->stream, M, n, H0.rp, H0.ci, p, q,
+                       rowlen, tt.t);
+    IPD_KERNEL_CHECK();
+    int h2[2] = {0, 0};
+    tt.wait(h2);
+    a.nnz = h2[0];
+    IPD_REQUIRE(h2[1] == 0, IPD_E_ARG, "p or q contains 0 !!!!!");  // Hybrid_AMG.m:18-19
     a.ci = dst.alloc<int>((size_t)a.nnz);
     a.va = dst.alloc<double>((size_t)a.nnz);
     const double inv_tk = 1.0 / tk;
@@ -1191,10 +1187,15 @@ void pcg_pot_dev(ipd_ctx* ctx, const Csr& H0, const double* tdiag, const double*
     double* D = pot_jacobian_dense(ctx, H0, tdiag, p, q, m, n, bk1, tk, s, phi);
     Csr J;
     J.nr = J.nc = N;
-    int* cnt = tmp.alloc<int>((size_t)N + 1);
-    dense_rowcount(ctx, N, N, N, D, cnt);
+    int* cnt = zeroed<int>(ctx, (size_t)N + 1);   // (biased counts: see ScanTail)
     J.rp = tmp.alloc<int>((size_t)N + 1);
-    J.nnz = exclusive_scan_total(ctx, cnt, J.rp, N);
+    {
+        TailTotal tt(ctx, cnt, J.rp, N);
+        dense_rowcount(ctx, N, N, N, D, cnt, tt.t);
+        int two[2] = {0, 0};
+        tt.wait(two);
+        J.nnz = two[0];
+    }
     J.ci = tmp.alloc<int>((size_t)J.nnz);
     J.va = tmp.alloc<double>((size_t)J.nnz);
     dense_compact(ctx, N, N, N, D, J);

@@ -150,6 +150,15 @@ struct ipd_ctx {
     // heuristics of the next hierarchy's products run on these estimates; 0 = none yet)
     int xfer_hint[40][3] = {};
     void* asat_agg = nullptr;      // k_asat_small's chained-scan words (ipd_kkt.hip)
+    // Zero pool: temporaries that must start out as zeros (transpose bitmaps, dense operand blocks, flags) are
+    // bumped out of one block that a single memset clears again at the start of the next hierarchy build --
+    // one fill per setup where there were fourteen.  zalloc'd memory dies when the function that took it returns
+    // (amg_setup calls zreset; nothing that holds such memory may call amg_setup).
+    char* zpool = nullptr;
+    size_t zpool_bytes = 0, zpool_used = 0;
+    int scope_depth = 0;           // CallScope nesting (the outermost scope also resets the zero pool)
+    void* zalloc(size_t bytes);    // nullptr when the pool has no room (callers fall back to alloc + memset)
+    void zreset();
     // injected visiting order of the connected components (ipd_ctx_set_component_order): the
     // smallest member of the component to visit k-th; empty = by smallest member ascending
     std::vector<int> comp_order;
@@ -198,10 +207,12 @@ struct CallScope {
     size_t cur, off;
     explicit CallScope(ipd_ctx* c) : ctx(c), cur(c->scratch->cur), off(c->scratch->off) {
         c->set_device();
+        if (c->scope_depth++ == 0 && c->zpool_used > (c->zpool_bytes >> 1)) c->zreset();
     }
     ~CallScope() {
         ctx->scratch->cur = cur;
         ctx->scratch->off = off;
+        --ctx->scope_depth;
     }
 };
 
@@ -228,6 +239,258 @@ struct ProfScope {
 };
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// scratch temporaries that start out as zeros: out of the zero pool when it has room
+template <class T>
+static inline T* zeroed(ipd_ctx* ctx, size_t n) {
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    if (void* p = ctx->zalloc(bytes)) return static_cast<T*>(p);
+    T* q = ctx->scratch->alloc<T>(n);
+    IPD_HIP(hipMemsetAsync(q, 0, bytes, ctx->stream));
+    return q;
+}
+
+// ---------------------------------------------------------------------------
+// scans that ride on the launch that produces the counts
+// ---------------------------------------------------------------------------
+// A launch that produces per-row counts is followed by an exclusive scan of them (the row pointers of the
+// matrix being built).  Instead of a second launch, the workgroup with the highest index does the scan at the
+// end of the producer: the counts array starts out as zeros (zero pool), every producer stores count + 1 with
+// an agent-scope store (scan_put: written through, visible across the XCDs' L2s without a fence), and the
+// scanning workgroup polls the entries until none is zero.  It is the last workgroup to be dispatched, so every
+// entry it waits for belongs to a workgroup that is running or done; a bounded spin turns a missing entry into
+// a negative total (the host raises) instead of a hang.  Bit 30 of an entry is a flag the producer may set
+// (scan_put's third argument); the OR of the flags travels beside the total.
+struct ScanTail {
+    const int* in = nullptr;     // n biased counts (zeros before the launch)
+    int* out = nullptr;          // n+1 row pointers (nullptr: no tail)
+    const int* in2 = nullptr;    // optionally a second array of the same length
+    int* out2 = nullptr;
+    int n = 0;
+    int* extra = nullptr;        // device copy of the total (lazy counts), or nullptr
+    int extra2 = 0;              // ... extra[1] receives the second total / the OR of the flags as well
+    volatile unsigned* box = nullptr;   // host mailbox (ipd_ctx::mailbox_wait): total, second total / flags
+    unsigned ticket = 0;
+};
+
+// Host side of a tail whose total the host waits for: through the mailbox when it is on, else through a device
+// word and a fetch.
+struct TailTotal {
+    ipd_ctx* ctx;
+    ScanTail t;
+    unsigned ticket = 0;
+    bool mail = false;
+    int* dev = nullptr;
+    TailTotal(ipd_ctx* c, const int* in, int* out, int n) : ctx(c) {
+        t.in = in;
+        t.out = out;
+        t.n = n;
+        mail = c->mailbox_begin(&ticket);
+        if (mail) {
+            t.box = c->mailbox;
+            t.ticket = ticket;
+        } else {
+            dev = c->scratch->alloc<int>(2);
+            t.extra = dev;
+            t.extra2 = 1;
+        }
+    }
+    void wait(int* two) {   // two[0] = total, two[1] = second total or the OR of the flags (0 / 1)
+        if (mail)
+            ctx->mailbox_wait(ticket, two, 2 * sizeof(int));
+        else
+            ctx->fetch(dev, two, 2);
+        IPD_REQUIRE(two[0] >= 0 && two[1] >= 0, IPD_E_HIP, "row-pointer scan: a count never arrived");
+    }
+};
+static inline ScanTail scan_tail_lazy(const int* in, int* out, int n, int* total_dev) {
+    ScanTail t;
+    t.in = in;
+    t.out = out;
+    t.n = n;
+    t.extra = total_dev;
+    return t;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void scan_put(int* cnt, int i, int count, bool flag = false) {
+    __hip_atomic_store(cnt + i, (count + 1) | (flag ? (1 << 30) : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Exclusive scan of n plain ints by the calling workgroup (any multiple of 64 threads up to 1024): a contiguous
+// chunk per thread, the chunk sums scanned across the workgroup.  Returns the total, also stored at out[n].
+__device__ __forceinline__ int ipd_scan_counts(const int* in, int* out, int n, int* wsum) {
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, w = tid >> 6, nwv = T >> 6;
+    const int chunk = (n + T - 1) / T;
+    const int b = min(n, tid * chunk), e = min(n, b + chunk);
+    int s = 0;
+    for (int i = b; i < e; ++i) s += in[i];
+    int x = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int k = 0; k < nwv; ++k) {
+        const int t = wsum[k];
+        if (k < w) woff += t;
+        total += t;
+    }
+    int run = woff + x - s;
+    for (int i = b; i < e; ++i) {
+        const int v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (tid == 0) out[n] = total;
+    return total;
+}
+
+constexpr int SCAN_TAIL_C = 8;   // entries per thread and pass of the scanning workgroup
+struct ScanTailLds {
+    int wsum[SCAN_TAIL_C * 16];   // (entries per thread) x (waves)
+};
+
+// polls, decodes and scans one array; returns the total (negative: an entry never arrived), ORs the flags.
+// Entry j*T + tid of a pass sits in register j of thread tid: loads and stores are coalesced, the scan runs
+// over the waves' inclusive scans of each register row.
+__device__ __forceinline__ int scan_tail_one(const int* in, int* out, int n, ScanTailLds& L, int* flags_out) {
+    constexpr int C = SCAN_TAIL_C;
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, w = tid >> 6, nwv = T >> 6;
+    int carry = 0, flags = 0;
+    bool dead = false;
+    for (int base = 0; base < n; base += C * T) {
+        int v[C];
+        unsigned spins = 0;
+        bool ok;
+        do {   // agent-scope loads, all in flight together; again until no entry is zero
+            ok = true;
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const int idx = base + j * T + tid;
+                v[j] = idx < n ? __hip_atomic_load(in + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
+            }
+#pragma unroll
+            for (int j = 0; j < C; ++j) ok &= v[j] != 0;
+            if (!ok) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 20)) {
+                    dead = true;
+                    ok = true;
+                }
+            }
+        } while (!ok);
+        int x[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            flags |= v[j] & (1 << 30);
+            v[j] = (v[j] & 0x3fffffff) - 1;
+            int t = v[j];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(t, d);
+                if (lane >= d) t += y;
+            }
+            x[j] = t;
+            if (lane == 63) L.wsum[j * nwv + w] = t;
+        }
+        __syncthreads();
+        int run = carry;   // sum of the (row, wave) blocks before the one being written
+#pragma unroll
+        for (int j = 0; j < C; ++j)
+            for (int k = 0; k < nwv; ++k) {
+                const int t = L.wsum[j * nwv + k];
+                if (k == w) {
+                    const int idx = base + j * T + tid;
+                    if (idx < n) out[idx] = run + x[j] - v[j];
+                }
+                run += t;
+            }
+        carry = run;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+    if (__syncthreads_or(flags != 0)) *flags_out = 1;
+    return __syncthreads_or(dead) ? -1 : carry;
+}
+
+// Called by EVERY thread of EVERY workgroup at the very end of the producer kernel (it holds barriers).
+// Workgroups of 256 threads and more (a pass covers 8 entries per thread).
+__device__ __forceinline__ void scan_tail(const ScanTail& s) {
+    if (!s.out) return;
+    if (blockIdx.x != gridDim.x - 1 || blockIdx.y != gridDim.y - 1) return;
+    __shared__ ScanTailLds L;
+    int flags = 0;
+    const int t1 = scan_tail_one(s.in, s.out, s.n, L, &flags);
+    const int t2 = s.in2 ? scan_tail_one(s.in2, s.out2, s.n, L, &flags) : flags;
+    if (threadIdx.x == 0) {
+        if (s.extra) {
+            s.extra[0] = t1;
+            if (s.extra2) s.extra[1] = t2;
+        }
+        if (s.box) {
+            s.box[16] = (unsigned)t1;
+            s.box[17] = (unsigned)t2;
+            __threadfence_system();
+            s.box[0] = s.ticket;
+        }
+    }
+}
+
+// The other way round, for producers with one-wave workgroups: the CONSUMER's workgroups each scan the (plain)
+// counts for themselves -- n <= SCAN_HEAD_MAX ints out of L2, a microsecond -- and workgroup 0 also stores the
+// row pointers and the total for whoever comes later.  256 threads.
+constexpr int SCAN_HEAD_MAX = 4096;
+struct ScanHeadLds {
+    int rp[SCAN_HEAD_MAX + 1];
+    int wsum[4];
+};
+__device__ __forceinline__ void scan_head(const int* __restrict__ cnt, int n, int* rp_out, int* total_out,
+                                          ScanHeadLds& L) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int C = (n + 255) >> 8;   // a contiguous chunk per thread, at most 16 entries
+    int v[SCAN_HEAD_MAX / 256];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_HEAD_MAX / 256; ++j) {
+        const int idx = tid * C + j;
+        v[j] = (j < C && idx < n) ? cnt[idx] : 0;
+        s += v[j];
+    }
+    int x = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) L.wsum[w] = x;
+    __syncthreads();
+    int woff = 0, carry = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = L.wsum[k];
+        if (k < w) woff += t;
+        carry += t;
+    }
+    int run = woff + x - s;
+#pragma unroll
+    for (int j = 0; j < SCAN_HEAD_MAX / 256; ++j) {
+        const int idx = tid * C + j;
+        if (j < C && idx < n) L.rp[idx] = run;
+        run += v[j];
+    }
+    if (tid == 0) L.rp[n] = carry;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int i = tid; i <= n; i += 256) rp_out[i] = L.rp[i];
+        if (tid == 0 && total_out) *total_out = carry;
+    }
+}
+#endif
 
 // Opt-in to more than 64 KiB of dynamic LDS.  The attribute is per DEVICE (a process may hold
 // contexts on several), so it is remembered per (kernel, device) pair, under a lock (contexts
@@ -260,7 +523,8 @@ void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n);
 constexpr size_t SPGEMM_LAZY_MAX = size_t(1) << 21;
 void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, int* total_dev = nullptr);
 void csr_expand_dense(ipd_ctx* ctx, const Csr& A, double* dense, int ld);  // dense pre-zeroed
-void dense_rowcount(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, int* rowcnt);
+// rowcnt: zeroed<int>; the launch's tail scans the (biased) counts into st.out -- nr > 0
+void dense_rowcount(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, int* rowcnt, const ScanTail& st);
 void dense_compact(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, const Csr& out);
 void csr_copy(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out);
 void csr_drop_zeros(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out);  // ipd_kkt.hip

@@ -714,26 +714,28 @@ static void amg_cf_split(ipd_ctx* ctx, const Csr& S, uint8_t* isC, uint8_t* isF)
 // (transfer.m:20-25); one lane per row, sequential, so the row sum used by the
 // isnsp normalisation (:22-24) is accumulated in ascending column order.
 __global__ __launch_bounds__(256) void k_bigph_count(int N, int nf, const int* __restrict__ rp,
-                                                     const int* __restrict__ ci,
-                                                     int* __restrict__ rowlen,
-                                                     int* __restrict__ bad) {
+                                                     const int* __restrict__ ci, int* rowlen,
+                                                     const ScanTail st) {
     WAVE_ROWS(i, N) {
         if (i >= nf) {
-            if (lane == 0) rowlen[i] = 1;
+            if (lane == 0) scan_put(rowlen, i, 1);
             continue;
         }
         int c = 0;
+        bool bad = false;   // Aff is not diagonal
         for (int t = rp[i] + lane; t < rp[i + 1]; t += 64) {
             const int j = ci[t];
             if (j >= nf)
                 ++c;
             else if (j != i)
-                *bad = 1;  // Aff is not diagonal
+                bad = true;
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
-        if (lane == 0) rowlen[i] = c;
+        bad = __any(bad);
+        if (lane == 0) scan_put(rowlen, i, c, bad);
     }
+    scan_tail(st);   // P's row pointers; total and flag to the host
 }
 
 // One wave per row.  Lanes write the entries in parallel; the row sum of the isnsp
@@ -857,7 +859,7 @@ __global__ __launch_bounds__(256) void k_build_W(int N, int Nc, const int* __res
         if (lane == 0) {
             int tot = 0;
             for (int w = 0; w < (T >> 6); ++w) tot += wcnt[w];
-            rowcnt[i] = tot;
+            rowcnt[i] = tot;   // (plain counts: the compaction or a scan launch turns them into row pointers)
         }
         __syncthreads();
     }
@@ -873,8 +875,8 @@ __global__ __launch_bounds__(256) void k_w_split_count(int N, const int* __restr
                                                       const uint8_t* __restrict__ strong,
                                                       const uint8_t* __restrict__ isC,
                                                       const uint8_t* __restrict__ isF,
-                                                      int* __restrict__ cnt1,
-                                                      int* __restrict__ cntx) {
+                                                      int* cnt1,
+                                                      int* cntx, const ScanTail st) {
     WAVE_ROWS(i, N) {
         int n1 = 0, nx = 0;
         if (!isC[i])
@@ -889,10 +891,11 @@ __global__ __launch_bounds__(256) void k_w_split_count(int N, const int* __restr
             nx += __shfl_xor(nx, d);
         }
         if (lane == 0) {
-            cnt1[i] = n1;
-            cntx[i] = nx;
+            scan_put(cnt1, i, n1);
+            scan_put(cntx, i, nx);
         }
     }
+    scan_tail(st);   // the row pointers of W1 and X, both totals in one mailbox message
 }
 
 __global__ __launch_bounds__(256) void k_w_split_fill(int N, const int* __restrict__ rp,
@@ -957,21 +960,6 @@ __global__ __launch_bounds__(256) void k_w_combine(int N, int Nc, const uint8_t*
     }
 }
 
-// D = diag(W*1); W = D\W on the F rows (transfer.m:60-62)
-__global__ __launch_bounds__(256) void k_row_normalize(int N, const uint8_t* __restrict__ isF,
-                                                       const int* __restrict__ prp,
-                                                       double* __restrict__ pva) {
-    WAVE_ROWS(i, N) {
-        if (!isF[i]) continue;
-        const int b = prp[i], e = prp[i + 1];
-        double acc = 0.0;
-        if (lane == 0)
-            for (int t = b; t < e; ++t) acc = acc + pva[t];  // ascending columns, sequential
-        const double s = __shfl(acc, 0);
-        for (int t = b + lane; t < e; t += 64) pva[t] = pva[t] / s;
-    }
-}
-
 __global__ void k_u8_to_flag(int n, const uint8_t* __restrict__ a, int* __restrict__ f) {
     THREAD_ELEMS(i, n) f[i] = a[i] ? 1 : 0;
 }
@@ -980,15 +968,45 @@ __global__ void k_count_bad_split(int n, const uint8_t* __restrict__ isC,
     THREAD_ELEMS(i, n) if ((isC[i] != 0) == (isF[i] != 0)) atomicAdd(bad, 1);
 }
 
-// dense rows -> CSR (shared with ipd_sparse.hip's SpGEMM; re-declared here)
+// dense rows -> CSR, one wave per row.  normF != NULL: D = diag(W*1); W = D\W on the F rows (transfer.m:60-62) --
+// the row sum runs over the stored entries one at a time in ascending column order (the order MATLAB's sum over
+// a sparse row takes), read out of the lanes that hold them.
+__device__ __forceinline__ double su_readlane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __global__ __launch_bounds__(256) void k_dense_compact2(int nr, int nc,
                                                         const double* __restrict__ dense,
-                                                        const int* __restrict__ rp,
+                                                        const int* rp,
                                                         int* __restrict__ ci,
-                                                        double* __restrict__ va) {
+                                                        double* __restrict__ va,
+                                                        const int* __restrict__ head_cnt, int* head_rp,
+                                                        int* head_total,
+                                                        const uint8_t* __restrict__ normF) {
+    __shared__ ScanHeadLds L;   // head_cnt != NULL: plain counts, scanned here (scan_head; nr <= SCAN_HEAD_MAX)
+    if (head_cnt) {
+        scan_head(head_cnt, nr, head_rp, head_total, L);
+        rp = L.rp;
+    }
     WAVE_ROWS(i, nr) {
         int base = rp[i];
         const double* drow = dense + (size_t)i * nc;
+        double s = 1.0;
+        const bool norm = normF && normF[i];
+        if (norm) {
+            double acc = 0.0;
+            for (int j0 = 0; j0 < nc; j0 += 64) {
+                const int j = j0 + lane;
+                const double v = j < nc ? drow[j] : 0.0;
+                unsigned long long mask = __ballot(v != 0.0);
+                while (mask) {
+                    const int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    acc = acc + su_readlane(v, l);
+                }
+            }
+            s = acc;
+        }
         for (int j0 = 0; j0 < nc; j0 += 64) {
             const int j = j0 + lane;
             const double v = j < nc ? drow[j] : 0.0;
@@ -997,7 +1015,7 @@ __global__ __launch_bounds__(256) void k_dense_compact2(int nr, int nc,
             if (nzf) {
                 const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
                 ci[pos] = j;
-                va[pos] = v;
+                va[pos] = norm ? v / s : v;
             }
             base += __popcll(mask);
         }
@@ -1051,19 +1069,15 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         const int nf = (int)o.fnode;
         IPD_REQUIRE(nf > 0 && nf < N, IPD_E_ARG, "transfer: fnode must satisfy 0 < fnode < N");
         P.nc = N - nf;
-        int* rowlen = tmp.alloc<int>((size_t)N + 1);
-        int* bad = tmp.alloc<int>(1);
-        IPD_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(k_bigph_count, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, nf,
-                           A.rp, A.ci, rowlen, bad);
-        IPD_KERNEL_CHECK();
+        int* rowlen = zeroed<int>(ctx, (size_t)N + 1);   // (biased counts: see ScanTail)
         P.rp = dst.alloc<int>((size_t)N + 1);
-        {   // entry count and the "Aff is not diagonal" flag in ONE round trip (they sit side by side)
-            int* two = tmp.alloc<int>(2);
-            exclusive_scan_i32(ctx, rowlen, P.rp, N, two);
-            IPD_HIP(hipMemcpyAsync(two + 1, bad, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        {   // entry count and the "Aff is not diagonal" flag: one launch, ONE round trip
+            TailTotal tt(ctx, rowlen, P.rp, N);
+            hipLaunchKernelGGL(k_bigph_count, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, nf,
+                               A.rp, A.ci, rowlen, tt.t);
+            IPD_KERNEL_CHECK();
             int h2[2] = {0, 0};
-            ctx->fetch(two, h2, 2);
+            tt.wait(h2);
             P.nnz = h2[0];
             IPD_REQUIRE(h2[1] == 0, IPD_E_UNSUPPORTED,
                         "transfer: bigph level 1 needs a diagonal Aff block (transfer.m:20-21)");
@@ -1116,11 +1130,28 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         const size_t dense_elems = (size_t)N * (size_t)Nc;
         IPD_REQUIRE(dense_elems * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
                     "transfer: dense interpolation scratch above 2 GiB");
-        double* dense = tmp.alloc<double>(dense_elems);
-        int* rowcnt = tmp.alloc<int>((size_t)N + 1);
         // long rows: the product form (see k_w_split_count); short rows: one kernel
         bool split = (double)A.nnz / std::max(N, 1) >= 64.0;
         if (const char* e = getenv("IPD_INTERP")) split = !strcmp(e, "split");
+        // (the product form adds into rows that start out as zeros)
+        double* dense = (split && o.inter < 2) ? zeroed<double>(ctx, dense_elems) : tmp.alloc<double>(dense_elems);
+        // P's row pointers.  The product form and the ideal interpolation count the rows in a 256-thread launch
+        // whose tail scans the counts (ScanTail: the total stays on the device -- lazy -- or comes back through
+        // the mailbox).  k_build_W's one-wave workgroups leave plain counts: with a lazy count the compaction
+        // scans them on its way in (scan_head), otherwise a scan launch fetches the total.
+        const bool wtail = o.inter >= 2 || split;
+        int* rowcnt = wtail ? zeroed<int>(ctx, (size_t)N + 1) : tmp.alloc<int>((size_t)N + 1);
+        P.rp = dst.alloc<int>((size_t)N + 1);
+        ScanTail pt;
+        std::unique_ptr<TailTotal> ptt;
+        if (wtail) {
+            if (lazy)
+                pt = scan_tail_lazy(rowcnt, P.rp, N, counts);
+            else {
+                ptt.reset(new TailTotal(ctx, rowcnt, P.rp, N));
+                pt = ptt->t;
+            }
+        }
         if (o.inter >= 2) {                                                  // :57-58  W = -Aff \ Afc
             // MATLAB solves with the sparse Aff (CHOLMOD); here a dense Cholesky of the F-F block
             // (a principal block of the SPD level matrix) with the Nc columns of Afc as right-hand
@@ -1147,20 +1178,28 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
             hipLaunchKernelGGL(k_ideal_rows, dim3((int)std::min<size_t>((dense_elems + 255) / 256, 8192)),
                                dim3(256), 0, ctx->stream, N, Nc, isF, fidx, cidx, (const double*)Afc, dense);
             IPD_KERNEL_CHECK();
-            dense_rowcount(ctx, N, Nc, Nc, dense, rowcnt);
+            dense_rowcount(ctx, N, Nc, Nc, dense, rowcnt, pt);
         } else if (split) {
-            int* cnt1 = tmp.alloc<int>((size_t)N + 1);
-            int* cntx = tmp.alloc<int>((size_t)N + 1);
-            hipLaunchKernelGGL(k_w_split_count, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp,
-                               A.ci, strong, isC, isF, cnt1, cntx);
-            IPD_KERNEL_CHECK();
+            int* cnt1 = zeroed<int>(ctx, (size_t)N + 1);
+            int* cntx = zeroed<int>(ctx, (size_t)N + 1);
             Csr W1, X, W2;
             W1.nr = N;
             W1.nc = Nc;
             X.nr = X.nc = N;
             W1.rp = tmp.alloc<int>((size_t)N + 1);
             X.rp = tmp.alloc<int>((size_t)N + 1);
-            exclusive_scan_total2(ctx, cnt1, W1.rp, cntx, X.rp, N, &W1.nnz, &X.nnz);   // one launch, one round trip
+            {   // counts, both scans and both totals: one launch, one round trip
+                TailTotal wt(ctx, cnt1, W1.rp, N);
+                wt.t.in2 = cntx;
+                wt.t.out2 = X.rp;
+                hipLaunchKernelGGL(k_w_split_count, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp,
+                                   A.ci, strong, isC, isF, cnt1, cntx, wt.t);
+                IPD_KERNEL_CHECK();
+                int t[2] = {0, 0};
+                wt.wait(t);
+                W1.nnz = t[0];
+                X.nnz = t[1];
+            }
             W1.ci = tmp.alloc<int>((size_t)std::max(W1.nnz, 1));
             W1.va = tmp.alloc<double>((size_t)std::max(W1.nnz, 1));
             X.ci = tmp.alloc<int>((size_t)std::max(X.nnz, 1));
@@ -1170,12 +1209,11 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
                                X.ci, X.va);
             IPD_KERNEL_CHECK();
             csr_spgemm(ctx, tmp, X, W1, &W2);
-            IPD_HIP(hipMemsetAsync(dense, 0, dense_elems * 8, ctx->stream));
             csr_expand_dense(ctx, W1, dense, Nc);
             hipLaunchKernelGGL(k_w_combine, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, Nc, isC,
                                cidx, W2.rp, W2.ci, W2.va, dense);
             IPD_KERNEL_CHECK();
-            dense_rowcount(ctx, N, Nc, Nc, dense, rowcnt);
+            dense_rowcount(ctx, N, Nc, Nc, dense, rowcnt, pt);
         } else {
             IPD_OPTIN_LDS(ctx, k_build_W, 128 * 1024);
             const int bw_threads = (double)A.nnz / std::max(N, 1) >= 96.0 ? 256 : 64;
@@ -1184,23 +1222,29 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
                                isC, isF, cidx, dense, rowcnt);
             IPD_KERNEL_CHECK();
         }
-        P.rp = dst.alloc<int>((size_t)N + 1);
+        const int* head = nullptr;   // plain counts the compaction scans itself
         if (lazy) {   // dense bound, no round trip: the count is fetched with the products' below
-            exclusive_scan_i32(ctx, rowcnt, P.rp, N, counts);
             P.nnz = (int)((size_t)N * (size_t)Nc);
+            if (!wtail) {
+                if (N <= SCAN_HEAD_MAX)
+                    head = rowcnt;
+                else
+                    exclusive_scan_i32(ctx, rowcnt, P.rp, N, counts);
+            }
+        } else if (wtail) {
+            int two[2] = {0, 0};
+            ptt->wait(two);
+            P.nnz = two[0];
         } else {
             P.nnz = exclusive_scan_total(ctx, rowcnt, P.rp, N);
         }
         P.ci = dst.alloc<int>((size_t)std::max(P.nnz, 1));
         P.va = dst.alloc<double>((size_t)std::max(P.nnz, 1));
+        // compaction, and D = diag(W*1); W = D\W on the F rows (transfer.m:60-62) in the same launch
         hipLaunchKernelGGL(k_dense_compact2, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, Nc,
-                           dense, P.rp, P.ci, P.va);
+                           dense, (const int*)P.rp, P.ci, P.va, head, P.rp, head ? counts : (int*)nullptr,
+                           o.isnsp == 1 ? (const uint8_t*)isF : (const uint8_t*)nullptr);
         IPD_KERNEL_CHECK();
-        if (o.isnsp == 1) {                                                  // :60-62
-            hipLaunchKernelGGL(k_row_normalize, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N,
-                               isF, P.rp, P.va);
-            IPD_KERNEL_CHECK();
-        }
     }
     // Ac = Pro'*A*Pro, evaluated left to right                               transfer.m:66
     Csr Pt, T1, C;
@@ -1302,6 +1346,7 @@ ipd_amg* amg_setup(ipd_ctx* ctx, const Csr& A, const AmgOpts& o, ipd_rng* rng,
     if (o.bigph)  // Class_AMG.m:36-40
         IPD_REQUIRE(o.fnode > 0, IPD_E_ARG, "amg_options.bigph = 1 requires Nf > 0");
     IPD_REQUIRE(o.smoth >= 0 && o.maxit >= 0, IPD_E_ARG, "negative smoth/maxit");
+    ctx->zreset();   // one memset for all the zero-initialised temporaries of the previous build
     std::unique_ptr<ipd_amg> h(new ipd_amg());
     h->ctx = ctx;
     h->arena.reset(new Arena(&ctx->pool));

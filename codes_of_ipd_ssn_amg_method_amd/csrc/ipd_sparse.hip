@@ -35,40 +35,13 @@ void fill_i32(ipd_ctx* ctx, int* p, int v, size_t n) { fill_t(ctx, p, v, n); }
 void fill_f64(ipd_ctx* ctx, double* p, double v, size_t n) { fill_t(ctx, p, v, n); }
 void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n) { fill_t(ctx, p, v, n); }
 
-// Exclusive scan of n ints by ONE workgroup (n is a row/column count, at most a
-// few thousand on this path); out[n] receives the total.  in == out is allowed.
-__device__ __forceinline__ int exscan_block(const int* __restrict__ in, int* out, int n, int* wsum) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    int carry = 0;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        const int v = i < n ? in[i] : 0;
-        int x = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int y = __shfl_up(x, d);
-            if (lane >= d) x += y;
-        }
-        if (lane == 63) wsum[w] = x;
-        __syncthreads();
-        int woff = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            int s = wsum[k];
-            if (k < w) woff += s;
-            total += s;
-        }
-        if (i < n) out[i] = carry + woff + x - v;
-        carry += total;
-        __syncthreads();
-    }
-    if (tid == 0) out[n] = carry;
-    return carry;
-}
+// Exclusive scan of n ints by ONE workgroup (n is a row/column count, at most a few thousand on this path);
+// out[n] receives the total.  in == out is allowed.  Most scans ride at the end of the launch that produces the
+// counts (ScanTail, ipd_internal.h); these launches serve the rest.
 __global__ __launch_bounds__(1024) void k_exscan(const int* __restrict__ in, int* out, int n,
                                                  volatile unsigned* box, unsigned ticket, int* extra) {
     __shared__ int wsum[16];
-    const int carry = exscan_block(in, out, n, wsum);
+    const int carry = ipd_scan_counts(in, out, n, wsum);
     if (threadIdx.x == 0 && extra) *extra = carry;
     if (threadIdx.x == 0 && box) {   // post the total to the host mailbox (ipd_ctx::mailbox_wait)
         box[16] = (unsigned)carry;
@@ -81,8 +54,8 @@ __global__ __launch_bounds__(1024) void k_exscan2(const int* __restrict__ in1, i
                                                   const int* __restrict__ in2, int* out2, int n,
                                                   volatile unsigned* box, unsigned ticket) {
     __shared__ int wsum[16];
-    const int c1 = exscan_block(in1, out1, n, wsum);
-    const int c2 = exscan_block(in2, out2, n, wsum);
+    const int c1 = ipd_scan_counts(in1, out1, n, wsum);
+    const int c2 = ipd_scan_counts(in2, out2, n, wsum);
     if (threadIdx.x == 0 && box) {
         box[16] = (unsigned)c1;
         box[17] = (unsigned)c2;
@@ -177,7 +150,7 @@ __global__ void k_tr_mark(int nr, const int* __restrict__ rp, const int* __restr
 
 // one wave per column: exclusive prefix of popcounts over the column's words
 __global__ void k_tr_prefix(int nc, const unsigned* __restrict__ bits, int* __restrict__ pref,
-                            int* __restrict__ cnt, int wpc) {
+                            int* cnt, int wpc, const ScanTail st) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -195,8 +168,9 @@ __global__ void k_tr_prefix(int nc, const unsigned* __restrict__ bits, int* __re
             if (w < wpc) pref[(size_t)c * wpc + w] = carry + x - v;
             carry += __shfl(x, 63);
         }
-        if (lane == 0) cnt[c] = carry;
+        if (lane == 0) scan_put(cnt, c, carry);
     }
+    scan_tail(st);   // the transpose's row pointers
 }
 
 __global__ void k_tr_scatter(int nr, const int* __restrict__ rp, const int* __restrict__ ci,
@@ -226,10 +200,9 @@ void csr_transpose(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* At) {
     IPD_REQUIRE(words * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
                 "csr_transpose: matrix too large for the bitmap transpose (limit 2 GiB)");
     Csr T = csr_alloc(dst, A.nc, A.nr, A.nnz);
-    unsigned* bits = tmp.alloc<unsigned>(words);
+    unsigned* bits = zeroed<unsigned>(ctx, words);
     int* pref = tmp.alloc<int>(words);
-    int* cnt = tmp.alloc<int>((size_t)A.nc + 1);
-    IPD_HIP(hipMemsetAsync(bits, 0, words * sizeof(unsigned), ctx->stream));
+    int* cnt = zeroed<int>(ctx, (size_t)A.nc + 1);   // (biased counts: see ScanTail)
     const int rows_blocks = std::max(1, std::min(cdiv(A.nr, 4), 2048));
     const int cols_blocks = std::max(1, std::min(cdiv(A.nc, 4), 2048));
     if (A.nnz) {
@@ -238,9 +211,8 @@ void csr_transpose(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* At) {
         IPD_KERNEL_CHECK();
     }
     hipLaunchKernelGGL(k_tr_prefix, dim3(cols_blocks), dim3(256), 0, ctx->stream, A.nc, bits, pref,
-                       cnt, wpc);
+                       cnt, wpc, scan_tail_lazy(cnt, T.rp, A.nc, nullptr));
     IPD_KERNEL_CHECK();
-    exclusive_scan_i32(ctx, cnt, T.rp, A.nc);
     if (A.nnz) {
         hipLaunchKernelGGL(k_tr_scatter, dim3(rows_blocks), dim3(256), 0, ctx->stream, A.nr, A.rp,
                            A.ci, A.va, bits, pref, wpc, T.rp, T.ci, T.va);
@@ -376,8 +348,9 @@ __global__ __launch_bounds__(256) void k_spgemm_rows(int nr, int nc, const int* 
                                                      const int* __restrict__ yci,
                                                      const double* __restrict__ yva,
                                                      double* __restrict__ dense,
-                                                     int* __restrict__ rowcnt,
-                                                     unsigned long long* __restrict__ rowbits) {
+                                                     int* rowcnt,
+                                                     unsigned long long* __restrict__ rowbits,
+                                                     const ScanTail st) {
     // blockDim.x = 64 (short rows of Y) or 256 (long rows): more lanes per inner step
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ int wcnt[4];
@@ -434,10 +407,11 @@ __global__ __launch_bounds__(256) void k_spgemm_rows(int nr, int nc, const int* 
         if (tid == 0) {
             int tot = 0;
             for (int w = 0; w < W; ++w) tot += wcnt[w];
-            rowcnt[i] = tot;
+            scan_put(rowcnt, i, tot);
         }
         __syncthreads();
     }
+    scan_tail(st);
 }
 
 // one wave per row: ordered compaction of the dense row into CSR; with `rowbits` only the
@@ -445,9 +419,18 @@ __global__ __launch_bounds__(256) void k_spgemm_rows(int nr, int nc, const int* 
 __global__ __launch_bounds__(256) void k_dense_compact(int nr, int nc, int ld,
                                                        const double* __restrict__ dense,
                                                        const unsigned long long* __restrict__ rowbits,
-                                                       const int* __restrict__ rp,
+                                                       const int* rp,
                                                        int* __restrict__ ci,
-                                                       double* __restrict__ va) {
+                                                       double* __restrict__ va,
+                                                       const int* __restrict__ head_cnt, int* head_rp,
+                                                       int* head_total) {
+    // head_cnt != NULL: the row pointers are still plain counts -- every workgroup scans them for itself and
+    // workgroup 0 stores them at head_rp (scan_head, ipd_internal.h; nr <= SCAN_HEAD_MAX)
+    __shared__ ScanHeadLds L;
+    if (head_cnt) {
+        scan_head(head_cnt, nr, head_rp, head_total, L);
+        rp = L.rp;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -579,7 +562,7 @@ __global__ __launch_bounds__(256) void k_gemm_ordered(int nkp, int ncp,
 // one wave per row: number of nonzeros of a dense row
 __global__ __launch_bounds__(256) void k_dense_rowcount(int nr, int nc, int ld,
                                                         const double* __restrict__ dense,
-                                                        int* __restrict__ rowcnt) {
+                                                        int* rowcnt, const ScanTail st) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -589,8 +572,9 @@ __global__ __launch_bounds__(256) void k_dense_rowcount(int nr, int nc, int ld,
         for (int j = lane; j < nc; j += 64) nz += (drow[j] != 0.0);
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d);
-        if (lane == 0) rowcnt[i] = nz;
+        if (lane == 0) scan_put(rowcnt, i, nz);
     }
+    scan_tail(st);
 }
 
 // The same product for short rows of Y, one WAVE per output row.  k_spgemm_rows pays three dependent
@@ -713,7 +697,7 @@ __global__ __launch_bounds__(64) void k_spgemm_rows_w(int nr, int nc, const int*
             rowbits[(size_t)i * nw + lane] = touched[lane];
             touched[lane] = 0ull;
         }
-        if (lane == 0) rowcnt[i] = nz;
+        if (lane == 0) rowcnt[i] = nz;   // (plain counts: one-wave workgroups leave the scan to the consumer)
         __syncthreads();
     }
 }
@@ -750,23 +734,48 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, in
     IPD_REQUIRE(X.nc == Y.nr, IPD_E_ARG, "spgemm: inner dimensions differ");
     const int nr = X.nr, nc = Y.nc;
     Arena& tmp = *ctx->scratch;
-    int* rowcnt = tmp.alloc<int>((size_t)nr + 1);
     Csr out;
     out.nr = nr;
     out.nc = nc;
     out.rp = dst.alloc<int>((size_t)nr + 1);
+    if (nr == 0) {
+        IPD_HIP(hipMemsetAsync(out.rp, 0, sizeof(int), ctx->stream));
+        if (total_dev) IPD_HIP(hipMemsetAsync(total_dev, 0, sizeof(int), ctx->stream));
+        out.nnz = 0;
+        out.ci = dst.alloc<int>(0);
+        out.va = dst.alloc<double>(0);
+        *C = out;
+        return;
+    }
     double* dense = nullptr;
     unsigned long long* rowbits = nullptr;   // row kernel only: the 64-column blocks a row touched
     int ld = nc;
     size_t tile_bytes = 0;
-    if (spgemm_prefers_tiles(X, Y, &tile_bytes)) {
+    const bool tiles = spgemm_prefers_tiles(X, Y, &tile_bytes);
+    const int threads = (Y.nr > 0 && (double)Y.nnz / Y.nr >= 96.0) ? 256 : 64;
+    // The row pointers.  Producers with 256-thread workgroups scan their own counts at the end of the launch
+    // (ScanTail: the total stays on the device -- lazy count -- or comes back through the host mailbox).  The
+    // one-wave row kernel leaves plain counts: with a lazy count the compaction scans them on its way in
+    // (scan_head), otherwise a scan launch fetches the total that sizes the arrays.
+    const bool tail = tiles || threads == 256;
+    int* rowcnt = tail ? zeroed<int>(ctx, (size_t)nr + 1) : tmp.alloc<int>((size_t)nr + 1);
+    ScanTail st;
+    std::unique_ptr<TailTotal> tt;
+    if (tail) {
+        if (total_dev)
+            st = scan_tail_lazy(rowcnt, out.rp, nr, total_dev);
+        else {
+            tt.reset(new TailTotal(ctx, rowcnt, out.rp, nr));
+            st = tt->t;
+        }
+    }
+    if (tiles) {
         const size_t nrp = round_up((size_t)nr, GT), nkp = round_up((size_t)X.nc, GT),
                      ncp = round_up((size_t)nc, GT);
-        double* xd = tmp.alloc<double>(nrp * nkp + nkp * ncp);   // both operands: one memset
+        double* xd = zeroed<double>(ctx, nrp * nkp + nkp * ncp);   // both operands
         double* yd = xd + nrp * nkp;
         dense = tmp.alloc<double>(nrp * ncp);
         ld = (int)ncp;
-        IPD_HIP(hipMemsetAsync(xd, 0, (nrp * nkp + nkp * ncp) * 8, ctx->stream));
         hipLaunchKernelGGL(k_csr_expand, dim3(std::min(cdiv(X.nr, 4), 4096)), dim3(256), 0,
                            ctx->stream, X.nr, (int)nkp, X.rp, X.ci, X.va, xd);
         hipLaunchKernelGGL(k_csr_expand, dim3(std::min(cdiv(Y.nr, 4), 4096)), dim3(256), 0,
@@ -774,43 +783,53 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, in
         hipLaunchKernelGGL(k_gemm_ordered, dim3((unsigned)(ncp / GT), (unsigned)(nrp / GT)),
                            dim3(256), 0, ctx->stream, (int)nkp, (int)ncp, xd, yd, dense);
         hipLaunchKernelGGL(k_dense_rowcount, dim3(std::min(cdiv(nr, 4), 4096)), dim3(256), 0,
-                           ctx->stream, nr, nc, ld, dense, rowcnt);
+                           ctx->stream, nr, nc, ld, dense, rowcnt, st);
         IPD_KERNEL_CHECK();
     } else {
         IPD_REQUIRE((size_t)nc * 8 <= 128 * 1024, IPD_E_LIMIT,
                     "spgemm: more than 16384 columns (LDS accumulator row limit)");
-        const size_t dense_elems = (size_t)(nr ? nr : 1) * (size_t)(nc ? nc : 1);
+        const size_t dense_elems = (size_t)nr * (size_t)(nc ? nc : 1);
         IPD_REQUIRE(dense_elems * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
                     "spgemm: dense scratch above 2 GiB");
         dense = tmp.alloc<double>(dense_elems);
-        rowbits = tmp.alloc<unsigned long long>((size_t)(nr ? nr : 1) * (size_t)((nc + 4095) / 4096 + 1));
-        if (nr > 0) {
-            const size_t lds = std::max<size_t>((size_t)nc * 8, 16);
+        rowbits = tmp.alloc<unsigned long long>((size_t)nr * (size_t)((nc + 4095) / 4096 + 1));
+        const size_t lds = std::max<size_t>((size_t)nc * 8, 16);
+        if (threads == 64) {
+            IPD_OPTIN_LDS(ctx, k_spgemm_rows_w<8>, 128 * 1024);
+            hipLaunchKernelGGL(k_spgemm_rows_w<8>, dim3(std::min(nr, 16384)), dim3(64), lds, ctx->stream, nr,
+                               nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense, rowcnt, rowbits);
+        } else {
             IPD_OPTIN_LDS(ctx, k_spgemm_rows, 128 * 1024);
-            const int threads = (Y.nr > 0 && (double)Y.nnz / Y.nr >= 96.0) ? 256 : 64;
-            if (threads == 64) {
-                IPD_OPTIN_LDS(ctx, k_spgemm_rows_w<8>, 128 * 1024);
-                hipLaunchKernelGGL(k_spgemm_rows_w<8>, dim3(std::min(nr, 16384)), dim3(64), lds, ctx->stream, nr,
-                                   nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense, rowcnt, rowbits);
-            } else
-                hipLaunchKernelGGL(k_spgemm_rows, dim3(std::min(nr, 16384)), dim3(threads), lds,
-                                   ctx->stream, nr, nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense,
-                                   rowcnt, rowbits);
-            IPD_KERNEL_CHECK();
+            hipLaunchKernelGGL(k_spgemm_rows, dim3(std::min(nr, 16384)), dim3(threads), lds,
+                               ctx->stream, nr, nc, X.rp, X.ci, X.va, Y.rp, Y.ci, Y.va, dense,
+                               rowcnt, rowbits, st);
         }
+        IPD_KERNEL_CHECK();
     }
-    if (total_dev) {   // lazy count: dense bound, no round trip
-        exclusive_scan_i32(ctx, rowcnt, out.rp, nr, total_dev);
+    const int* head = nullptr;   // plain counts the compaction scans itself
+    if (tail) {
+        if (total_dev) {   // lazy count: dense bound, no round trip
+            out.nnz = (int)((size_t)nr * (size_t)nc);
+        } else {
+            int two[2] = {0, 0};
+            tt->wait(two);
+            out.nnz = two[0];
+        }
+    } else if (total_dev) {
         out.nnz = (int)((size_t)nr * (size_t)nc);
+        if (nr <= SCAN_HEAD_MAX)
+            head = rowcnt;
+        else
+            exclusive_scan_i32(ctx, rowcnt, out.rp, nr, total_dev);
     } else {
         out.nnz = exclusive_scan_total(ctx, rowcnt, out.rp, nr);
     }
     out.ci = dst.alloc<int>((size_t)out.nnz);
     out.va = dst.alloc<double>((size_t)out.nnz);
-    if (out.nnz) {
+    if (out.nnz || head) {
         hipLaunchKernelGGL(k_dense_compact, dim3(std::max(1, std::min(cdiv(nr, 4), 4096))), dim3(256),
-                           0, ctx->stream, nr, nc, ld, dense, (const unsigned long long*)rowbits, out.rp, out.ci,
-                           out.va);
+                           0, ctx->stream, nr, nc, ld, dense, (const unsigned long long*)rowbits,
+                           (const int*)out.rp, out.ci, out.va, head, out.rp, total_dev);
         IPD_KERNEL_CHECK();
     }
     *C = out;
@@ -824,10 +843,10 @@ void csr_expand_dense(ipd_ctx* ctx, const Csr& A, double* dense, int ld) {
     IPD_KERNEL_CHECK();
 }
 
-void dense_rowcount(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, int* rowcnt) {
+void dense_rowcount(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, int* rowcnt, const ScanTail& st) {
     if (nr == 0) return;
     hipLaunchKernelGGL(k_dense_rowcount, dim3(std::min(cdiv(nr, 4), 4096)), dim3(256), 0,
-                       ctx->stream, nr, nc, ld, dense, rowcnt);
+                       ctx->stream, nr, nc, ld, dense, rowcnt, st);
     IPD_KERNEL_CHECK();
 }
 
@@ -836,7 +855,7 @@ void dense_compact(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, co
     if (nr == 0 || out.nnz == 0) return;
     hipLaunchKernelGGL(k_dense_compact, dim3(std::max(1, std::min(cdiv(nr, 4), 4096))), dim3(256), 0,
                        ctx->stream, nr, nc, ld, dense, (const unsigned long long*)nullptr, (const int*)out.rp,
-                       out.ci, out.va);
+                       out.ci, out.va, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
     IPD_KERNEL_CHECK();
 }
 
