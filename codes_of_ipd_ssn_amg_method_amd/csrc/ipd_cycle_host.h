@@ -531,8 +531,12 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     D.retol = h->opts.retol;
     D.pcg_maxit = h->opts.pcg_maxit;
     // bigraph transfers P = [W; I]: the kernel adds the identity entries instead of walking them
+    // (a bigraph level 1 built by amg_transfer has them by construction -- k_bigph_fill writes the rows of I --
+    // which saves the check and its round trip on every hierarchy of a run)
     D.wident = 0;
-    if (N2 == nc) {
+    if (N2 == nc && h->opts.bigph) {
+        D.wident = 1;
+    } else if (N2 == nc) {
         int* bad = zeroed<int>(h->ctx, 1);
         hipLaunchKernelGGL(k_res_check_ident, dim3(cdiv(N2, 256)), dim3(256), 0, h->ctx->stream, nf, N2,
                            csr(l2.P), csr(l2.Pt), bad);

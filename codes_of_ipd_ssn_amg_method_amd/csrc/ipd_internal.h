@@ -523,7 +523,8 @@ void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n);
 constexpr size_t SPGEMM_LAZY_MAX = size_t(1) << 21;
 void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, int* total_dev = nullptr);
 void csr_expand_dense(ipd_ctx* ctx, const Csr& A, double* dense, int ld);  // dense pre-zeroed
-// rowcnt: zeroed<int>; the launch's tail scans the (biased) counts into st.out -- nr > 0
+// st.out != NULL: rowcnt is zeroed<int> and the launch's tail scans the (biased) counts into st.out (nr > 0);
+// an empty st leaves plain counts
 void dense_rowcount(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, int* rowcnt, const ScanTail& st);
 void dense_compact(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, const Csr& out);
 void csr_copy(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out);

@@ -715,10 +715,17 @@ static void amg_cf_split(ipd_ctx* ctx, const Csr& S, uint8_t* isC, uint8_t* isF)
 // isnsp normalisation (:22-24) is accumulated in ascending column order.
 __global__ __launch_bounds__(256) void k_bigph_count(int N, int nf, const int* __restrict__ rp,
                                                      const int* __restrict__ ci, int* rowlen,
-                                                     const ScanTail st) {
+                                                     const ScanTail st, int* __restrict__ badp) {
+    // st.out != NULL: biased counts with the flag in bit 30, scanned and posted by the launch's tail;
+    // otherwise plain counts (k_bigph_fill scans them) and the flag at *badp
     WAVE_ROWS(i, N) {
         if (i >= nf) {
-            if (lane == 0) scan_put(rowlen, i, 1);
+            if (lane == 0) {
+                if (st.out)
+                    scan_put(rowlen, i, 1);
+                else
+                    rowlen[i] = 1;
+            }
             continue;
         }
         int c = 0;
@@ -733,7 +740,14 @@ __global__ __launch_bounds__(256) void k_bigph_count(int N, int nf, const int* _
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
         bad = __any(bad);
-        if (lane == 0) scan_put(rowlen, i, c, bad);
+        if (lane == 0) {
+            if (st.out)
+                scan_put(rowlen, i, c, bad);
+            else {
+                rowlen[i] = c;
+                if (bad) *badp = 1;
+            }
+        }
     }
     scan_tail(st);   // P's row pointers; total and flag to the host
 }
@@ -745,9 +759,16 @@ __global__ __launch_bounds__(256) void k_bigph_fill(int N, int nf, int isnsp,
                                                     const int* __restrict__ rp,
                                                     const int* __restrict__ ci,
                                                     const double* __restrict__ va,
-                                                    const int* __restrict__ prp,
+                                                    const int* prp,
                                                     int* __restrict__ pci, double* __restrict__ pva,
-                                                    uint8_t* __restrict__ cmask) {
+                                                    uint8_t* __restrict__ cmask,
+                                                    const int* __restrict__ head_cnt, int* head_rp,
+                                                    int* head_total) {
+    __shared__ ScanHeadLds L;   // head_cnt != NULL: plain counts, scanned here (scan_head; N <= SCAN_HEAD_MAX)
+    if (head_cnt) {
+        scan_head(head_cnt, N, head_rp, head_total, L);
+        prp = L.rp;
+    }
     WAVE_ROWS(i, N) {
         const int pos0 = prp[i];
         if (i >= nf) {
@@ -891,8 +912,13 @@ __global__ __launch_bounds__(256) void k_w_split_count(int N, const int* __restr
             nx += __shfl_xor(nx, d);
         }
         if (lane == 0) {
-            scan_put(cnt1, i, n1);
-            scan_put(cntx, i, nx);
+            if (st.out) {
+                scan_put(cnt1, i, n1);
+                scan_put(cntx, i, nx);
+            } else {
+                cnt1[i] = n1;
+                cntx[i] = nx;
+            }
         }
     }
     scan_tail(st);   // the row pointers of W1 and X, both totals in one mailbox message
@@ -906,10 +932,21 @@ __global__ __launch_bounds__(256) void k_w_split_fill(int N, const int* __restri
                                                      const uint8_t* __restrict__ isC,
                                                      const uint8_t* __restrict__ isF,
                                                      const int* __restrict__ cidx,
-                                                     const int* __restrict__ rp1,
+                                                     const int* rp1,
                                                      int* __restrict__ ci1, double* __restrict__ va1,
-                                                     const int* __restrict__ rpx,
-                                                     int* __restrict__ cix, double* __restrict__ vax) {
+                                                     const int* rpx,
+                                                     int* __restrict__ cix, double* __restrict__ vax,
+                                                     const int* __restrict__ head1,
+                                                     const int* __restrict__ headx, int* rp1_out,
+                                                     int* rpx_out) {
+    // head1 != NULL: rp1 / rpx are still k_w_split_count's plain counts, scanned here (scan_head; N <= SCAN_HEAD_MAX)
+    __shared__ ScanHeadLds L1, Lx;
+    if (head1) {
+        scan_head(head1, N, rp1_out, nullptr, L1);
+        scan_head(headx, N, rpx_out, nullptr, Lx);
+        rp1 = L1.rp;
+        rpx = Lx.rp;
+    }
     WAVE_ROWS(i, N) {
         if (isC[i]) continue;
         const double ndi = -diag[i];
@@ -1069,12 +1106,26 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         const int nf = (int)o.fnode;
         IPD_REQUIRE(nf > 0 && nf < N, IPD_E_ARG, "transfer: fnode must satisfy 0 < fnode < N");
         P.nc = N - nf;
-        int* rowlen = zeroed<int>(ctx, (size_t)N + 1);   // (biased counts: see ScanTail)
         P.rp = dst.alloc<int>((size_t)N + 1);
-        {   // entry count and the "Aff is not diagonal" flag: one launch, ONE round trip
+        // lazy counts (see below): the fill scans the plain row lengths itself, P's arrays are sized by A's entry
+        // count, and count and "Aff is not diagonal" flag are fetched with the products' counts
+        lazy = level < 40 && ctx->xfer_hint[level][0] > 0 && ctx->xfer_hint[level][1] > 0 &&
+               ctx->xfer_hint[level][2] > 0 && N <= SCAN_HEAD_MAX && (size_t)N * (size_t)P.nc <= SPGEMM_LAZY_MAX &&
+               (size_t)P.nc * (size_t)P.nc <= SPGEMM_LAZY_MAX;
+        const int* head = nullptr;
+        if (lazy) {
+            counts = zeroed<int>(ctx, 4);
+            int* rowlen = tmp.alloc<int>((size_t)N + 1);
+            hipLaunchKernelGGL(k_bigph_count, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, nf,
+                               A.rp, A.ci, rowlen, ScanTail(), counts + 3);
+            IPD_KERNEL_CHECK();
+            P.nnz = (int)std::min<size_t>((size_t)A.nnz + (size_t)N, (size_t)N * (size_t)P.nc);
+            head = rowlen;
+        } else {   // entry count and flag: one launch, ONE round trip
+            int* rowlen = zeroed<int>(ctx, (size_t)N + 1);   // (biased counts: see ScanTail)
             TailTotal tt(ctx, rowlen, P.rp, N);
             hipLaunchKernelGGL(k_bigph_count, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, nf,
-                               A.rp, A.ci, rowlen, tt.t);
+                               A.rp, A.ci, rowlen, tt.t, (int*)nullptr);
             IPD_KERNEL_CHECK();
             int h2[2] = {0, 0};
             tt.wait(h2);
@@ -1085,7 +1136,8 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         P.ci = dst.alloc<int>((size_t)P.nnz);
         P.va = dst.alloc<double>((size_t)P.nnz);
         hipLaunchKernelGGL(k_bigph_fill, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, nf,
-                           o.isnsp, A.rp, A.ci, A.va, P.rp, P.ci, P.va, cmask);
+                           o.isnsp, A.rp, A.ci, A.va, (const int*)P.rp, P.ci, P.va, cmask, head, P.rp,
+                           head ? counts : (int*)nullptr);
         IPD_KERNEL_CHECK();
     } else {                                                                 // transfer.m:41-63
         uint8_t* isC = cmask;
@@ -1121,7 +1173,7 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         lazy = level >= 1 && level < 40 && ctx->xfer_hint[level][0] > 0 && ctx->xfer_hint[level][1] > 0 &&
                ctx->xfer_hint[level][2] > 0 && (size_t)N * (size_t)Nc <= SPGEMM_LAZY_MAX &&
                (size_t)Nc * (size_t)Nc <= SPGEMM_LAZY_MAX;
-        if (lazy) counts = tmp.alloc<int>(3);
+        if (lazy) counts = zeroed<int>(ctx, 4);   // entries of P, P'A, Ac; a flag (bigraph level: Aff not diagonal)
         if (!small_done) {
             hipLaunchKernelGGL(k_rowmax, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp, A.ci,
                                A.va, maxrow, diag);
@@ -1135,11 +1187,12 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         if (const char* e = getenv("IPD_INTERP")) split = !strcmp(e, "split");
         // (the product form adds into rows that start out as zeros)
         double* dense = (split && o.inter < 2) ? zeroed<double>(ctx, dense_elems) : tmp.alloc<double>(dense_elems);
-        // P's row pointers.  The product form and the ideal interpolation count the rows in a 256-thread launch
-        // whose tail scans the counts (ScanTail: the total stays on the device -- lazy -- or comes back through
-        // the mailbox).  k_build_W's one-wave workgroups leave plain counts: with a lazy count the compaction
-        // scans them on its way in (scan_head), otherwise a scan launch fetches the total.
-        const bool wtail = o.inter >= 2 || split;
+        // P's row pointers.  With a lazy count the compaction scans the plain counts on its way in (scan_head).
+        // Otherwise the host needs the total: the product form and the ideal interpolation count the rows in a
+        // 256-thread launch whose tail scans and posts it (ScanTail); k_build_W's one-wave workgroups are followed
+        // by a scan launch.
+        const bool head_ok = lazy && N <= SCAN_HEAD_MAX;
+        const bool wtail = !head_ok && (o.inter >= 2 || split);
         int* rowcnt = wtail ? zeroed<int>(ctx, (size_t)N + 1) : tmp.alloc<int>((size_t)N + 1);
         P.rp = dst.alloc<int>((size_t)N + 1);
         ScanTail pt;
@@ -1180,35 +1233,57 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
             IPD_KERNEL_CHECK();
             dense_rowcount(ctx, N, Nc, Nc, dense, rowcnt, pt);
         } else if (split) {
-            int* cnt1 = zeroed<int>(ctx, (size_t)N + 1);
-            int* cntx = zeroed<int>(ctx, (size_t)N + 1);
             Csr W1, X, W2;
             W1.nr = N;
             W1.nc = Nc;
             X.nr = X.nc = N;
             W1.rp = tmp.alloc<int>((size_t)N + 1);
             X.rp = tmp.alloc<int>((size_t)N + 1);
-            {   // counts, both scans and both totals: one launch, one round trip
-                TailTotal wt(ctx, cnt1, W1.rp, N);
-                wt.t.in2 = cntx;
-                wt.t.out2 = X.rp;
+            if (head_ok) {
+                // no round trip: W1 and X are sub-patterns of A (arrays sized by A's entry count, the fill scans
+                // the plain counts itself) and the product's count stays on the device
+                int* cnt1 = tmp.alloc<int>((size_t)N + 1);
+                int* cntx = tmp.alloc<int>((size_t)N + 1);
                 hipLaunchKernelGGL(k_w_split_count, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp,
-                                   A.ci, strong, isC, isF, cnt1, cntx, wt.t);
+                                   A.ci, strong, isC, isF, cnt1, cntx, ScanTail());
                 IPD_KERNEL_CHECK();
-                int t[2] = {0, 0};
-                wt.wait(t);
-                W1.nnz = t[0];
-                X.nnz = t[1];
+                W1.nnz = X.nnz = std::max(A.nnz, 1);   // (allocation bound)
+                W1.ci = tmp.alloc<int>((size_t)W1.nnz);
+                W1.va = tmp.alloc<double>((size_t)W1.nnz);
+                X.ci = tmp.alloc<int>((size_t)X.nnz);
+                X.va = tmp.alloc<double>((size_t)X.nnz);
+                hipLaunchKernelGGL(k_w_split_fill, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp,
+                                   A.ci, A.va, diag, strong, isC, isF, cidx, (const int*)W1.rp, W1.ci, W1.va,
+                                   (const int*)X.rp, X.ci, X.va, (const int*)cnt1, (const int*)cntx, W1.rp, X.rp);
+                IPD_KERNEL_CHECK();
+                W1.nnz = X.nnz = std::max(A.nnz / 2, 1);   // (estimates for the product's kernel choice)
+                csr_spgemm(ctx, tmp, X, W1, &W2, tmp.alloc<int>(1));
+            } else {
+                int* cnt1 = zeroed<int>(ctx, (size_t)N + 1);
+                int* cntx = zeroed<int>(ctx, (size_t)N + 1);
+                {   // counts, both scans and both totals: one launch, one round trip
+                    TailTotal wt(ctx, cnt1, W1.rp, N);
+                    wt.t.in2 = cntx;
+                    wt.t.out2 = X.rp;
+                    hipLaunchKernelGGL(k_w_split_count, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp,
+                                       A.ci, strong, isC, isF, cnt1, cntx, wt.t);
+                    IPD_KERNEL_CHECK();
+                    int t[2] = {0, 0};
+                    wt.wait(t);
+                    W1.nnz = t[0];
+                    X.nnz = t[1];
+                }
+                W1.ci = tmp.alloc<int>((size_t)std::max(W1.nnz, 1));
+                W1.va = tmp.alloc<double>((size_t)std::max(W1.nnz, 1));
+                X.ci = tmp.alloc<int>((size_t)std::max(X.nnz, 1));
+                X.va = tmp.alloc<double>((size_t)std::max(X.nnz, 1));
+                hipLaunchKernelGGL(k_w_split_fill, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp,
+                                   A.ci, A.va, diag, strong, isC, isF, cidx, (const int*)W1.rp, W1.ci, W1.va,
+                                   (const int*)X.rp, X.ci, X.va, (const int*)nullptr, (const int*)nullptr,
+                                   (int*)nullptr, (int*)nullptr);
+                IPD_KERNEL_CHECK();
+                csr_spgemm(ctx, tmp, X, W1, &W2);
             }
-            W1.ci = tmp.alloc<int>((size_t)std::max(W1.nnz, 1));
-            W1.va = tmp.alloc<double>((size_t)std::max(W1.nnz, 1));
-            X.ci = tmp.alloc<int>((size_t)std::max(X.nnz, 1));
-            X.va = tmp.alloc<double>((size_t)std::max(X.nnz, 1));
-            hipLaunchKernelGGL(k_w_split_fill, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp,
-                               A.ci, A.va, diag, strong, isC, isF, cidx, W1.rp, W1.ci, W1.va, X.rp,
-                               X.ci, X.va);
-            IPD_KERNEL_CHECK();
-            csr_spgemm(ctx, tmp, X, W1, &W2);
             csr_expand_dense(ctx, W1, dense, Nc);
             hipLaunchKernelGGL(k_w_combine, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, Nc, isC,
                                cidx, W2.rp, W2.ci, W2.va, dense);
@@ -1223,14 +1298,12 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
             IPD_KERNEL_CHECK();
         }
         const int* head = nullptr;   // plain counts the compaction scans itself
-        if (lazy) {   // dense bound, no round trip: the count is fetched with the products' below
+        if (head_ok) {   // dense bound, no round trip: the count is fetched with the products' below
             P.nnz = (int)((size_t)N * (size_t)Nc);
-            if (!wtail) {
-                if (N <= SCAN_HEAD_MAX)
-                    head = rowcnt;
-                else
-                    exclusive_scan_i32(ctx, rowcnt, P.rp, N, counts);
-            }
+            head = rowcnt;
+        } else if (lazy) {
+            P.nnz = (int)((size_t)N * (size_t)Nc);
+            if (!wtail) exclusive_scan_i32(ctx, rowcnt, P.rp, N, counts);
         } else if (wtail) {
             int two[2] = {0, 0};
             ptt->wait(two);
@@ -1258,17 +1331,19 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
     const bool lazy_prod = hint && hint[1] > 0 && hint[2] > 0 && (lazy || P.nnz >= 0) &&
                            (size_t)Ncc * (size_t)N <= SPGEMM_LAZY_MAX && (size_t)Ncc * (size_t)Ncc <= SPGEMM_LAZY_MAX;
     if (lazy_prod) {
-        int* c3 = lazy ? counts : tmp.alloc<int>(3);
+        int* c3 = lazy ? counts : tmp.alloc<int>(4);
         Csr Pe = P, Pte = Pt;
         if (lazy) Pe.nnz = Pte.nnz = std::max(1, std::min(hint[0], P.nnz));   // (estimates for the heuristic only)
         csr_spgemm(ctx, T1out ? dst : tmp, Pte, A, &T1, c3 + 1);
         Csr T1e = T1;
         T1e.nnz = std::max(1, std::min(hint[1], T1.nnz));
         csr_spgemm(ctx, dst, T1e, Pe, &C, c3 + 2);
-        int h3[3] = {0, 0, 0};
+        int h3[4] = {0, 0, 0, 0};
         if (lazy) {
-            ctx->fetch(c3, h3, 3);
+            ctx->fetch(c3, h3, 4);
             P.nnz = Pt.nnz = h3[0];
+            IPD_REQUIRE(h3[3] == 0, IPD_E_UNSUPPORTED,
+                        "transfer: bigph level 1 needs a diagonal Aff block (transfer.m:20-21)");
         } else {
             ctx->fetch(c3 + 1, h3 + 1, 2);
         }

@@ -150,7 +150,7 @@ __global__ void k_tr_mark(int nr, const int* __restrict__ rp, const int* __restr
 
 // one wave per column: exclusive prefix of popcounts over the column's words
 __global__ void k_tr_prefix(int nc, const unsigned* __restrict__ bits, int* __restrict__ pref,
-                            int* cnt, int wpc, const ScanTail st) {
+                            int* __restrict__ cnt, int wpc) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -168,15 +168,23 @@ __global__ void k_tr_prefix(int nc, const unsigned* __restrict__ bits, int* __re
             if (w < wpc) pref[(size_t)c * wpc + w] = carry + x - v;
             carry += __shfl(x, 63);
         }
-        if (lane == 0) scan_put(cnt, c, carry);
+        if (lane == 0) cnt[c] = carry;
     }
-    scan_tail(st);   // the transpose's row pointers
 }
 
-__global__ void k_tr_scatter(int nr, const int* __restrict__ rp, const int* __restrict__ ci,
-                             const double* __restrict__ va, const unsigned* __restrict__ bits,
-                             const int* __restrict__ pref, int wpc, const int* __restrict__ trp,
-                             int* __restrict__ tci, double* __restrict__ tva) {
+// head_cnt != NULL: the transpose's row pointers are still the column counts -- every workgroup scans them for
+// itself and workgroup 0 stores them at head_rp (scan_head, ipd_internal.h; at most SCAN_HEAD_MAX columns)
+__global__ __launch_bounds__(256) void k_tr_scatter(int nr, const int* __restrict__ rp,
+                                                    const int* __restrict__ ci, const double* __restrict__ va,
+                                                    const unsigned* __restrict__ bits,
+                                                    const int* __restrict__ pref, int wpc, const int* trp,
+                                                    int* __restrict__ tci, double* __restrict__ tva,
+                                                    const int* __restrict__ head_cnt, int ncols, int* head_rp) {
+    __shared__ ScanHeadLds L;
+    if (head_cnt) {
+        scan_head(head_cnt, ncols, head_rp, nullptr, L);
+        trp = L.rp;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -202,7 +210,7 @@ void csr_transpose(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* At) {
     Csr T = csr_alloc(dst, A.nc, A.nr, A.nnz);
     unsigned* bits = zeroed<unsigned>(ctx, words);
     int* pref = tmp.alloc<int>(words);
-    int* cnt = zeroed<int>(ctx, (size_t)A.nc + 1);   // (biased counts: see ScanTail)
+    int* cnt = tmp.alloc<int>((size_t)A.nc + 1);
     const int rows_blocks = std::max(1, std::min(cdiv(A.nr, 4), 2048));
     const int cols_blocks = std::max(1, std::min(cdiv(A.nc, 4), 2048));
     if (A.nnz) {
@@ -211,11 +219,16 @@ void csr_transpose(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* At) {
         IPD_KERNEL_CHECK();
     }
     hipLaunchKernelGGL(k_tr_prefix, dim3(cols_blocks), dim3(256), 0, ctx->stream, A.nc, bits, pref,
-                       cnt, wpc, scan_tail_lazy(cnt, T.rp, A.nc, nullptr));
+                       cnt, wpc);
     IPD_KERNEL_CHECK();
+    // the column counts become the transpose's row pointers inside the scatter (scan_head), or in a launch of
+    // their own when there are too many columns for that (or nothing to scatter)
+    const bool head = A.nnz > 0 && A.nc <= SCAN_HEAD_MAX;
+    if (!head) exclusive_scan_i32(ctx, cnt, T.rp, A.nc);
     if (A.nnz) {
         hipLaunchKernelGGL(k_tr_scatter, dim3(rows_blocks), dim3(256), 0, ctx->stream, A.nr, A.rp,
-                           A.ci, A.va, bits, pref, wpc, T.rp, T.ci, T.va);
+                           A.ci, A.va, bits, pref, wpc, (const int*)T.rp, T.ci, T.va,
+                           head ? (const int*)cnt : (const int*)nullptr, A.nc, T.rp);
         IPD_KERNEL_CHECK();
     }
     *At = T;
@@ -407,7 +420,10 @@ __global__ __launch_bounds__(256) void k_spgemm_rows(int nr, int nc, const int* 
         if (tid == 0) {
             int tot = 0;
             for (int w = 0; w < W; ++w) tot += wcnt[w];
-            scan_put(rowcnt, i, tot);
+            if (st.out)
+                scan_put(rowcnt, i, tot);
+            else
+                rowcnt[i] = tot;
         }
         __syncthreads();
     }
@@ -492,35 +508,41 @@ __global__ __launch_bounds__(256) void k_csr_expand(int nr, int ld, const int* _
     }
 }
 
+// R x R outputs per thread, 16 x 16 threads: a (16 R)-edge output tile per workgroup.  R = 4 for large products;
+// R = 2 when 64-edge tiles would leave most of the chip idle (a 330 x 1024 x 330 product is 36 of them, each
+// walking the 1024 inner indices alone: 29 us; 121 tiles of edge 32 take a third of that).  The order of the
+// additions into every C(i,j) does not depend on R.
+template <int R>
 __global__ __launch_bounds__(256) void k_gemm_ordered(int nkp, int ncp,
                                                       const double* __restrict__ X,
                                                       const double* __restrict__ Y,
                                                       double* __restrict__ C) {
     // X: (rows padded to GT) x nkp, Y: nkp x ncp, C: rows x ncp; nkp % GK == 0, ncp % GT == 0
-    __shared__ __attribute__((aligned(16))) double xs[GK][GT];   // transposed: xs[k][row]
-    __shared__ __attribute__((aligned(16))) double ys[GK][GT];
+    constexpr int TE = 16 * R;   // tile edge
+    __shared__ __attribute__((aligned(16))) double xs[GK][TE];   // transposed: xs[k][row]
+    __shared__ __attribute__((aligned(16))) double ys[GK][TE];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int r0 = blockIdx.y * GT, c0 = blockIdx.x * GT;
-    double acc[4][4];
+    const int r0 = blockIdx.y * TE, c0 = blockIdx.x * TE;
+    double acc[R][R];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
-    // fetch roles: X tile 64 rows x 16 k (4 consecutive k per thread), Y tile 16 k x 64 columns
-    const int xr = tid >> 2, xk = (tid & 3) * 4;
-    const int yk = tid >> 4, yc = (tid & 15) * 4;
+        for (int c = 0; c < R; ++c) acc[r][c] = 0.0;
+    // fetch roles: X tile TE rows x 16 k (R consecutive k per thread), Y tile 16 k x TE columns
+    const int xr = tid / (16 / R), xk = (tid % (16 / R)) * R;
+    const int yk = tid >> 4, yc = (tid & 15) * R;
     const double* xp = X + (size_t)(r0 + xr) * nkp + xk;
     const double* yp = Y + (size_t)yk * ncp + c0 + yc;
-    double xf[4], yf[4];
+    double xf[R], yf[R];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < R; ++u) {
         xf[u] = xp[u];
         yf[u] = yp[u];
     }
     for (int k0 = 0; k0 < nkp; k0 += GK) {
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < R; ++u) {
             xs[xk + u][xr] = xf[u];
             ys[yk][yc + u] = yf[u];
         }
@@ -529,33 +551,33 @@ __global__ __launch_bounds__(256) void k_gemm_ordered(int nkp, int ncp,
             xp += GK;
             yp += (size_t)GK * ncp;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < R; ++u) {
                 xf[u] = xp[u];
                 yf[u] = yp[u];
             }
         }
 #pragma unroll
         for (int kk = 0; kk < GK; ++kk) {
-            double a[4], b[4];
+            double a[R], b[R];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = xs[kk][ty * 4 + u];
-                b[u] = ys[kk][tx * 4 + u];
+            for (int u = 0; u < R; ++u) {
+                a[u] = xs[kk][ty * R + u];
+                b[u] = ys[kk][tx * R + u];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < R; ++c) {
                     const double prod = a[r] * b[c];
                     acc[r][c] = acc[r][c] + prod;
                 }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        double* crow = C + (size_t)(r0 + ty * 4 + r) * ncp + c0 + tx * 4;
+    for (int r = 0; r < R; ++r) {
+        double* crow = C + (size_t)(r0 + ty * R + r) * ncp + c0 + tx * R;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) crow[c] = acc[r][c];
+        for (int c = 0; c < R; ++c) crow[c] = acc[r][c];
     }
 }
 
@@ -572,7 +594,12 @@ __global__ __launch_bounds__(256) void k_dense_rowcount(int nr, int nc, int ld,
         for (int j = lane; j < nc; j += 64) nz += (drow[j] != 0.0);
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d);
-        if (lane == 0) scan_put(rowcnt, i, nz);
+        if (lane == 0) {
+            if (st.out)
+                scan_put(rowcnt, i, nz);
+            else
+                rowcnt[i] = nz;
+        }
     }
     scan_tail(st);
 }
@@ -753,11 +780,12 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, in
     size_t tile_bytes = 0;
     const bool tiles = spgemm_prefers_tiles(X, Y, &tile_bytes);
     const int threads = (Y.nr > 0 && (double)Y.nnz / Y.nr >= 96.0) ? 256 : 64;
-    // The row pointers.  Producers with 256-thread workgroups scan their own counts at the end of the launch
-    // (ScanTail: the total stays on the device -- lazy count -- or comes back through the host mailbox).  The
-    // one-wave row kernel leaves plain counts: with a lazy count the compaction scans them on its way in
-    // (scan_head), otherwise a scan launch fetches the total that sizes the arrays.
-    const bool tail = tiles || threads == 256;
+    // The row pointers.  With a lazy count (total_dev) the compaction scans the plain counts on its way in
+    // (scan_head).  Otherwise the host needs the total to size the arrays: producers with 256-thread workgroups
+    // scan their own counts at the end of the launch and post it (ScanTail); the one-wave row kernel is followed
+    // by a scan launch.
+    const bool head_ok = total_dev && nr <= SCAN_HEAD_MAX;
+    const bool tail = !head_ok && (tiles || threads == 256);
     int* rowcnt = tail ? zeroed<int>(ctx, (size_t)nr + 1) : tmp.alloc<int>((size_t)nr + 1);
     ScanTail st;
     std::unique_ptr<TailTotal> tt;
@@ -780,8 +808,12 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, in
                            ctx->stream, X.nr, (int)nkp, X.rp, X.ci, X.va, xd);
         hipLaunchKernelGGL(k_csr_expand, dim3(std::min(cdiv(Y.nr, 4), 4096)), dim3(256), 0,
                            ctx->stream, Y.nr, (int)ncp, Y.rp, Y.ci, Y.va, yd);
-        hipLaunchKernelGGL(k_gemm_ordered, dim3((unsigned)(ncp / GT), (unsigned)(nrp / GT)),
-                           dim3(256), 0, ctx->stream, (int)nkp, (int)ncp, xd, yd, dense);
+        if ((nrp / GT) * (ncp / GT) >= 256)
+            hipLaunchKernelGGL(k_gemm_ordered<4>, dim3((unsigned)(ncp / GT), (unsigned)(nrp / GT)),
+                               dim3(256), 0, ctx->stream, (int)nkp, (int)ncp, xd, yd, dense);
+        else   // few 64-edge tiles: 32-edge ones spread the inner-index walk over four times the CUs
+            hipLaunchKernelGGL(k_gemm_ordered<2>, dim3((unsigned)(ncp / 32), (unsigned)(nrp / 32)),
+                               dim3(256), 0, ctx->stream, (int)nkp, (int)ncp, xd, yd, dense);
         hipLaunchKernelGGL(k_dense_rowcount, dim3(std::min(cdiv(nr, 4), 4096)), dim3(256), 0,
                            ctx->stream, nr, nc, ld, dense, rowcnt, st);
         IPD_KERNEL_CHECK();
@@ -807,8 +839,11 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, in
         IPD_KERNEL_CHECK();
     }
     const int* head = nullptr;   // plain counts the compaction scans itself
-    if (tail) {
-        if (total_dev) {   // lazy count: dense bound, no round trip
+    if (head_ok) {   // lazy count: dense bound, no round trip
+        out.nnz = (int)((size_t)nr * (size_t)nc);
+        head = rowcnt;
+    } else if (tail) {
+        if (total_dev) {
             out.nnz = (int)((size_t)nr * (size_t)nc);
         } else {
             int two[2] = {0, 0};
@@ -817,10 +852,7 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, in
         }
     } else if (total_dev) {
         out.nnz = (int)((size_t)nr * (size_t)nc);
-        if (nr <= SCAN_HEAD_MAX)
-            head = rowcnt;
-        else
-            exclusive_scan_i32(ctx, rowcnt, out.rp, nr, total_dev);
+        exclusive_scan_i32(ctx, rowcnt, out.rp, nr, total_dev);
     } else {
         out.nnz = exclusive_scan_total(ctx, rowcnt, out.rp, nr);
     }
