@@ -62,15 +62,13 @@ __global__ __launch_bounds__(BT) void k_top(TopArgs a) {
 }
 
 // padded off-diagonal copy of a CSR matrix: one wave per row
-__global__ __launch_bounds__(256) void k_pad_build(int N, int S, const int* __restrict__ rp,
-                                                   const int* __restrict__ ci,
-                                                   const double* __restrict__ va,
-                                                   unsigned short* __restrict__ pci,
-                                                   double* __restrict__ pva,
-                                                   double* __restrict__ diag) {
+__device__ __forceinline__ void pad_build_rows(int vb, int nvb, int N, int S, const int* __restrict__ rp,
+                                               const int* __restrict__ ci, const double* __restrict__ va,
+                                               unsigned short* __restrict__ pci, double* __restrict__ pva,
+                                               double* __restrict__ diag) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int wave = (vb * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (nvb * blockDim.x) >> 6;
     for (int r = wave; r < N; r += nwaves) {
         const int b = rp[r], e = rp[r + 1];
         int dpos = 0x7fffffff;
@@ -93,6 +91,30 @@ __global__ __launch_bounds__(256) void k_pad_build(int N, int S, const int* __re
         }
         if (lane == 0) diag[r] = hasd ? va[dpos] : 0.0;
     }
+}
+__global__ __launch_bounds__(256) void k_pad_build(int N, int S, const int* __restrict__ rp,
+                                                   const int* __restrict__ ci,
+                                                   const double* __restrict__ va,
+                                                   unsigned short* __restrict__ pci,
+                                                   double* __restrict__ pva,
+                                                   double* __restrict__ diag) {
+    pad_build_rows(blockIdx.x, gridDim.x, N, S, rp, ci, va, pci, pva, diag);
+}
+// the padded copies of all the levels of a hierarchy in one launch (blockIdx.y = entry)
+constexpr int PAD_BATCH = 8;
+struct PadBatch {
+    int n = 0;
+    int N[PAD_BATCH], S[PAD_BATCH];
+    const int* rp[PAD_BATCH];
+    const int* ci[PAD_BATCH];
+    const double* va[PAD_BATCH];
+    unsigned short* pci[PAD_BATCH];
+    double* pva[PAD_BATCH];
+    double* diag[PAD_BATCH];
+};
+__global__ __launch_bounds__(256) void k_pad_build_batch(const PadBatch b) {
+    const int q = blockIdx.y;
+    pad_build_rows(blockIdx.x, gridDim.x, b.N[q], b.S[q], b.rp[q], b.ci[q], b.va[q], b.pci[q], b.pva[q], b.diag[q]);
 }
 
 // hist[0] = res0 (set on the first call), hist[1] = res, hist[2] = previous res,

@@ -198,9 +198,18 @@ static int pick_blocks(int nrows, int L, int cu);
 
 // Builds the padded off-diagonal copy when the level is big and regular enough
 // (see ipd_cycle_phases.h, item 2) and adapts the launch geometry to it.
+static void pad_flush(ipd_ctx* ctx, PadBatch* b) {
+    if (b->n == 0) return;
+    int rows = 1;
+    for (int q = 0; q < b->n; ++q) rows = std::max(rows, b->N[q]);
+    hipLaunchKernelGGL(k_pad_build_batch, dim3(std::max(1, std::min(cdiv(rows, 4), 4096)), b->n), dim3(256), 0,
+                       ctx->stream, *b);
+    IPD_KERNEL_CHECK();
+    b->n = 0;
+}
 static void build_padded(ipd_ctx* ctx, Arena& ar, const Csr& A, int rows_per_launch, int cu,
                          int maxlen /* longest off-diagonal row, from k_level_prepare */,
-                         LevelDev* dev) {
+                         LevelDev* dev, PadBatch* batch) {
     dev->S = 0;
     dev->pci = nullptr;
     dev->pva = nullptr;
@@ -212,15 +221,23 @@ static void build_padded(ipd_ctx* ctx, Arena& ar, const Csr& A, int rows_per_lau
     // small levels too: one dependent round trip less per launch (measured -6 % solve time on
     // the m=n=1024 Class 1 run)
     if (avg_off < 0.5) return;
-    const int grid = std::max(1, std::min(cdiv(A.nr, 4), 4096));
     const int S = (maxlen + 3) / 4 * 4;
     if (S == 0 || (double)S > 1.3 * avg_off + 16.0) return;
     unsigned short* pci = ar.alloc<unsigned short>((size_t)A.nr * S);
     double* pva = ar.alloc<double>((size_t)A.nr * S);
     double* diag = ar.alloc<double>((size_t)A.nr);
-    hipLaunchKernelGGL(k_pad_build, dim3(grid), dim3(256), 0, ctx->stream, A.nr, S, A.rp, A.ci, A.va,
-                       pci, pva, diag);
-    IPD_KERNEL_CHECK();
+    {   // (launched with the other levels' copies: pad_flush)
+        if (batch->n == PAD_BATCH) pad_flush(ctx, batch);
+        const int q = batch->n++;
+        batch->N[q] = A.nr;
+        batch->S[q] = S;
+        batch->rp[q] = A.rp;
+        batch->ci[q] = A.ci;
+        batch->va[q] = A.va;
+        batch->pci[q] = pci;
+        batch->pva[q] = pva;
+        batch->diag[q] = diag;
+    }
     dev->S = S;
     dev->pci = pci;
     dev->pva = pva;
@@ -833,6 +850,7 @@ void amg_prepare_levels(ipd_amg* h) {
     }
     std::vector<int> hmax((size_t)h->J + 1);
     ctx->fetch(maxoff, hmax.data(), (size_t)h->J + 1);
+    PadBatch pads;   // the levels' padded copies: one launch after the loop
     for (int k = 1; k <= h->J; ++k) {
         Level& lv = h->L[k];
         const int N = lv.N;
@@ -868,10 +886,11 @@ void amg_prepare_levels(ipd_amg* h) {
             rn.dev.G = dd.G;
             lv.lanes = donor->L[k].lanes;
         } else {
-            build_padded(ctx, ar, lv.A, rows_per_launch, cu, hmax[(size_t)k], &rn.dev);
+            build_padded(ctx, ar, lv.A, rows_per_launch, cu, hmax[(size_t)k], &rn.dev, &pads);
         rn.maxoff = hmax[(size_t)k];
         }
     }
+    pad_flush(ctx, &pads);
     for (int k = 1; k < h->J; ++k) {
         Level& fine = h->L[k];
         Level& coarse = h->L[k + 1];
@@ -1345,36 +1364,46 @@ void amg_prepare_levels(ipd_amg* h) {
         sd->nreloc = (int)relocs.size();
         *lds_total = off;
         char* img = reinterpret_cast<char*>(ar.alloc_bytes(image_bytes));
-        std::vector<char> head(SOL_HEAD, 0);
-        std::memcpy(head.data(), sd, sizeof(SolveDesc));
-        std::memcpy(head.data() + r16(sizeof(SolveDesc)), relocs.data(), relocs.size() * sizeof(unsigned));
-        ctx->upload_bytes(img, head.data(), SOL_HEAD);
-        for (PackEntry& e : packs) e.dst_off += 0;   // offsets are relative to the image start
-        PackEntry* dents = ctx->scratch->alloc<PackEntry>(packs.size());
-        ctx->upload_bytes(dents, packs.data(), packs.size() * sizeof(PackEntry));
+        // the image head and the pack descriptors go up in ONE copy: [head | packs | dense | lmaps | polys] in
+        // a scratch block, the head then moves into the image as one more entry of k_pack_image
+        auto r16b = [](size_t v) { return (v + 15) & ~size_t(15); };
+        const size_t o_packs = r16b(SOL_HEAD), o_dense = o_packs + r16b((packs.size() + 1) * sizeof(PackEntry)),
+                     o_lmaps = o_dense + r16b(dense.size() * sizeof(DenseEntry)),
+                     o_polys = o_lmaps + r16b(lmaps.size() * sizeof(LmapEntry)),
+                     o_end = o_polys + r16b(polys.size() * sizeof(PolyEntry));
+        char* stg = reinterpret_cast<char*>(ctx->scratch->alloc_bytes(o_end));
+        std::vector<char> hb(o_end, 0);
+        std::memcpy(hb.data(), sd, sizeof(SolveDesc));
+        std::memcpy(hb.data() + r16(sizeof(SolveDesc)), relocs.data(), relocs.size() * sizeof(unsigned));
+        {
+            PackEntry he{};
+            he.src = stg;
+            he.dst_off = 0;
+            he.bytes = (unsigned)SOL_HEAD;
+            packs.push_back(he);
+        }
+        std::memcpy(hb.data() + o_packs, packs.data(), packs.size() * sizeof(PackEntry));
+        if (!dense.empty()) std::memcpy(hb.data() + o_dense, dense.data(), dense.size() * sizeof(DenseEntry));
+        if (!lmaps.empty()) std::memcpy(hb.data() + o_lmaps, lmaps.data(), lmaps.size() * sizeof(LmapEntry));
+        if (!polys.empty()) std::memcpy(hb.data() + o_polys, polys.data(), polys.size() * sizeof(PolyEntry));
+        ctx->upload_bytes(stg, hb.data(), o_end);
         hipLaunchKernelGGL(k_pack_image, dim3((unsigned)packs.size()), dim3(256), 0, ctx->stream,
-                           (const PackEntry*)dents, img);
+                           reinterpret_cast<const PackEntry*>(stg + o_packs), img);
         IPD_KERNEL_CHECK();
         if (!dense.empty()) {
-            DenseEntry* dd = ctx->scratch->alloc<DenseEntry>(dense.size());
-            ctx->upload_bytes(dd, dense.data(), dense.size() * sizeof(DenseEntry));
             hipLaunchKernelGGL(k_pack_dense, dim3((unsigned)dense.size()), dim3(256), 0, ctx->stream,
-                               (const DenseEntry*)dd, img);
+                               reinterpret_cast<const DenseEntry*>(stg + o_dense), img);
             IPD_KERNEL_CHECK();
         }
         if (!lmaps.empty()) {
-            LmapEntry* lp = ctx->scratch->alloc<LmapEntry>(lmaps.size());
-            ctx->upload_bytes(lp, lmaps.data(), lmaps.size() * sizeof(LmapEntry));
             hipLaunchKernelGGL(k_pack_lmap, dim3((unsigned)lmaps.size()), dim3(BT), 0, ctx->stream,
-                               (const LmapEntry*)lp, img);
+                               reinterpret_cast<const LmapEntry*>(stg + o_lmaps), img);
             IPD_KERNEL_CHECK();
         }
         if (!polys.empty()) {
-            PolyEntry* pp = ctx->scratch->alloc<PolyEntry>(polys.size());
-            ctx->upload_bytes(pp, polys.data(), polys.size() * sizeof(PolyEntry));
             IPD_OPTIN_LDS(ctx, k_pack_poly, 156 * 1024);
             hipLaunchKernelGGL(k_pack_poly, dim3((unsigned)polys.size()), dim3(BT), poly_lds, ctx->stream,
-                               (const PolyEntry*)pp, img);
+                               reinterpret_cast<const PolyEntry*>(stg + o_polys), img);
             IPD_KERNEL_CHECK();
         }
         st->level_forms.resize((size_t)h->J + 1, 0);

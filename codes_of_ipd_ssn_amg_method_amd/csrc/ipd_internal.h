@@ -303,6 +303,14 @@ struct TailTotal {
         IPD_REQUIRE(two[0] >= 0 && two[1] >= 0, IPD_E_HIP, "row-pointer scan: a count never arrived");
     }
 };
+// csr_spgemm(..., post): the compaction of a lazily counted product posts post->n device words starting at
+// post->src to the host mailbox (box != NULL afterwards: wait for post->ticket; else fetch them)
+struct LazyPost {
+    const int* src = nullptr;
+    int n = 0;
+    volatile unsigned* box = nullptr;
+    unsigned ticket = 0;
+};
 static inline ScanTail scan_tail_lazy(const int* in, int* out, int n, int* total_dev) {
     ScanTail t;
     t.in = in;
@@ -449,8 +457,8 @@ struct ScanHeadLds {
     int rp[SCAN_HEAD_MAX + 1];
     int wsum[4];
 };
-__device__ __forceinline__ void scan_head(const int* __restrict__ cnt, int n, int* rp_out, int* total_out,
-                                          ScanHeadLds& L) {
+__device__ __forceinline__ int scan_head(const int* __restrict__ cnt, int n, int* rp_out, int* total_out,
+                                         ScanHeadLds& L) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int C = (n + 255) >> 8;   // a contiguous chunk per thread, at most 16 entries
     int v[SCAN_HEAD_MAX / 256];
@@ -489,6 +497,7 @@ __device__ __forceinline__ void scan_head(const int* __restrict__ cnt, int n, in
         for (int i = tid; i <= n; i += 256) rp_out[i] = L.rp[i];
         if (tid == 0 && total_out) *total_out = carry;
     }
+    return carry;
 }
 #endif
 
@@ -521,7 +530,8 @@ void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n);
 // caller has checked SPGEMM_LAZY_MAX), C->nnz is that bound until the caller has fetched *total_dev; the nnz of
 // X and Y are then only read by the kernel-choice heuristic (estimates will do: both kernels give the same bits)
 constexpr size_t SPGEMM_LAZY_MAX = size_t(1) << 21;
-void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, int* total_dev = nullptr);
+void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, int* total_dev = nullptr,
+                LazyPost* post = nullptr);
 void csr_expand_dense(ipd_ctx* ctx, const Csr& A, double* dense, int ld);  // dense pre-zeroed
 // st.out != NULL: rowcnt is zeroed<int> and the launch's tail scans the (biased) counts into st.out (nr > 0);
 // an empty st leaves plain counts

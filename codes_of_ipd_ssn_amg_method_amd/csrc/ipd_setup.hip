@@ -1331,21 +1331,25 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
     const bool lazy_prod = hint && hint[1] > 0 && hint[2] > 0 && (lazy || P.nnz >= 0) &&
                            (size_t)Ncc * (size_t)N <= SPGEMM_LAZY_MAX && (size_t)Ncc * (size_t)Ncc <= SPGEMM_LAZY_MAX;
     if (lazy_prod) {
-        int* c3 = lazy ? counts : tmp.alloc<int>(4);
+        int* c3 = lazy ? counts : zeroed<int>(ctx, 4);
         Csr Pe = P, Pte = Pt;
         if (lazy) Pe.nnz = Pte.nnz = std::max(1, std::min(hint[0], P.nnz));   // (estimates for the heuristic only)
         csr_spgemm(ctx, T1out ? dst : tmp, Pte, A, &T1, c3 + 1);
         Csr T1e = T1;
         T1e.nnz = std::max(1, std::min(hint[1], T1.nnz));
-        csr_spgemm(ctx, dst, T1e, Pe, &C, c3 + 2);
+        LazyPost post;   // the level's counts ride back on the last compaction
+        post.src = c3;
+        post.n = 4;
+        csr_spgemm(ctx, dst, T1e, Pe, &C, c3 + 2, &post);
         int h3[4] = {0, 0, 0, 0};
-        if (lazy) {
+        if (post.box)
+            ctx->mailbox_wait(post.ticket, h3, sizeof(h3));
+        else
             ctx->fetch(c3, h3, 4);
+        if (lazy) {
             P.nnz = Pt.nnz = h3[0];
             IPD_REQUIRE(h3[3] == 0, IPD_E_UNSUPPORTED,
                         "transfer: bigph level 1 needs a diagonal Aff block (transfer.m:20-21)");
-        } else {
-            ctx->fetch(c3 + 1, h3 + 1, 2);
         }
         T1.nnz = h3[1];
         C.nnz = h3[2];

@@ -116,16 +116,27 @@ Csr csr_alloc(Arena& a, int nr, int nc, int nnz) {
     return m;
 }
 
+// the three arrays in one launch (three copies cost three dispatches and their gaps)
+__global__ __launch_bounds__(256) void k_csr_copy(int nr1, int nnz, const int* __restrict__ rp,
+                                                  const int* __restrict__ ci, const double* __restrict__ va,
+                                                  int* __restrict__ orp, int* __restrict__ oci,
+                                                  double* __restrict__ ova) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)nnz; i += stride) {
+        oci[i] = ci[i];
+        ova[i] = va[i];
+        if (i < (size_t)nr1) orp[i] = rp[i];
+    }
+    for (size_t i = (size_t)nnz + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)nr1; i += stride)
+        orp[i] = rp[i];
+}
+
 void csr_copy(ipd_ctx* ctx, Arena& dst, const Csr& A, Csr* out) {
     Csr m = csr_alloc(dst, A.nr, A.nc, A.nnz);
-    IPD_HIP(hipMemcpyAsync(m.rp, A.rp, sizeof(int) * ((size_t)A.nr + 1), hipMemcpyDeviceToDevice,
-                           ctx->stream));
-    if (A.nnz) {
-        IPD_HIP(hipMemcpyAsync(m.ci, A.ci, sizeof(int) * (size_t)A.nnz, hipMemcpyDeviceToDevice,
-                               ctx->stream));
-        IPD_HIP(hipMemcpyAsync(m.va, A.va, sizeof(double) * (size_t)A.nnz,
-                               hipMemcpyDeviceToDevice, ctx->stream));
-    }
+    const size_t n = std::max<size_t>((size_t)A.nnz, (size_t)A.nr + 1);
+    hipLaunchKernelGGL(k_csr_copy, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0,
+                       ctx->stream, A.nr + 1, A.nnz, A.rp, A.ci, A.va, m.rp, m.ci, m.va);
+    IPD_KERNEL_CHECK();
     *out = m;
 }
 
@@ -439,13 +450,21 @@ __global__ __launch_bounds__(256) void k_dense_compact(int nr, int nc, int ld,
                                                        int* __restrict__ ci,
                                                        double* __restrict__ va,
                                                        const int* __restrict__ head_cnt, int* head_rp,
-                                                       int* head_total) {
+                                                       int* head_total, const LazyPost post) {
     // head_cnt != NULL: the row pointers are still plain counts -- every workgroup scans them for itself and
-    // workgroup 0 stores them at head_rp (scan_head, ipd_internal.h; nr <= SCAN_HEAD_MAX)
+    // workgroup 0 stores them at head_rp (scan_head, ipd_internal.h; nr <= SCAN_HEAD_MAX).  post.box != NULL:
+    // workgroup 0 then posts post.n device words (the level's lazy counts, this product's total among them)
+    // to the host mailbox -- the fetch that would follow, without its launch.
     __shared__ ScanHeadLds L;
     if (head_cnt) {
-        scan_head(head_cnt, nr, head_rp, head_total, L);
+        const int total = scan_head(head_cnt, nr, head_rp, head_total, L);
         rp = L.rp;
+        if (post.box && blockIdx.x == 0 && threadIdx.x == 0) {
+            for (int w = 0; w < post.n; ++w)
+                post.box[16 + w] = post.src + w == head_total ? (unsigned)total : (unsigned)post.src[w];
+            __threadfence_system();
+            post.box[0] = post.ticket;
+        }
     }
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -494,6 +513,28 @@ __global__ __launch_bounds__(256) void k_dense_compact(int nr, int nc, int ld,
 // unit is compiled with -ffp-contract=off: multiply, round, add, round).
 constexpr int GT = 64;   // output tile edge
 constexpr int GK = 16;   // inner-index tile
+
+// both operands of a tile product in one launch (blockIdx.y picks the matrix)
+struct ExpandPair {
+    int nr[2], ld[2];
+    const int* rp[2];
+    const int* ci[2];
+    const double* va[2];
+    double* dense[2];
+};
+__global__ __launch_bounds__(256) void k_csr_expand2(const ExpandPair e) {
+    const int q = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int* __restrict__ rp = e.rp[q];
+    const int* __restrict__ ci = e.ci[q];
+    const double* __restrict__ va = e.va[q];
+    for (int i = wave; i < e.nr[q]; i += nwaves) {
+        double* drow = e.dense[q] + (size_t)i * e.ld[q];
+        for (int t = rp[i] + lane; t < rp[i + 1]; t += 64) drow[ci[t]] = va[t];
+    }
+}
 
 __global__ __launch_bounds__(256) void k_csr_expand(int nr, int ld, const int* __restrict__ rp,
                                                     const int* __restrict__ ci,
@@ -731,12 +772,13 @@ __global__ __launch_bounds__(64) void k_spgemm_rows_w(int nr, int nc, const int*
 
 static inline size_t round_up(size_t v, size_t q) { return (v + q - 1) / q * q; }
 
-// Which product kernel is expected to finish first.  The row kernel is a dependent chain per
-// output row: one step per entry of X's row, each step a pass over a row of Y plus a barrier
-// (about 0.35 us + 0.25 us per 256 entries, measured on MI355X), with rows spread over the CUs
-// as LDS allows.  The tile kernel walks the padded rows x inner x columns box at about 0.9 us
-// per 16 inner indices per wave of 256 tiles, plus the expansion of the operands.
-// IPD_PRODUCT=rows|tiles overrides the choice (tests compare the two bit for bit).
+// Which product kernel is expected to finish first (measured on MI355X, round 4).  The row kernels are a
+// dependent chain per output row, one step per entry of X's row: the one-wave kernel (short rows of Y) takes
+// about 0.16 us per entry with the rows of Y prefetched eight deep, the 256-thread kernel 0.35 us + 0.25 us per
+// 256 entries of Y's row with a barrier per step; rows are spread over the CUs as LDS allows.  The tile kernel
+// walks the padded rows x inner x columns box 16 inner indices at a time -- about 0.9 us per step and wave of
+// 256 64-edge tiles, 0.23 us with the 32-edge tiles small products get -- plus 20-40 us for the expansion of
+// the operands and the row count.  IPD_PRODUCT=rows|tiles overrides the choice (tests compare the two bit for bit).
 static bool spgemm_prefers_tiles(const Csr& X, const Csr& Y, size_t* bytes) {
     const size_t nrp = round_up((size_t)X.nr, GT), nkp = round_up((size_t)X.nc, GT),
                  ncp = round_up((size_t)Y.nc, GT);
@@ -748,16 +790,19 @@ static bool spgemm_prefers_tiles(const Csr& X, const Csr& Y, size_t* bytes) {
         if (!strcmp(e, "rows")) return false;
     }
     const double xlen = (double)X.nnz / X.nr, ylen = (double)Y.nnz / Y.nr;
-    const double lds_rows = std::max(1.0, std::min(8.0, 160.0 * 1024 / (8.0 * Y.nc + 64)));
+    const double lds_rows = std::max(1.0, std::min(ylen < 96.0 ? 32.0 : 8.0, 160.0 * 1024 / (8.0 * Y.nc + 64)));
     const double row_rounds = std::ceil(X.nr / (256.0 * lds_rows));
-    const double t_rows = row_rounds * xlen * (0.35 + 0.25 * std::ceil(ylen / 256.0));
+    const double t_rows = row_rounds * xlen * (ylen < 96.0 ? 0.16 : 0.35 + 0.25 * std::ceil(ylen / 256.0));
     const double tiles = (double)(nrp / GT) * (double)(ncp / GT);
-    const double t_tiles = 40.0 + std::ceil(tiles / 256.0) * (double)(nkp / GK) * 0.9 +
-                           (double)*bytes / 3.0e6;   // memset + expand + rowcount at ~3 TB/s
+    const double steps = (double)(nkp / GK);
+    const double t_walk = tiles >= 256.0 ? 20.0 + std::ceil(tiles / 256.0) * steps * 0.9
+                                         : std::ceil(4.0 * tiles / 1024.0) * steps * 0.23;
+    const double t_tiles = 20.0 + t_walk + (double)*bytes / 3.0e6;   // (operand block zeroed and written at ~3 TB/s)
     return t_tiles < t_rows;
 }
 
-void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, int* total_dev) {
+void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, int* total_dev, LazyPost* post) {
+    if (post) post->box = nullptr;
     IPD_REQUIRE(X.nc == Y.nr, IPD_E_ARG, "spgemm: inner dimensions differ");
     const int nr = X.nr, nc = Y.nc;
     Arena& tmp = *ctx->scratch;
@@ -804,10 +849,11 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, in
         double* yd = xd + nrp * nkp;
         dense = tmp.alloc<double>(nrp * ncp);
         ld = (int)ncp;
-        hipLaunchKernelGGL(k_csr_expand, dim3(std::min(cdiv(X.nr, 4), 4096)), dim3(256), 0,
-                           ctx->stream, X.nr, (int)nkp, X.rp, X.ci, X.va, xd);
-        hipLaunchKernelGGL(k_csr_expand, dim3(std::min(cdiv(Y.nr, 4), 4096)), dim3(256), 0,
-                           ctx->stream, Y.nr, (int)ncp, Y.rp, Y.ci, Y.va, yd);
+        ExpandPair ep;
+        ep.nr[0] = X.nr, ep.ld[0] = (int)nkp, ep.rp[0] = X.rp, ep.ci[0] = X.ci, ep.va[0] = X.va, ep.dense[0] = xd;
+        ep.nr[1] = Y.nr, ep.ld[1] = (int)ncp, ep.rp[1] = Y.rp, ep.ci[1] = Y.ci, ep.va[1] = Y.va, ep.dense[1] = yd;
+        hipLaunchKernelGGL(k_csr_expand2, dim3(std::max(1, std::min(cdiv(std::max(X.nr, Y.nr), 4), 4096)), 2),
+                           dim3(256), 0, ctx->stream, ep);
         if ((nrp / GT) * (ncp / GT) >= 256)
             hipLaunchKernelGGL(k_gemm_ordered<4>, dim3((unsigned)(ncp / GT), (unsigned)(nrp / GT)),
                                dim3(256), 0, ctx->stream, (int)nkp, (int)ncp, xd, yd, dense);
@@ -859,9 +905,14 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, in
     out.ci = dst.alloc<int>((size_t)out.nnz);
     out.va = dst.alloc<double>((size_t)out.nnz);
     if (out.nnz || head) {
+        LazyPost lp;
+        if (post && head && post->n <= 32 && ctx->mailbox_begin(&post->ticket)) {
+            post->box = ctx->mailbox;
+            lp = *post;
+        }
         hipLaunchKernelGGL(k_dense_compact, dim3(std::max(1, std::min(cdiv(nr, 4), 4096))), dim3(256),
                            0, ctx->stream, nr, nc, ld, dense, (const unsigned long long*)rowbits,
-                           (const int*)out.rp, out.ci, out.va, head, out.rp, total_dev);
+                           (const int*)out.rp, out.ci, out.va, head, out.rp, total_dev, lp);
         IPD_KERNEL_CHECK();
     }
     *C = out;
@@ -887,7 +938,7 @@ void dense_compact(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, co
     if (nr == 0 || out.nnz == 0) return;
     hipLaunchKernelGGL(k_dense_compact, dim3(std::max(1, std::min(cdiv(nr, 4), 4096))), dim3(256), 0,
                        ctx->stream, nr, nc, ld, dense, (const unsigned long long*)nullptr, (const int*)out.rp,
-                       out.ci, out.va, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+                       out.ci, out.va, (const int*)nullptr, (int*)nullptr, (int*)nullptr, LazyPost());
     IPD_KERNEL_CHECK();
 }
 
