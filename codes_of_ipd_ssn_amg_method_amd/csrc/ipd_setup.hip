@@ -886,6 +886,156 @@ __global__ __launch_bounds__(256) void k_build_W(int N, int Nc, const int* __res
     }
 }
 
+// The same rows with ONE WAVE per row, pipelined (the form of k_spgemm_rows_w).  k_build_W's loop over the
+// strong F neighbours k is a chain of four dependent global round trips and a barrier per neighbour -- column,
+// then diag / row range of k, then k's entries, then their C flags and indices: 0.5 us each, 44 us for the
+// 90-entry rows of a 100-row level.  Here the lanes read the metadata of 64 entries of row i at once; the
+// strong F neighbours are listed in LDS in ascending order, a row of k longer than 64 entries as up to four
+// consecutive 64-entry pieces; and the pieces D ahead -- already filtered to C columns and divided by -a_kk --
+// are in flight while the current D are applied.  Every acc2[c] still receives x(i,k) * w1(k,c) one term at a
+// time in ascending k (the pieces of one k touch distinct columns), and a wave's LDS operations execute in
+// program order: the bits equal k_build_W's.
+constexpr int BW_PIECES = 4;   // 64-entry pieces of a neighbour's row that are prefetched (the rest: a plain loop)
+template <int D>
+__global__ __launch_bounds__(64) void k_build_W_w(int N, int Nc, const int* __restrict__ rp,
+                                                  const int* __restrict__ ci,
+                                                  const double* __restrict__ va,
+                                                  const double* __restrict__ diag,
+                                                  const uint8_t* __restrict__ strong,
+                                                  const uint8_t* __restrict__ isC,
+                                                  const uint8_t* __restrict__ isF,
+                                                  const int* __restrict__ cidx,
+                                                  double* __restrict__ dense,
+                                                  int* __restrict__ rowcnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* acc2 = reinterpret_cast<double*>(smem_raw);
+    double* acc1 = acc2 + Nc;
+    __shared__ int s_yb[64 * BW_PIECES], s_yn[64 * BW_PIECES], s_te[64 * BW_PIECES];
+    __shared__ double s_x[64 * BW_PIECES], s_nd[64 * BW_PIECES];
+    const int lane = threadIdx.x;
+    for (int i = blockIdx.x; i < N; i += gridDim.x) {
+        double* drow = dense + (size_t)i * Nc;
+        if (isC[i]) {  // identity row of P = [W; I]
+            const int me = cidx[i];
+            for (int c = lane; c < Nc; c += 64) drow[c] = (c == me) ? 1.0 : 0.0;
+            if (lane == 0) rowcnt[i] = 1;
+            continue;
+        }
+        for (int c = lane; c < Nc; c += 64) {
+            acc1[c] = 0.0;
+            acc2[c] = 0.0;
+        }
+        __syncthreads();
+        const double ndi = -diag[i];
+        const int b = rp[i], e = rp[i + 1];
+        for (int e0 = b; e0 < e; e0 += 64) {
+            const int t = e0 + lane;
+            const bool mine = t < e;
+            const int kk = mine ? ci[t] : 0;
+            const double av = mine ? va[t] : 0.0;
+            const bool kC = mine && isC[kk];
+            const bool take = mine && isF[kk] && (kk == i || strong[t]);
+            const double xq = av / ndi;                    // W1(i, .) entry or X(i, k)
+            if (kC) acc1[cidx[kk]] = xq;
+            // the strong F neighbours of this batch in ascending order, a row of more than 64 entries as pieces
+            const int yb0 = take ? rp[kk] : 0;
+            const int ylen = take ? rp[kk + 1] - yb0 : 0;
+            const int npc = take ? min(BW_PIECES, (ylen + 63) >> 6) : 0;
+            int r0 = npc;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(r0, d);
+                if (lane >= d) r0 += y;
+            }
+            const int cnt = __shfl(r0, 63);
+            r0 -= npc;
+            if (take) {
+                const double ndk = -diag[kk];
+                for (int c = 0; c < npc; ++c) {
+                    s_yb[r0 + c] = yb0 + 64 * c;
+                    s_yn[r0 + c] = min(64, ylen - 64 * c);
+                    s_te[r0 + c] = (c == npc - 1 && ylen > 64 * BW_PIECES) ? yb0 + ylen : 0;
+                    s_x[r0 + c] = xq;
+                    s_nd[r0 + c] = ndk;
+                }
+            }
+            __syncthreads();
+            int jA[D], jB[D], tA[D], tB[D];
+            double vA[D], vB[D], xA[D], xB[D];
+            // pieces u0 .. u0+D-1: C column index (or -1) and w1 = a_kj / -a_kk of the lane's entry; x(i,k) and the
+            // long-row mark ride along, so that applying a piece is one LDS read-add-write and nothing else
+            auto load = [&](int u0, int* jj, double* vv, double* xs, int* ts) __attribute__((always_inline)) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int u = u0 + d;   // uniform
+                    jj[d] = -1;
+                    vv[d] = 0.0;
+                    xs[d] = 0.0;
+                    ts[d] = 0;
+                    if (u < cnt) {
+                        const int bb = s_yb[u], n = s_yn[u];
+                        xs[d] = s_x[u];
+                        ts[d] = s_te[u];
+                        if (lane < n) {
+                            const int j = ci[bb + lane];
+                            if (isC[j]) {
+                                jj[d] = cidx[j];
+                                vv[d] = va[bb + lane] / s_nd[u];
+                            }
+                        }
+                    }
+                }
+            };
+            auto apply = [&](int u0, const int* jj, const double* vv, const double* xs, const int* ts)
+                             __attribute__((always_inline)) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int u = u0 + d;   // uniform
+                    if (u < cnt) {
+                        const double x = xs[d];
+                        if (jj[d] >= 0) {
+                            const double prod = x * vv[d];
+                            acc2[jj[d]] = acc2[jj[d]] + prod;
+                        }
+                        const int te = ts[d];
+                        if (te) {   // the rest of a very long row (distinct columns: lane order is free)
+                            const double ndk = s_nd[u];
+                            for (int q = s_yb[u] + 64 + lane; q < te; q += 64) {
+                                const int j = ci[q];
+                                if (isC[j]) {
+                                    const double w1 = va[q] / ndk;
+                                    const double prod = x * w1;
+                                    const int c = cidx[j];
+                                    acc2[c] = acc2[c] + prod;
+                                }
+                            }
+                        }
+                    }
+                }
+            };
+            load(0, jA, vA, xA, tA);
+            for (int u0 = 0; u0 < cnt; u0 += 2 * D) {
+                load(u0 + D, jB, vB, xB, tB);
+                apply(u0, jA, vA, xA, tA);
+                load(u0 + 2 * D, jA, vA, xA, tA);
+                apply(u0 + D, jB, vB, xB, tB);
+            }
+            __syncthreads();   // (the lists are rewritten by the next batch)
+        }
+        int nz = 0;
+        for (int c = lane; c < Nc; c += 64) {
+            const double half = 0.5 * acc2[c];
+            const double v = acc1[c] + half;
+            drow[c] = v;
+            nz += (v != 0.0);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d);
+        if (lane == 0) rowcnt[i] = nz;
+        __syncthreads();
+    }
+}
+
 // The same rows through the ordered product of ipd_sparse.hip, for levels whose rows are long
 // (filled-in level 2 under dense masks): W1 and X are written as CSR matrices over all N rows
 // (C rows empty), W2 = X*W1 is one csr_spgemm (which switches to register tiles when that is
@@ -1182,8 +1332,9 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         const size_t dense_elems = (size_t)N * (size_t)Nc;
         IPD_REQUIRE(dense_elems * 8 <= (size_t(2) << 30), IPD_E_LIMIT,
                     "transfer: dense interpolation scratch above 2 GiB");
-        // long rows: the product form (see k_w_split_count); short rows: one kernel
-        bool split = (double)A.nnz / std::max(N, 1) >= 64.0;
+        // very long rows (filled-in level 2 under dense masks): the product form (see k_w_split_count), whose
+        // product can run on register tiles; otherwise one kernel (k_build_W_w)
+        bool split = (double)A.nnz / std::max(N, 1) >= 256.0;
         if (const char* e = getenv("IPD_INTERP")) split = !strcmp(e, "split");
         // (the product form adds into rows that start out as zeros)
         double* dense = (split && o.inter < 2) ? zeroed<double>(ctx, dense_elems) : tmp.alloc<double>(dense_elems);
@@ -1290,11 +1441,19 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
             IPD_KERNEL_CHECK();
             dense_rowcount(ctx, N, Nc, Nc, dense, rowcnt, pt);
         } else {
-            IPD_OPTIN_LDS(ctx, k_build_W, 128 * 1024);
-            const int bw_threads = (double)A.nnz / std::max(N, 1) >= 96.0 ? 256 : 64;
-            hipLaunchKernelGGL(k_build_W, dim3(std::min(N, 16384)), dim3(bw_threads),
-                               (size_t)Nc * 16, ctx->stream, N, Nc, A.rp, A.ci, A.va, diag, strong,
-                               isC, isF, cidx, dense, rowcnt);
+            const char* bwe = getenv("IPD_INTERP");
+            if (bwe && !strcmp(bwe, "block")) {   // (the barrier-per-neighbour form, kept for the bit-for-bit tests)
+                const bool wide = (double)A.nnz / std::max(N, 1) >= 96.0;
+                IPD_OPTIN_LDS(ctx, k_build_W, 128 * 1024);
+                hipLaunchKernelGGL(k_build_W, dim3(std::min(N, 16384)), dim3(wide ? 256 : 64),
+                                   (size_t)Nc * 16, ctx->stream, N, Nc, A.rp, A.ci, A.va, diag, strong,
+                                   isC, isF, cidx, dense, rowcnt);
+            } else {
+                IPD_OPTIN_LDS(ctx, k_build_W_w<8>, 128 * 1024);
+                hipLaunchKernelGGL(k_build_W_w<8>, dim3(std::min(N, 16384)), dim3(64),
+                                   (size_t)Nc * 16, ctx->stream, N, Nc, A.rp, A.ci, A.va, diag, strong,
+                                   isC, isF, cidx, dense, rowcnt);
+            }
             IPD_KERNEL_CHECK();
         }
         const int* head = nullptr;   // plain counts the compaction scans itself

@@ -254,6 +254,27 @@ def test_hierarchy_bit_exact_split_interpolation(ipd, monkeypatch, name, m, n, m
     h.close()
 
 
+@pytest.mark.parametrize("name,m,n,mk,t", CASES, ids=[c[0] for c in CASES])
+def test_hierarchy_bit_exact_block_interpolation(ipd, monkeypatch, name, m, n, mk, t):
+    """The interpolation build by k_build_W (a workgroup per row, a barrier per strong F neighbour: the form
+    rows of 96 entries and more still take) forced on every setup case; the default for shorter rows is the
+    pipelined one-wave kernel k_build_W_w, which the unforced tests above compare with the oracle."""
+    monkeypatch.setenv("IPD_INTERP", "block")
+    s = mk()
+    Ae, pd = newton_matrix(m, n, s)
+    lab = sp.csgraph.connected_components(Ae)[1]
+    pk = np.flatnonzero(lab == np.argmax(np.bincount(lab)))
+    Ae = sp.csr_matrix(Ae[pk, :][:, pk])
+    o = O.amg_options_class1("v"); o.update(fnode=int((pk < n).sum()), isnsp=1)
+    ho = O.amg_setup(Ae, o, O.matlab_rng())
+    h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand())
+    assert h.level_sizes() == ho.level_sizes()
+    for k in range(2, ho.J + 1):
+        assert csc_equal(h.A(k), ho.Ack[k]), f"Ack{{{k}}} differs"
+        assert csc_equal(h.P(k), ho.Prok[k]), f"Prok{{{k}}} differs"
+    h.close()
+
+
 @pytest.mark.parametrize("rho", [1.0, 0.4])
 def test_tile_product_matches_row_product(ipd, monkeypatch, rho):
     """At a size where the tile kernel is the default choice, both product kernels give the same
