@@ -148,7 +148,7 @@ struct ipd_ctx {
     long long asat_nnz_hint = 0;   // entries of the last ASAt result (sizes the next one's arrays)
     // entries of P, Pt*A and Ac of the last hierarchy's level k (amg_transfer's lazy counts: the kernel-choice
     // heuristics of the next hierarchy's products run on these estimates; 0 = none yet)
-    int xfer_hint[40][3] = {};
+    int xfer_hint[40][4] = {};   // [3]: longest row of P'A
     void* asat_agg = nullptr;      // k_asat_small's chained-scan words (ipd_kkt.hip)
     // Zero pool: temporaries that must start out as zeros (transpose bitmaps, dense operand blocks, flags) are
     // bumped out of one block that a single memset clears again at the start of the next hierarchy build --
@@ -458,7 +458,7 @@ struct ScanHeadLds {
     int wsum[4];
 };
 __device__ __forceinline__ int scan_head(const int* __restrict__ cnt, int n, int* rp_out, int* total_out,
-                                         ScanHeadLds& L) {
+                                         ScanHeadLds& L, int* max_out = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int C = (n + 255) >> 8;   // a contiguous chunk per thread, at most 16 entries
     int v[SCAN_HEAD_MAX / 256];
@@ -496,6 +496,18 @@ __device__ __forceinline__ int scan_head(const int* __restrict__ cnt, int n, int
     if (blockIdx.x == 0) {
         for (int i = tid; i <= n; i += 256) rp_out[i] = L.rp[i];
         if (tid == 0 && total_out) *total_out = carry;
+        if (max_out) {   // the longest row (the next hierarchy's product model wants it: the row kernels are as slow
+                         // as their longest row)
+            int mx = 0;
+#pragma unroll
+            for (int j = 0; j < SCAN_HEAD_MAX / 256; ++j) mx = max(mx, v[j]);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+            __syncthreads();
+            if (lane == 0) L.wsum[w] = mx;
+            __syncthreads();
+            if (tid == 0) *max_out = max(max(L.wsum[0], L.wsum[1]), max(L.wsum[2], L.wsum[3]));
+        }
     }
     return carry;
 }
@@ -530,8 +542,9 @@ void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n);
 // caller has checked SPGEMM_LAZY_MAX), C->nnz is that bound until the caller has fetched *total_dev; the nnz of
 // X and Y are then only read by the kernel-choice heuristic (estimates will do: both kernels give the same bits)
 constexpr size_t SPGEMM_LAZY_MAX = size_t(1) << 21;
+// maxrow_dev (lazy only): the longest row of C is stored there; x_maxrow: the longest row of X if known (estimate)
 void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, int* total_dev = nullptr,
-                LazyPost* post = nullptr);
+                LazyPost* post = nullptr, int* maxrow_dev = nullptr, int x_maxrow = 0);
 void csr_expand_dense(ipd_ctx* ctx, const Csr& A, double* dense, int ld);  // dense pre-zeroed
 // st.out != NULL: rowcnt is zeroed<int> and the launch's tail scans the (biased) counts into st.out (nr > 0);
 // an empty st leaves plain counts

@@ -964,26 +964,30 @@ __global__ __launch_bounds__(64) void k_build_W_w(int N, int Nc, const int* __re
             double vA[D], vB[D], xA[D], xB[D];
             // pieces u0 .. u0+D-1: C column index (or -1) and w1 = a_kj / -a_kk of the lane's entry; x(i,k) and the
             // long-row mark ride along, so that applying a piece is one LDS read-add-write and nothing else
+            // (branch-free in two rounds -- all the pieces' entries, then all their C flags and indices -- so that the
+            // D pieces' dependent loads overlap: under `if (lane < n) { j = ...; if (isC[j]) ... }` each piece
+            // waited for its own two round trips in turn, 1.5 us per call)
             auto load = [&](int u0, int* jj, double* vv, double* xs, int* ts) __attribute__((always_inline)) {
+                int jt[D], nn[D];
+                double nd[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    const int u = u0 + d;   // uniform
-                    jj[d] = -1;
-                    vv[d] = 0.0;
-                    xs[d] = 0.0;
-                    ts[d] = 0;
-                    if (u < cnt) {
-                        const int bb = s_yb[u], n = s_yn[u];
-                        xs[d] = s_x[u];
-                        ts[d] = s_te[u];
-                        if (lane < n) {
-                            const int j = ci[bb + lane];
-                            if (isC[j]) {
-                                jj[d] = cidx[j];
-                                vv[d] = va[bb + lane] / s_nd[u];
-                            }
-                        }
-                    }
+                    const int u = min(u0 + d, cnt - 1);   // uniform; cnt > 0 here
+                    const int bb = s_yb[u];
+                    nn[d] = u0 + d < cnt ? s_yn[u] : 0;
+                    xs[d] = s_x[u];
+                    ts[d] = u0 + d < cnt ? s_te[u] : 0;
+                    nd[d] = s_nd[u];
+                    const int idx = bb + min(lane, max(nn[d], 1) - 1);
+                    jt[d] = ci[idx];
+                    vv[d] = va[idx];
+                }
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const bool c = isC[jt[d]] != 0;
+                    const int cd = cidx[jt[d]];
+                    jj[d] = (lane < nn[d] && c) ? cd : -1;
+                    vv[d] = vv[d] / nd[d];
                 }
             };
             auto apply = [&](int u0, const int* jj, const double* vv, const double* xs, const int* ts)
@@ -1013,12 +1017,14 @@ __global__ __launch_bounds__(64) void k_build_W_w(int N, int Nc, const int* __re
                     }
                 }
             };
-            load(0, jA, vA, xA, tA);
-            for (int u0 = 0; u0 < cnt; u0 += 2 * D) {
-                load(u0 + D, jB, vB, xB, tB);
-                apply(u0, jA, vA, xA, tA);
-                load(u0 + 2 * D, jA, vA, xA, tA);
-                apply(u0 + D, jB, vB, xB, tB);
+            if (cnt > 0) {
+                load(0, jA, vA, xA, tA);
+                for (int u0 = 0; u0 < cnt; u0 += 2 * D) {
+                    load(u0 + D, jB, vB, xB, tB);
+                    apply(u0, jA, vA, xA, tA);
+                    load(u0 + 2 * D, jA, vA, xA, tA);
+                    apply(u0 + D, jB, vB, xB, tB);
+                }
             }
             __syncthreads();   // (the lists are rewritten by the next batch)
         }
@@ -1264,7 +1270,7 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
                (size_t)P.nc * (size_t)P.nc <= SPGEMM_LAZY_MAX;
         const int* head = nullptr;
         if (lazy) {
-            counts = zeroed<int>(ctx, 4);
+            counts = zeroed<int>(ctx, 6);
             int* rowlen = tmp.alloc<int>((size_t)N + 1);
             hipLaunchKernelGGL(k_bigph_count, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, nf,
                                A.rp, A.ci, rowlen, ScanTail(), counts + 3);
@@ -1323,7 +1329,7 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
         lazy = level >= 1 && level < 40 && ctx->xfer_hint[level][0] > 0 && ctx->xfer_hint[level][1] > 0 &&
                ctx->xfer_hint[level][2] > 0 && (size_t)N * (size_t)Nc <= SPGEMM_LAZY_MAX &&
                (size_t)Nc * (size_t)Nc <= SPGEMM_LAZY_MAX;
-        if (lazy) counts = zeroed<int>(ctx, 4);   // entries of P, P'A, Ac; a flag (bigraph level: Aff not diagonal)
+        if (lazy) counts = zeroed<int>(ctx, 6);   // entries of P, P'A, Ac; a flag (bigraph level: Aff not diagonal); longest row of P'A
         if (!small_done) {
             hipLaunchKernelGGL(k_rowmax, dim3(rows_grid(N)), dim3(256), 0, ctx->stream, N, A.rp, A.ci,
                                A.va, maxrow, diag);
@@ -1490,21 +1496,22 @@ void amg_transfer(ipd_ctx* ctx, Arena& dst, const Csr& A, const AmgOpts& o, int 
     const bool lazy_prod = hint && hint[1] > 0 && hint[2] > 0 && (lazy || P.nnz >= 0) &&
                            (size_t)Ncc * (size_t)N <= SPGEMM_LAZY_MAX && (size_t)Ncc * (size_t)Ncc <= SPGEMM_LAZY_MAX;
     if (lazy_prod) {
-        int* c3 = lazy ? counts : zeroed<int>(ctx, 4);
+        int* c3 = lazy ? counts : zeroed<int>(ctx, 6);
         Csr Pe = P, Pte = Pt;
         if (lazy) Pe.nnz = Pte.nnz = std::max(1, std::min(hint[0], P.nnz));   // (estimates for the heuristic only)
-        csr_spgemm(ctx, T1out ? dst : tmp, Pte, A, &T1, c3 + 1);
+        csr_spgemm(ctx, T1out ? dst : tmp, Pte, A, &T1, c3 + 1, nullptr, c3 + 4);
         Csr T1e = T1;
         T1e.nnz = std::max(1, std::min(hint[1], T1.nnz));
         LazyPost post;   // the level's counts ride back on the last compaction
         post.src = c3;
-        post.n = 4;
-        csr_spgemm(ctx, dst, T1e, Pe, &C, c3 + 2, &post);
-        int h3[4] = {0, 0, 0, 0};
+        post.n = 5;
+        csr_spgemm(ctx, dst, T1e, Pe, &C, c3 + 2, &post, nullptr, hint[3]);
+        int h3[5] = {0, 0, 0, 0, 0};
         if (post.box)
             ctx->mailbox_wait(post.ticket, h3, sizeof(h3));
         else
-            ctx->fetch(c3, h3, 4);
+            ctx->fetch(c3, h3, 5);
+        hint[3] = h3[4];
         if (lazy) {
             P.nnz = Pt.nnz = h3[0];
             IPD_REQUIRE(h3[3] == 0, IPD_E_UNSUPPORTED,

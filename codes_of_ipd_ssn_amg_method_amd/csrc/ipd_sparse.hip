@@ -450,14 +450,14 @@ __global__ __launch_bounds__(256) void k_dense_compact(int nr, int nc, int ld,
                                                        int* __restrict__ ci,
                                                        double* __restrict__ va,
                                                        const int* __restrict__ head_cnt, int* head_rp,
-                                                       int* head_total, const LazyPost post) {
+                                                       int* head_total, const LazyPost post, int* head_max) {
     // head_cnt != NULL: the row pointers are still plain counts -- every workgroup scans them for itself and
     // workgroup 0 stores them at head_rp (scan_head, ipd_internal.h; nr <= SCAN_HEAD_MAX).  post.box != NULL:
     // workgroup 0 then posts post.n device words (the level's lazy counts, this product's total among them)
     // to the host mailbox -- the fetch that would follow, without its launch.
     __shared__ ScanHeadLds L;
     if (head_cnt) {
-        const int total = scan_head(head_cnt, nr, head_rp, head_total, L);
+        const int total = scan_head(head_cnt, nr, head_rp, head_total, L, head_max);
         rp = L.rp;
         if (post.box && blockIdx.x == 0 && threadIdx.x == 0) {
             for (int w = 0; w < post.n; ++w)
@@ -779,7 +779,7 @@ static inline size_t round_up(size_t v, size_t q) { return (v + q - 1) / q * q; 
 // walks the padded rows x inner x columns box 16 inner indices at a time -- about 0.9 us per step and wave of
 // 256 64-edge tiles, 0.23 us with the 32-edge tiles small products get -- plus 20-40 us for the expansion of
 // the operands and the row count.  IPD_PRODUCT=rows|tiles overrides the choice (tests compare the two bit for bit).
-static bool spgemm_prefers_tiles(const Csr& X, const Csr& Y, size_t* bytes) {
+static bool spgemm_prefers_tiles(const Csr& X, const Csr& Y, size_t* bytes, int x_maxrow) {
     const size_t nrp = round_up((size_t)X.nr, GT), nkp = round_up((size_t)X.nc, GT),
                  ncp = round_up((size_t)Y.nc, GT);
     *bytes = 8 * (nrp * nkp + nkp * ncp + nrp * ncp);
@@ -789,7 +789,9 @@ static bool spgemm_prefers_tiles(const Csr& X, const Csr& Y, size_t* bytes) {
         if (!strcmp(e, "tiles")) return true;
         if (!strcmp(e, "rows")) return false;
     }
-    const double xlen = (double)X.nnz / X.nr, ylen = (double)Y.nnz / Y.nr;
+    // (one round of rows: the launch is as slow as its longest row)
+    const double ylen = (double)Y.nnz / Y.nr;
+    const double xlen = (X.nr <= 256 * 8) ? std::max((double)X.nnz / X.nr, (double)x_maxrow) : (double)X.nnz / X.nr;
     const double lds_rows = std::max(1.0, std::min(ylen < 96.0 ? 32.0 : 8.0, 160.0 * 1024 / (8.0 * Y.nc + 64)));
     const double row_rounds = std::ceil(X.nr / (256.0 * lds_rows));
     const double t_rows = row_rounds * xlen * (ylen < 96.0 ? 0.16 : 0.35 + 0.25 * std::ceil(ylen / 256.0));
@@ -798,10 +800,14 @@ static bool spgemm_prefers_tiles(const Csr& X, const Csr& Y, size_t* bytes) {
     const double t_walk = tiles >= 256.0 ? 20.0 + std::ceil(tiles / 256.0) * steps * 0.9
                                          : std::ceil(4.0 * tiles / 1024.0) * steps * 0.23;
     const double t_tiles = 20.0 + t_walk + (double)*bytes / 3.0e6;   // (operand block zeroed and written at ~3 TB/s)
+    if (const char* dbg = getenv("IPD_DEBUG_LEVELS"); dbg && dbg[0] == '1')
+        std::fprintf(stderr, "[ipd] product %d x %d x %d: x row %.1f, y row %.1f entries; model rows %.1f us, tiles %.1f us\n",
+                     X.nr, X.nc, Y.nc, xlen, ylen, t_rows, t_tiles);
     return t_tiles < t_rows;
 }
 
-void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, int* total_dev, LazyPost* post) {
+void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, int* total_dev, LazyPost* post,
+                int* maxrow_dev, int x_maxrow) {
     if (post) post->box = nullptr;
     IPD_REQUIRE(X.nc == Y.nr, IPD_E_ARG, "spgemm: inner dimensions differ");
     const int nr = X.nr, nc = Y.nc;
@@ -823,7 +829,7 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, in
     unsigned long long* rowbits = nullptr;   // row kernel only: the 64-column blocks a row touched
     int ld = nc;
     size_t tile_bytes = 0;
-    const bool tiles = spgemm_prefers_tiles(X, Y, &tile_bytes);
+    const bool tiles = spgemm_prefers_tiles(X, Y, &tile_bytes, x_maxrow);
     const int threads = (Y.nr > 0 && (double)Y.nnz / Y.nr >= 96.0) ? 256 : 64;
     // The row pointers.  With a lazy count (total_dev) the compaction scans the plain counts on its way in
     // (scan_head).  Otherwise the host needs the total to size the arrays: producers with 256-thread workgroups
@@ -912,7 +918,8 @@ void csr_spgemm(ipd_ctx* ctx, Arena& dst, const Csr& X, const Csr& Y, Csr* C, in
         }
         hipLaunchKernelGGL(k_dense_compact, dim3(std::max(1, std::min(cdiv(nr, 4), 4096))), dim3(256),
                            0, ctx->stream, nr, nc, ld, dense, (const unsigned long long*)rowbits,
-                           (const int*)out.rp, out.ci, out.va, head, out.rp, total_dev, lp);
+                           (const int*)out.rp, out.ci, out.va, head, out.rp, total_dev, lp,
+                           head ? maxrow_dev : (int*)nullptr);
         IPD_KERNEL_CHECK();
     }
     *C = out;
@@ -938,7 +945,7 @@ void dense_compact(ipd_ctx* ctx, int nr, int nc, int ld, const double* dense, co
     if (nr == 0 || out.nnz == 0) return;
     hipLaunchKernelGGL(k_dense_compact, dim3(std::max(1, std::min(cdiv(nr, 4), 4096))), dim3(256), 0,
                        ctx->stream, nr, nc, ld, dense, (const unsigned long long*)nullptr, (const int*)out.rp,
-                       out.ci, out.va, (const int*)nullptr, (int*)nullptr, (int*)nullptr, LazyPost());
+                       out.ci, out.va, (const int*)nullptr, (int*)nullptr, (int*)nullptr, LazyPost(), (int*)nullptr);
     IPD_KERNEL_CHECK();
 }
 
