@@ -85,12 +85,12 @@ void Arena::release() {
 // per cycle.  Measured on MI355X (tools/ubench_fetch.hip): kernel + hipMemcpyAsync to pinned
 // memory + hipStreamSynchronize 14.3 us per round trip; a one-wave kernel that stores the words
 // and then a ticket into host-coherent memory while the host spins on the ticket 5.8 us.
-constexpr int MAILBOX_WORDS = 32;
+constexpr int MAILBOX_WORDS = 224;   // payload words (a resident solve's result block is 136)
 
 __global__ void k_mailbox(const unsigned* __restrict__ src, int nwords, volatile unsigned* box,
                           unsigned ticket) {
     const int i = threadIdx.x;
-    if (i < nwords) box[16 + i] = src[i];
+    for (int w = i; w < nwords; w += 64) box[16 + w] = src[w];
     __threadfence_system();   // the payload is visible to the host before the ticket is
     __syncthreads();
     if (i == 0) box[0] = ticket;
@@ -264,8 +264,8 @@ extern "C" int ipd_ctx_create(int device, ipd_ctx** out) {
             c->up_ring = static_cast<char*>(ring);
         }
         void* box = nullptr;
-        IPD_HIP(hipHostMalloc(&box, 64 * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset(box, 0, 64 * sizeof(unsigned));
+        IPD_HIP(hipHostMalloc(&box, 256 * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(box, 0, 256 * sizeof(unsigned));
         c->mailbox = static_cast<volatile unsigned*>(box);
         *out = c.release();
     });

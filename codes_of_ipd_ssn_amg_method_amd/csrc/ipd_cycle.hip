@@ -1927,7 +1927,7 @@ __device__ __forceinline__ void bpoly_pass_t(SolveCtx& c, int k, const double* _
                 gptr p = col + (size_t)b * (8 * LD);
                 m0[u] = *reinterpret_cast<gptr2>(p + 2 * l);
                 if (HALVES > 1) {
-                    m1[u] = (d2)(0.0, 0.0);
+                    m1[u] = d2{0.0, 0.0};
                     if (a1) m1[u] = *reinterpret_cast<gptr2>(p + 128 + 2 * l);
                 }
             }

@@ -121,7 +121,6 @@ static void build_Ae(ipd_ctx* ctx, Arena& dst, const Csr& H0, const double* tdia
                      const double* q, int m, int n, double bk1, double tk, Csr* Ae) {
     const int M = m + n;
     IPD_REQUIRE(H0.nr == M && H0.nc == M, IPD_E_ARG, "Hybrid_AMG: H0 must be (n+m) x (n+m)");
-    Arena& tmp = *ctx->scratch;
     int* rowlen = zeroed<int>(ctx, (size_t)M + 1);   // (biased counts: see ScanTail)
     Csr a;
     a.nr = a.nc = M;

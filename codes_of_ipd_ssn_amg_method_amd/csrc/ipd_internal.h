@@ -142,7 +142,7 @@ struct ipd_ctx {
     size_t up_ring_bytes = 0, up_ring_off = 0;
     // mailbox for scalar readbacks: host-coherent memory a one-wave kernel writes the words and
     // then a ticket into, while the host spins on the ticket (no copy engine, no stream wait)
-    volatile unsigned* mailbox = nullptr;   // [0] ticket, [16..48) payload words
+    volatile unsigned* mailbox = nullptr;   // [0] ticket, [16..240) payload words
     unsigned mailbox_ticket = 0;
     int num_cu = 256;
     long long asat_nnz_hint = 0;   // entries of the last ASAt result (sizes the next one's arrays)
@@ -188,7 +188,7 @@ struct ipd_ctx {
     }
     void fetch_bytes(const void* dsrc, void* hdst, size_t bytes);
     // For kernels that post their own scalar results: take a ticket, pass `mailbox` and the
-    // ticket to the kernel (which stores <= 32 words at mailbox[16..] and then the ticket at
+    // ticket to the kernel (which stores <= 224 words at mailbox[16..] and then the ticket at
     // mailbox[0], see k_mailbox), then wait.  Returns false when the mailbox is switched off.
     bool mailbox_begin(unsigned* ticket);
     void mailbox_wait(unsigned ticket, void* hdst, size_t bytes);
@@ -532,11 +532,7 @@ void csr_spmv(ipd_ctx* ctx, const Csr& A, const double* x, double* y);
 void exclusive_scan_i32(ipd_ctx* ctx, const int* in, int* out, int n,   // out has n+1 entries
                         int* total_dev = nullptr);                       // ... the total also goes there (device)
 int exclusive_scan_total(ipd_ctx* ctx, const int* in, int* out, int n);
-void exclusive_scan_total2(ipd_ctx* ctx, const int* in1, int* out1, const int* in2, int* out2, int n,
-                           int* total1, int* total2);  // same, returns out[n]
-void fill_i32(ipd_ctx* ctx, int* p, int v, size_t n);
 void fill_f64(ipd_ctx* ctx, double* p, double v, size_t n);
-void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n);
 // C = X*Y with MATLAB ordering (ascending inner index, no FMA, exact zeros dropped)
 // total_dev != NULL ("lazy count"): no host round trip -- C's arrays are sized by the dense bound nr*nc (the
 // caller has checked SPGEMM_LAZY_MAX), C->nnz is that bound until the caller has fetched *total_dev; the nnz of

@@ -31,9 +31,7 @@ static void fill_t(ipd_ctx* ctx, T* p, T v, size_t n) {
     hipLaunchKernelGGL(k_fill<T>, dim3(blocks), dim3(256), 0, ctx->stream, p, v, n);
     IPD_KERNEL_CHECK();
 }
-void fill_i32(ipd_ctx* ctx, int* p, int v, size_t n) { fill_t(ctx, p, v, n); }
 void fill_f64(ipd_ctx* ctx, double* p, double v, size_t n) { fill_t(ctx, p, v, n); }
-void fill_u8(ipd_ctx* ctx, uint8_t* p, uint8_t v, size_t n) { fill_t(ctx, p, v, n); }
 
 // Exclusive scan of n ints by ONE workgroup (n is a row/column count, at most a few thousand on this path);
 // out[n] receives the total.  in == out is allowed.  Most scans ride at the end of the launch that produces the
@@ -49,21 +47,6 @@ __global__ __launch_bounds__(1024) void k_exscan(const int* __restrict__ in, int
         box[0] = ticket;
     }
 }
-// two arrays of the same length, one launch, both totals in one mailbox message
-__global__ __launch_bounds__(1024) void k_exscan2(const int* __restrict__ in1, int* out1,
-                                                  const int* __restrict__ in2, int* out2, int n,
-                                                  volatile unsigned* box, unsigned ticket) {
-    __shared__ int wsum[16];
-    const int c1 = ipd_scan_counts(in1, out1, n, wsum);
-    const int c2 = ipd_scan_counts(in2, out2, n, wsum);
-    if (threadIdx.x == 0 && box) {
-        box[16] = (unsigned)c1;
-        box[17] = (unsigned)c2;
-        __threadfence_system();
-        box[0] = ticket;
-    }
-}
-
 void exclusive_scan_i32(ipd_ctx* ctx, const int* in, int* out, int n, int* total_dev) {
     hipLaunchKernelGGL(k_exscan, dim3(1), dim3(1024), 0, ctx->stream, in, out, n,
                        (volatile unsigned*)nullptr, 0u, total_dev);
@@ -83,23 +66,6 @@ int exclusive_scan_total(ipd_ctx* ctx, const int* in, int* out, int n) {
     int total = 0;
     ctx->mailbox_wait(ticket, &total, sizeof(int));
     return total;
-}
-
-void exclusive_scan_total2(ipd_ctx* ctx, const int* in1, int* out1, const int* in2, int* out2, int n,
-                           int* total1, int* total2) {
-    unsigned ticket = 0;
-    if (!ctx->mailbox_begin(&ticket)) {
-        *total1 = exclusive_scan_total(ctx, in1, out1, n);
-        *total2 = exclusive_scan_total(ctx, in2, out2, n);
-        return;
-    }
-    hipLaunchKernelGGL(k_exscan2, dim3(1), dim3(1024), 0, ctx->stream, in1, out1, in2, out2, n, ctx->mailbox,
-                       ticket);
-    IPD_KERNEL_CHECK();
-    int t[2] = {0, 0};
-    ctx->mailbox_wait(ticket, t, sizeof(t));
-    *total1 = t[0];
-    *total2 = t[1];
 }
 
 // ---------------------------------------------------------------------------
