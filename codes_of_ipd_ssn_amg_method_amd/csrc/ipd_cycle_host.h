@@ -762,8 +762,11 @@ static bool run_resident(ipd_amg* h, CycleState* st, const double* b_dev, double
     if (ms) IPD_HIP(hipEventRecord(e1, ctx->stream));
     const size_t nout = 4 + 2 * ((size_t)std::max(h->opts.maxit, 0) + 2);
     std::vector<double> out(nout);
-    ctx->fetch(st->res_out, out.data(), nout);   // synchronises the stream
-    if (ms) IPD_HIP(hipEventElapsedTime(ms, e0, e1));
+    ctx->fetch(st->res_out, out.data(), nout);   // waits for the kernel (through the host mailbox: no stream synchronisation)
+    if (ms) {
+        IPD_HIP(hipEventSynchronize(e1));
+        IPD_HIP(hipEventElapsedTime(ms, e0, e1));
+    }
     if (out[3] != 0.0) {   // a bounded spin gave up somewhere (any workgroup: the kernel reports the
         // time-out word, not only workgroup 0's own view): not every workgroup was resident
         ++st->res_timeouts;
