@@ -950,6 +950,13 @@ struct SolveDesc {
     long long* dbg;   // optional: wall_clock64 stamps (100 MHz) of k_subcycle's stages
     int stage_bytes;  // size of the gather staging area at the start of dynamic LDS
     double* bp_part;  // LDS: 8 x gLD partial sums + 8 (block-wide polynomial passes)
+    // One block-wide polynomial level's operator as an LDS copy (round 4): a compact column-major copy of
+    // L[bm_level].gM with bm_ld rows (the stacked N + Nc <= 128, rounded up to even) sits at bm_src; a kernel whose
+    // launch carries lds_total + bm_bytes of dynamic LDS (the resident kernels' tail workgroup, which serves a whole
+    // solve out of one image load) copies it to LDS offset bm_off and its passes read it there -- 0.7 us per pass
+    // against 1.7 us out of L2.  bm_bytes = 0: none.
+    const double* bm_src;
+    int bm_level, bm_ld, bm_off, bm_bytes;
     double retol;
     PcgArgs pcg;
     SolveLevel L[SOLVE_ML + 1];
@@ -965,6 +972,7 @@ struct SolveCtx {  // per-thread copies of uniform state
     double* part;       // 3 x 16 per-wave partial sums (blk_cycle)
     double* sumr;       // per-level sum of the right-hand side (blk_cycle)
     long long* dbg;     // optional stage clocks (ipd_amg_bench_subcycle), NULL in production
+    unsigned bm_lds;    // LDS address of the loaded operator copy (SolveDesc::bm_src), 0: not loaded
 };
 // accumulates the 100 MHz clock spent since t0 into dbg[slot] (thread 0 only)
 #define SOL_DBG_T0(c) const long long dbg_t0__ = (c).dbg ? wall_clock64() : 0
@@ -1063,6 +1071,9 @@ struct LdsLevel {
     AS3 const double* pW;
     int pLD;
     bool poly;
+    AS3 const double* bM;   // LDS copy of gM (SolveDesc::bm_src), NULL: read gM from global memory
+    AS3 const double* bW;   // ... and of gW behind it
+    int bLD;
     AS3 const unsigned* lmap;
     bool mapped;
     bool bdense;
@@ -1126,6 +1137,9 @@ __device__ __forceinline__ LdsLevel lds_level(const SolveCtx& c, int k) {
     L.gM = G.gM;
     L.gW = G.gW;
     L.gLD = G.gLD;
+    L.bM = (c.bm_lds && D->bm_level == k) ? (AS3 const double*)c.bm_lds : (AS3 const double*)0;
+    L.bLD = D->bm_ld;
+    L.bW = L.bM + (D->bm_bytes / 8 - D->bm_ld);
     L.semi = (k == D->k_semi);
     L.grp = G.lv.rp;
     L.gci = G.lv.ci;
@@ -2030,11 +2044,80 @@ __device__ __forceinline__ void lpoly_pass(SolveCtx& c, int k, AS3 const double*
     }
     __syncthreads();
 }
+// The block-wide pass of bpoly_pass_t<1> with the operator in LDS (SolveDesc::bm_src: bm_ld rows per column, at
+// most 128): the same columns per wave, the same rows per lane, the same order of the sums -- the same bits.
+__device__ __forceinline__ void bpoly_pass_lds(SolveCtx& c, int k, AS3 const double* M, int LDm,
+                                               AS3 const double* Wl, int rows, int nb0,
+                                               AS3 const double* x0, int nb1, AS3 const double* x1, int nb2,
+                                               AS3 const double* x2, bool pre, AS3 double* outA, int nA,
+                                               AS3 double* outB) {
+    typedef __attribute__((ext_vector_type(2))) double d2;
+    typedef AS3 const d2* lptr2;
+    constexpr int LD = 128, U = 12;
+    const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    AS3 double* part = as_lds(c.D->bp_part);
+    const bool a0 = 2 * l < rows;
+    const int nbt = (c.D->dbg_skip & 1) ? 0 : nb0 + nb1 + nb2;
+    const double wv = t < rows ? Wl[t] : 0.0;
+    double xl = 0.0;
+    if (l < nbt) {
+        AS3 const double* xs = l < nb0 ? x0 + 8 * l : (l < nb0 + nb1 ? x1 + 8 * (l - nb0) : x2 + 8 * (l - nb0 - nb1));
+        xl = xs[w];
+    }
+    const double sx = pre ? wave_sum(l < nb0 ? xl : 0.0) : 0.0;
+    const int xlo = __double2loint(xl), xhi = __double2hiint(xl);
+    AS3 const double* col = M + w * LDm;   // uniform; column 8 b + w starts at col + b * 8 * LDm
+    double y00 = 0.0, y01 = 0.0;
+    if (a0) {
+        for (int b0 = 0; b0 < nbt; b0 += U) {
+            d2 m0[U];
+            double xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + u < nbt ? b0 + u : nbt - 1;   // uniform (the surplus of the last batch: x = 0)
+                const double x = __hiloint2double(__builtin_amdgcn_readlane(xhi, b), __builtin_amdgcn_readlane(xlo, b));
+                xv[u] = b0 + u < nbt ? x : 0.0;
+                m0[u] = *reinterpret_cast<lptr2>(col + b * (8 * LDm) + 2 * l);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                y00 = __builtin_fma(m0[u].x, xv[u], y00);
+                y01 = __builtin_fma(m0[u].y, xv[u], y01);
+            }
+        }
+    }
+    part[w * LD + 2 * l] = y00;
+    part[w * LD + 2 * l + 1] = y01;
+    if (pre && l == 0) part[8 * LD + w] = sx;
+    __syncthreads();
+    double sumr;
+    if (pre) {
+        sumr = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) sumr += part[8 * LD + g];
+        if (t == 0) as_lds(c.sumr)[k] = sumr;   // 1'r of this visit: the post-smoothing pass needs it again
+    } else {
+        sumr = as_lds(c.sumr)[k];
+    }
+    if (t < rows) {
+        double y = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) y += part[g * LD + t];
+        y = __builtin_fma(wv, sumr, y);
+        if (t < nA)
+            outA[t] = y;
+        else
+            outB[t - nA] = y;
+    }
+    __syncthreads();
+}
 __device__ __forceinline__ void bpoly_pass(SolveCtx& c, int k, const LdsLevel& L, int rows, int nb0,
                                            AS3 const double* x0, int nb1, AS3 const double* x1, int nb2,
                                            AS3 const double* x2, bool pre, AS3 double* outA, int nA,
                                            AS3 double* outB) {
-    if (!L.gM)
+    if (L.gM && L.bM)
+        bpoly_pass_lds(c, k, L.bM, L.bLD, L.bW, rows, nb0, x0, nb1, x1, nb2, x2, pre, outA, nA, outB);
+    else if (!L.gM)
         lpoly_pass(c, k, L.pMr, L.pW, rows, nb0, x0, nb1, x1, nb2, x2, pre, outA, nA, outB);
     else if (L.gLD == 128)
         bpoly_pass_t<1>(c, k, L.gM, L.gW, rows, nb0, x0, nb1, x1, nb2, x2, pre, outA, nA, outB);
@@ -2442,6 +2525,18 @@ struct PackEntry {
     const void* src;
     unsigned dst_off, bytes;  // multiples of 4
 };
+// compact copy of a block-wide polynomial operator (column-major, gld rows per column) with ld rows per column
+// (SolveDesc::bm_src): one workgroup per column
+// (the last workgroup copies the vector W behind the columns)
+__global__ __launch_bounds__(128) void k_bm_compact(const double* __restrict__ src, int gld, double* __restrict__ dst,
+                                                    int ld, const double* __restrict__ W, int rows) {
+    const int c = blockIdx.x, r = threadIdx.x;
+    if (c == (int)gridDim.x - 1) {
+        if (r < ld) dst[(size_t)c * ld + r] = r < rows ? W[r] : 0.0;
+        return;
+    }
+    if (r < ld) dst[(size_t)c * ld + r] = src[(size_t)c * gld + r];
+}
 // gathers the constant arrays of the cached levels into the image (one workgroup per array)
 __global__ __launch_bounds__(256) void k_pack_image(const PackEntry* __restrict__ ents,
                                                     char* __restrict__ img) {
@@ -3008,6 +3103,7 @@ __global__ __launch_bounds__(BT) void k_solve_small(const SolveDesc* __restrict_
     c.part = blkpart;
     c.sumr = blkpart + 48;
     c.dbg = nullptr;
+    c.bm_lds = 0;
     D = c.D;
     const int N = D->L[1].lv.N;
     const int maxit = D->maxit;
@@ -3117,6 +3213,7 @@ __global__ __launch_bounds__(BT) void k_subcycle(const SolveDesc* __restrict__ D
     c.part = blkpart;
     c.sumr = blkpart + 48;
     c.dbg = dbg;
+    c.bm_lds = 0;
     if (dbg && threadIdx.x == 0) {
         dbg[4] = dbg[5] = dbg[6] = dbg[7] = 0;
         dbg[9] = dbg[10] = dbg[11] = dbg[12] = dbg[13] = 0;

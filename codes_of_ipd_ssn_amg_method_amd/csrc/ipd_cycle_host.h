@@ -58,6 +58,8 @@ struct CycleState {
     size_t sub5_lds = 0;
     int k_sub = 0;
     size_t sub_lds = 0;
+    // dynamic LDS an image's operator copy needs on top of its *_lds (SolveDesc::bm_src; 0: none)
+    size_t sub_bm = 0, sub3_bm = 0, sub4_bm = 0;
     double* x2 = nullptr;
     // level-resident solve kernel (ipd_resident.h): the whole Class_AMG loop in one launch of
     // res_G co-resident workgroups that keep the matrices of levels 1-2 in registers
@@ -387,7 +389,7 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     bool remote = false, three = false;
     int ke3 = 0;
     const SolveDesc* tail_img = nullptr;   // the remote tail's LDS image and its dynamic LDS size
-    size_t tail_lds = 0;
+    size_t tail_lds = 0, tail_bm = 0;   // tail_bm: room for the image's operator copy (SolveDesc::bm_src)
     if (!local_tail) {
         const char* nr = std::getenv("IPD_NO_RESIDENT_REMOTE");
         const bool cyc = h->opts.cycle == 'w' || h->opts.cycle == 'v';
@@ -400,6 +402,7 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
         const char* n3 = std::getenv("IPD_NO_RESIDENT_THREE");
         tail_img = st->k_sub == 0 ? st->d_sub3 : st->d_sub;
         tail_lds = st->k_sub == 0 ? st->sub3_lds : st->sub_lds;
+        tail_bm = st->k_sub == 0 ? st->sub3_bm : st->sub_bm;
         const bool img4 = (st->k_sub == 4 && st->d_sub) || (st->k_sub == 3 && st->d_sub4);
         if (!(nr && nr[0] == '1') && !(n3 && n3[0] == '1') && h->J >= 5 && img4 && cyc) {
             // (its rows are usually too uneven for the launches' padded copy -- hubs -- but in registers
@@ -413,6 +416,7 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
                 if (st->k_sub == 3) {
                     tail_img = st->d_sub4;
                     tail_lds = st->sub4_lds;
+                    tail_bm = st->sub4_bm;
                 }
             }
         }
@@ -464,8 +468,10 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     if (poly4) {
         tail_img = st->d_sub5;
         tail_lds = st->sub5_lds;
+        tail_bm = 0;   // (entered at level 5: the copied level is one the resident workgroups hold)
     }
-    const size_t lds = remote ? std::max<size_t>(RES_LDS_BYTES, tail_lds) : RES_LDS_BYTES;
+    if (!remote || tail_lds + tail_bm > (size_t)156 * 1024) tail_bm = 0;
+    const size_t lds = remote ? std::max<size_t>(RES_LDS_BYTES, tail_lds + tail_bm) : RES_LDS_BYTES;
     if (lds > 156 * 1024) return;
     Arena& ar = *h->arena;
     ResDesc D{};
@@ -571,6 +577,7 @@ static void plan_resident(ipd_amg* h, CycleState* st) {
     D.tmo = reinterpret_cast<unsigned*>(st->res_block + 2 * gbytes);
     D.remote = remote ? 1 : 0;
     D.sub = remote ? tail_img : nullptr;
+    D.tail_bm = (remote && tail_bm > 0) ? 1 : 0;
     D.tin = remote ? st->res_block + 2 * gbytes + 16 : st->res_block;        // never touched without
     D.tout = remote ? st->res_block + 4 * gbytes + 16 : st->res_block;       // a remote tail
     D.tctl = remote ? reinterpret_cast<unsigned*>(st->res_block + 6 * gbytes + 16) : D.tmo;
@@ -1168,7 +1175,7 @@ void amg_prepare_levels(ipd_amg* h) {
     };
     // Lays levels k_from..J out behind the staging area, packs the image on the device and
     // returns it (the descriptor the kernels take); *lds_total = dynamic LDS bytes to request.
-    auto build_image = [&](SolveDesc* sd, int k_from, size_t stage, size_t* lds_total) {
+    auto build_image = [&](SolveDesc* sd, int k_from, size_t stage, size_t* lds_total, size_t* bm_extra = nullptr) {
         const bool lean = lean_vectors && sd->k_blk <= std::max(2, k_from);
         std::vector<PackEntry> packs;
         std::vector<unsigned> relocs;
@@ -1366,6 +1373,34 @@ void amg_prepare_levels(ipd_amg* h) {
         off = r16(off);
         sd->nreloc = (int)relocs.size();
         *lds_total = off;
+        // One block-wide polynomial level's operator as an LDS copy (SolveDesc::bm_src), for the launches that can
+        // afford bm_bytes more dynamic LDS (the resident kernels' tail workgroup): the deepest such level whose
+        // stacked operator has at most 128 rows and fits behind the work vectors.
+        sd->bm_src = nullptr;
+        sd->bm_level = sd->bm_ld = sd->bm_off = sd->bm_bytes = 0;
+        if (bm_extra) {
+            *bm_extra = 0;
+            for (int k = h->J - 1; k >= std::max(2, k_from); --k) {
+                const SolveLevel& T = sd->L[k];
+                if (!T.gM || T.gLD != 128) continue;
+                const size_t N = (size_t)T.lv.N, Nc = (size_t)h->L[k + 1].A.nr, rows = N + Nc;
+                if (rows > 128) continue;
+                const size_t ld = (rows + 1) & ~size_t(1), ncols = 8 * (2 * ((N + 7) / 8) + (Nc + 7) / 8);
+                const size_t need = 8 * ld * (ncols + 1);   // (ld even: a multiple of 16; the vector W behind the columns)
+                if (off + need > (size_t)156 * 1024) continue;
+                double* cp = ar.alloc<double>(ld * (ncols + 1));
+                hipLaunchKernelGGL(k_bm_compact, dim3((unsigned)ncols + 1), dim3(128), 0, ctx->stream, T.gM, 128, cp,
+                                   (int)ld, T.gW, (int)rows);
+                IPD_KERNEL_CHECK();
+                sd->bm_src = cp;
+                sd->bm_level = k;
+                sd->bm_ld = (int)ld;
+                sd->bm_off = (int)off;
+                sd->bm_bytes = (int)need;
+                *bm_extra = need;
+                break;
+            }
+        }
         char* img = reinterpret_cast<char*>(ar.alloc_bytes(image_bytes));
         // the image head and the pack descriptors go up in ONE copy: [head | packs | dense | lmaps | polys] in
         // a scratch block, the head then moves into the image as one more entry of k_pack_image
@@ -1483,7 +1518,7 @@ void amg_prepare_levels(ipd_amg* h) {
             sd->root_r = h->L[2].r;
             sd->root_e = h->L[2].e;
             st->k_sub = 2;
-            st->d_sub = build_image(sd.get(), 2, stage, &st->sub_lds);
+            st->d_sub = build_image(sd.get(), 2, stage, &st->sub_lds, &st->sub_bm);
             semi_done = true;
         }
         if (want && !semi_done) {
@@ -1539,7 +1574,7 @@ void amg_prepare_levels(ipd_amg* h) {
                     sd->root_e = h->L[kroot].e;
                     st->k_sub = kroot;
                     st->sub_semi_root = semi_root;
-                    st->d_sub = build_image(sd.get(), kroot, stage, &st->sub_lds);
+                    st->d_sub = build_image(sd.get(), kroot, stage, &st->sub_lds, &st->sub_bm);
                     break;
                 }
             }
@@ -1574,7 +1609,7 @@ void amg_prepare_levels(ipd_amg* h) {
             sd->stage_bytes = (int)stage;
             sd->root_r = h->L[4].r;
             sd->root_e = h->L[4].e;
-            st->d_sub4 = build_image(sd.get(), 4, stage, &st->sub4_lds);
+            st->d_sub4 = build_image(sd.get(), 4, stage, &st->sub4_lds, &st->sub4_bm);
         }
     }
     // (b3) No sub-cycle at all because level 3's interpolation is big (P_3 with more than 40 k entries:
@@ -1600,7 +1635,7 @@ void amg_prepare_levels(ipd_amg* h) {
             sd->stage_bytes = (int)stage;
             sd->root_r = h->L[3].r;
             sd->root_e = h->L[3].e;
-            st->d_sub3 = build_image(sd.get(), 3, stage, &st->sub3_lds);
+            st->d_sub3 = build_image(sd.get(), 3, stage, &st->sub3_lds, &st->sub3_bm);
         }
     }
     // (b4) the image rooted at level 5 (see root5 above) is the one the deep mode's tail workgroup takes

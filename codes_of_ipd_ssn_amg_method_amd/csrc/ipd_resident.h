@@ -120,6 +120,7 @@ struct ResDesc {
     const double* xm_beta;   // nc: the C node's factor
     const double* xm_rho;    // nf: the F row's factor (1 / row sum with isnsp)
     int localfirst;   // zero-start first sweeps formed locally (see k_resident); 0: handed off like the rest
+    int tail_bm;      // the launch's dynamic LDS has room for the tail image's operator copy (SolveDesc::bm_src)
     int wident;       // P = [W; I] verified (k_res_check_ident): identity entries are added, not walked
     int Nt;           // rows of the tail level (local tail) or of the remote tail's root level
     int nu, isnsp, wcycle, anycycle, maxit;
@@ -366,6 +367,14 @@ __device__ __forceinline__ void res_tail_workgroup(const ResDesc& D, char* dyn_r
     c.part = blkpart;
     c.sumr = blkpart + 48;
     c.dbg = nullptr;
+    c.bm_lds = 0;
+    if (D.tail_bm && LD->bm_bytes) {   // one block-wide level's operator into LDS for the whole solve (SolveDesc::bm_src)
+        const uint4* src = reinterpret_cast<const uint4*>(LD->bm_src);
+        uint4* dst = reinterpret_cast<uint4*>(dyn_raw + LD->bm_off);
+        for (int i = tid; i < LD->bm_bytes / 16; i += BT) dst[i] = src[i];
+        __syncthreads();
+        c.bm_lds = (unsigned)(size_t)(dyn_raw + LD->bm_off);
+    }
     const int k0 = D.tail_root, N3 = k0 == 5 ? D.N5 : D.Nt, N2 = k0 == 3 ? D.L2.N : D.L3.N;   // inbox / outbox rows
     const ResCsr& Pout = k0 == 3 ? D.P3 : D.P4;
     const bool two_legs = D.wcycle && k0 < LD->J;
