@@ -380,6 +380,7 @@ __device__ __forceinline__ void res_tail_workgroup(const ResDesc& D, char* dyn_r
     const bool two_legs = D.wcycle && k0 < LD->J;
     const auto rin = __builtin_amdgcn_make_buffer_rsrc(D.tin, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
     const auto rout = __builtin_amdgcn_make_buffer_rsrc(D.tout, 0, 2 * RES_GRAN_MAX * 16, 0x00020000);
+    long long busy = 0;
     for (unsigned tseq = 1;; ++tseq) {
         double v[1];
         const int st = res_wait_slow<1>(rin, tseq, N3, D.tmo, D.tctl, v);
@@ -388,7 +389,11 @@ __device__ __forceinline__ void res_tail_workgroup(const ResDesc& D, char* dyn_r
         int any = 0;
 #pragma unroll
         for (int k = 0; k < RES_WAVES; ++k) any |= stat[k];
-        if (any) return;                       // uniform: every wave reads the same eight words
+        if (any) {                             // uniform: every wave reads the same eight words
+            if (D.dbg && tid == 0) D.dbg[9] = busy;   // (diagnostic build of the bench: clocks between a request's arrival and its answer's stores)
+            return;
+        }
+        const long long tb0 = (D.dbg && tid == 0) ? (long long)__builtin_amdgcn_s_memtime() : 0;
         if (tid < N3) LD->L[k0].lv.r[tid] = v[0];
         __syncthreads();
         sol_cycle(c, k0, false);
@@ -408,6 +413,7 @@ __device__ __forceinline__ void res_tail_workgroup(const ResDesc& D, char* dyn_r
             for (int t = Pout.rp[j]; t < Pout.rp[j + 1]; ++t) sd += Pout.va[t] * e3[Pout.ci[t]];
             __builtin_amdgcn_raw_buffer_store_b128(res_pack(sd, tseq), rout, base + j * 16, 0, 16 /* sc1 */);
         }
+        if (D.dbg && tid == 0) busy += (long long)__builtin_amdgcn_s_memtime() - tb0;
         __syncthreads();                       // stat and e3 are rewritten by the next visit
     }
 }

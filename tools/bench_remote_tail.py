@@ -55,9 +55,10 @@ for path in files[::int(os.environ.get("STRIDE", "7"))]:
             m2 = c_double()
             _lib.check(_lib.lib.ipd_amg_bench_resident(h.handle, db.ptr, dx.ptr, c_int(20), byref(m2), st))
             wait, tot, nh, ticks, bar1, store, bar2, xfer, tail = [int(v) for v in st][:9]
+            busy = int(st[9])
             mhz = tot / (ticks / 100.0)
-            extra = " | per cycle: %.0f hand-offs, wait %.1f us, tail (incl. waiting for it) %.1f us, total %.1f us" % (
-                nh / 20, wait / mhz / 20, tail / mhz / 20, tot / mhz / 20)
+            extra = " | per cycle: %.0f hand-offs, wait %.1f us, tail (incl. waiting for it) %.1f us of which the tail workgroup is busy %.1f us, total %.1f us" % (
+                nh / 20, wait / mhz / 20, tail / mhz / 20, busy / mhz / 20, tot / mhz / 20)
         res[off] = (mode.value, grid.value, it, rel, 1e3 * t, ms.value / 20, extra)
         lv = [(h.level_dims(k)) for k in range(1, h.J + 1)]
         h.close()
