@@ -42,6 +42,10 @@ SHAPES = [
     (150, 150, 150, 0.02, 0.02),  # sparse both (the usual coarse levels)
     (300, 40, 500, 1.0, 0.3),
     (37, 512, 3, 0.5, 1.0),       # three output columns
+    # row counts beyond one pass of the scans that ride on the count launches (2048 entries per pass of a
+    # 256-thread producer's tail, ipd_internal.h ScanTail) and beyond what a consumer scans for itself (4096)
+    (2500, 60, 300, 0.3, 0.5),    # long rows of Y: the 256-thread row kernel or the tiles, either with a tail
+    (5000, 40, 64, 0.2, 0.9),     # short rows of Y: the one-wave row kernel and a scan launch
 ]
 
 
