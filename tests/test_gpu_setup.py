@@ -275,6 +275,30 @@ def test_hierarchy_bit_exact_block_interpolation(ipd, monkeypatch, name, m, n, m
     h.close()
 
 
+def test_first_and_later_hierarchies_of_a_context(ipd):
+    """The first hierarchy a context builds fetches every entry count as it goes (the counting launches' tails post
+    them); from the second on the counts of a level stay on the device until its last compaction posts them, the
+    arrays are sized by dense bounds and the consumers scan the row counts themselves (csrc/ipd_setup.hip "lazy
+    counts", ipd_internal.h scan_head / ScanTail).  Same bits either way, on a fresh context so that the first
+    build really is one."""
+    from codes_of_ipd_ssn_amg_method_amd import _lib
+    m, n = 300, 260
+    Ae, pd = newton_matrix(m, n, PR.mask_bernoulli(m, n, 0.03, seed=9))
+    lab = sp.csgraph.connected_components(Ae)[1]
+    pk = np.flatnonzero(lab == np.argmax(np.bincount(lab)))
+    Ae = sp.csr_matrix(Ae[pk, :][:, pk])
+    o = O.amg_options_class1("w"); o.update(fnode=int((pk < n).sum()), isnsp=1)
+    ho = O.amg_setup(Ae, o, O.matlab_rng())
+    ctx = _lib.Context(0)
+    for build in range(3):
+        h = ipd.AMGHierarchy(Ae, o, ipd.MatlabRand(), ctx=ctx)
+        assert h.level_sizes() == ho.level_sizes(), build
+        for k in range(2, ho.J + 1):
+            assert csc_equal(h.A(k), ho.Ack[k]), (build, k)
+            assert csc_equal(h.P(k), ho.Prok[k]), (build, k)
+        h.close()
+
+
 @pytest.mark.parametrize("rho", [1.0, 0.4])
 def test_tile_product_matches_row_product(ipd, monkeypatch, rho):
     """At a size where the tile kernel is the default choice, both product kernels give the same
